@@ -1,0 +1,550 @@
+"""CPU oracle: a numpy restatement of the reference's ISS hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``fruits_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` use it, and only as the checker.  Parity is PINNED: every
+function here is checked by ``tests/test_oracle.py`` against golden vectors
+that ``tests/golden/make_golden.py`` produced by running the reference itself
+(irkri/fruits @ 2025-09-05), and against the hand-computed vectors held by the
+reference's own tests.
+
+Each function cites the reference file:line it restates (paths relative to the
+reference root).  The arithmetic is the reference's: same multiply / divide
+order per letter, strictly sequential ``cumsum`` along time, the same shifts.
+The only liberty is vectorisation over the series axis N (the reference loops
+``prange`` over N), which changes no floating-point result.
+"""
+from __future__ import annotations
+
+import itertools
+import re
+
+import numpy as np
+
+# --------------------------------------------------------------------------
+# words
+# --------------------------------------------------------------------------
+
+_WORD_RE = re.compile(r"(\[(-?\d|\(-?\d+\))+\])+")
+
+
+def parse_word(string: str) -> list[list[int]]:
+    """fruits/iss/words/word.py:189-245 (SimpleWord.__init__/multiply).
+
+    ``"[-12][(10)1]"`` -> one row per extended letter; entry d = signed number
+    of occurrences of dimension d+1 (negative = reciprocal power).
+    """
+    if not _WORD_RE.fullmatch(string):
+        raise ValueError("not a simple word: %r" % (string,))
+    rows_raw = []
+    for el in string.split("]")[:-1]:
+        el = el[1:]
+        letters = []
+        j = 0
+        while j < len(el):
+            if el[j] == "(":
+                k = el.index(")", j)
+                letters.append(int(el[j + 1:k]))
+                j = k
+            elif el[j] == "-":
+                letters.append(int(el[j:j + 2]))
+                j += 1
+            else:
+                letters.append(int(el[j]))
+            j += 1
+        rows_raw.append(letters)
+    max_dim = max(abs(x) for r in rows_raw for x in r)
+    rows = []
+    for letters in rows_raw:
+        row = [0] * max_dim
+        for x in set(letters):
+            c = letters.count(x)
+            row[abs(x) - 1] += c if x > 0 else -c
+        rows.append(row)
+    return rows
+
+
+def _partitions_of(n, start=1):
+    # fruits/iss/words/creation.py:8-12
+    yield (n,)
+    for i in range(start, n // 2 + 1):
+        for p in _partitions_of(n - i, i):
+            yield (i,) + p
+
+
+def of_weight_strings(w: int, dim: int = 1, perm_order=None) -> list[str]:
+    """fruits/iss/words/creation.py:26-50.
+
+    The reference iterates ``set(itertools.permutations(partition))`` whose
+    order is an implementation detail of CPython's set; the golden manifest
+    pins the order the reference produced, and the tests compare against it.
+    """
+    letters = []
+    for i in range(1, w + 1):
+        letters.append([
+            "[" + "".join("(%d)" % x if x > 9 else str(x) for x in el) + "]"
+            for el in itertools.combinations_with_replacement(
+                range(1, dim + 1), i)
+        ])
+    out = []
+    for partition in _partitions_of(w):
+        for mixed in set(itertools.permutations(partition)):
+            for raw in itertools.product(*[letters[k - 1] for k in mixed]):
+                out.append("".join(raw))
+    return out
+
+
+def cache_plan(word_strings: list[str]) -> list[int]:
+    """fruits/iss/cache.py:17-37 (CachePlan._create_plan)."""
+    plan = []
+    for i, wstr in enumerate(word_strings):
+        els = wstr.split("[")[1:]
+        start = 0
+        depth = len(els)
+        for j in range(len(els)):
+            prefix = "[" + "[".join(els[:j + 1])
+            for k in range(start, i):
+                if word_strings[k].startswith(prefix):
+                    start = k
+                    depth -= 1
+                    break
+            else:
+                break
+        plan.append(depth)
+    return plan
+
+
+def plan_labels(word_strings: list[str], plan: list[int]) -> list[str]:
+    """fruits/iss/cache.py:55-65 (CachePlan.get_word_string) for every index."""
+    labels = []
+    for wstr, depth in zip(word_strings, plan):
+        parts = wstr.split("]")
+        n = len(parts) - 1
+        for e in range(depth):
+            # is_index runs -depth .. -1 ; slice [:is_index] of the split
+            labels.append("]".join(parts[:e - depth]) + "]")
+        del n
+    return labels
+
+
+# --------------------------------------------------------------------------
+# preparateurs
+# --------------------------------------------------------------------------
+
+def increments(X: np.ndarray, k: int) -> np.ndarray:
+    """fruits/cache.py:8-13 (_increments): out[..., k:] = X[..., k:] - X[..., :-k]."""
+    out = np.zeros(X.shape)
+    out[:, :, k:] = X[:, :, k:] - X[:, :, :-k]
+    return out
+
+
+def inc_transform(X, shift=1, depth=1, zero_padding=True):
+    """fruits/preparation/transform.py:60-75 (INC._transform)."""
+    if isinstance(shift, int):
+        k = shift
+    elif isinstance(shift, float):
+        k = int(np.ceil(shift * X.shape[2]))
+    else:
+        k = int(shift(X.shape[2]))
+    out = X
+    for _ in range(depth):
+        out = increments(out, k)
+        if not zero_padding:
+            out[:, :, :shift] = X[:, :, :shift]
+    return out
+
+
+def std_transform(X, var=True, eps=1e-5):
+    """fruits/preparation/transform.py:141-147 (STD._transform, separately=True)."""
+    mean_ = np.mean(X, axis=2)[:, :, None]
+    std_ = np.ones((X.shape[0], X.shape[1], 1))
+    if var:
+        std_ = np.std(X, axis=2)[:, :, None]
+    return (X - mean_) / (std_ + eps)
+
+
+def new_transform(X, inner):
+    """fruits/preparation/wrapper.py:78-93 (NEW._transform)."""
+    t = X if inner is None else inner(X)
+    out = np.zeros((X.shape[0], X.shape[1] + t.shape[1], X.shape[2]))
+    out[:, :X.shape[1]] = X
+    out[:, X.shape[1]:] = t
+    return out
+
+
+def nrm_rows(R: np.ndarray) -> np.ndarray:
+    """fruits/preparation/transform.py:184-198 (NRM._transform, scale_dim=False)
+    applied to (N, T) rows: (x-min)/(max-min), constant rows -> 0."""
+    mn = R.min(axis=1, keepdims=True)
+    mx = R.max(axis=1, keepdims=True)
+    # zeros_like keeps R's dtype: for the integer range of Indices(relative=False)
+    # the reference therefore truncates to 0/1 (transform.py:195-196) - kept.
+    out = np.zeros_like(R)
+    mask = (mn != mx)[:, 0]
+    out[mask] = (R[mask] - mn[mask]) / (mx[mask] - mn[mask])
+    return out
+
+
+# --------------------------------------------------------------------------
+# weighting lookups
+# --------------------------------------------------------------------------
+
+def l1_sum(X: np.ndarray) -> np.ndarray:
+    """fruits/cache.py:25-31 (_L1_sum): cumsum |increments| of DIMENSION 0."""
+    Y = increments(X, 1)[:, 0, :]
+    return np.cumsum(np.abs(Y), axis=1)
+
+
+def lookup_indices(N, T, relative=True, scale=50.0):
+    """fruits/iss/weighting.py:100-110 (Indices.get_lookup, no transform)."""
+    r = np.arange(1, T + 1)
+    if relative:
+        r = r / T
+    r = nrm_rows(np.asarray(r)[None, :])[0] * scale
+    return np.ones((N, T)) * r
+
+
+def lookup_l1(X_for_l1, relative=False, scale=50.0):
+    """fruits/iss/weighting.py:148-160 (L1.get_lookup, no transform).
+
+    ``X_for_l1`` is the RAW fruit input unless on_prepared=True
+    (fruits/cache.py:108-112 via SharedSeedCache)."""
+    r = l1_sum(X_for_l1)
+    if relative:
+        r = r / (r[:, -1:] + 1e-5)
+    return nrm_rows(r) * scale
+
+
+# --------------------------------------------------------------------------
+# the ISS operator
+# --------------------------------------------------------------------------
+
+def _letters(tmp, Z, el):
+    # fruits/iss/semiring.py:111-117 / :143-149 : repeated multiply / divide
+    for d, occ in enumerate(el):
+        if occ > 0:
+            for _ in range(occ):
+                tmp = tmp * Z[:, d, :]
+        elif occ < 0:
+            for _ in range(-occ):
+                tmp = tmp / Z[:, d, :]
+    return tmp
+
+
+def _shift(tmp):
+    # np.roll(tmp, 1); tmp[0] = 0   (semiring.py:109-110, :155-156)
+    out = np.empty_like(tmp)
+    out[:, 1:] = tmp[:, :-1]
+    out[:, 0] = 0
+    return out
+
+
+def iterated_sum_fast(Z, word, alpha, lookup, extended, total_weighting):
+    """fruits/iss/semiring.py:167-201 (Reals._iterated_sum_fast) with its two
+    per-series bodies ``_total_weighted_reals_single`` (:128-158) and
+    ``_reals_single`` (:93-125), vectorised over N.
+
+    Z (N,D,T) f8, word (L,Dw) i4, alpha (L,) f4, lookup (N,T) f8 -> (N,E,T)."""
+    N, _, T = Z.shape
+    L = len(word)
+    word = np.asarray(word, dtype=np.int32).reshape(L, -1)
+    alpha = np.asarray(alpha, dtype=np.float32)
+    out = np.zeros((N, extended, T))
+    tmp = np.ones((N, T))
+    # the reference indexes lookup[j] for j < N (semiring.py:185-199): a lookup
+    # with more rows than Z (fit on a sub-sample, see fruit_fit) is cut by position
+    lookup = lookup[:N]
+    if total_weighting:
+        for k in range(L):
+            tmp = _letters(tmp, Z, word[k])
+            tmp = tmp * np.exp(lookup * alpha[k])
+            tmp = np.cumsum(tmp, axis=1)
+            if L - k <= extended:
+                out[:, extended - (L - k), :] = tmp * np.exp(-lookup * alpha[k])
+            if k < L - 1:
+                tmp = _shift(tmp)
+                tmp = tmp * np.exp(-lookup * alpha[k])
+    else:
+        for k in range(L):
+            if k > 0:
+                tmp = _shift(tmp)
+            tmp = _letters(tmp, Z, word[k])
+            if k > 0:
+                tmp = tmp * np.exp(-lookup * alpha[k - 1])
+            if L - k <= extended:
+                out[:, extended - (L - k), :] = np.cumsum(tmp, axis=1)
+            if k < L - 1:
+                tmp = tmp * np.exp(lookup * alpha[k])
+                tmp = np.cumsum(tmp, axis=1)
+    return out
+
+
+def iterated_sums(Z, word_rows, alpha=None, lookup=None, extended=1, total=False):
+    """fruits/iss/semiring.py:14-41 (Semiring.iterated_sums) for a SimpleWord:
+    no weighting => zero alpha, zero lookup, total=True (:27-28, :35)."""
+    L = len(word_rows)
+    if lookup is None:
+        alpha_ = np.zeros((L,), dtype=np.float32)
+        lookup_ = np.zeros((Z.shape[0], Z.shape[2]))
+        total_ = True
+    else:
+        alpha_ = (np.ones((L,), dtype=np.float32) if alpha is None
+                  else np.asarray(alpha, dtype=np.float32))
+        lookup_ = lookup
+        total_ = total
+    return iterated_sum_fast(Z, np.array(word_rows, dtype=np.int32), alpha_,
+                             lookup_, extended, total_)
+
+
+def iss_transform(X, word_strings, mode="SINGLE", alphas=None, lookup=None,
+                  total=False):
+    """fruits/iss/iss.py:21-67 (_calculate_ISS, one batch of all words)
+    -> (K, N, T) in the reference's row order."""
+    X = np.asarray(X, dtype=np.float64)
+    if mode == "EXTENDED":
+        plan = cache_plan(word_strings)
+    else:
+        plan = [1] * len(word_strings)
+    K = sum(plan)
+    out = np.zeros((K, X.shape[0], X.shape[2]))
+    idx = 0
+    for i, s in enumerate(word_strings):
+        rows = parse_word(s)
+        a = None if alphas is None else alphas[i]
+        r = iterated_sums(X, rows, a, lookup, plan[i], total)
+        out[idx:idx + plan[i]] = np.swapaxes(r, 0, 1)
+        idx += plan[i]
+    return out
+
+
+# --------------------------------------------------------------------------
+# sieves
+# --------------------------------------------------------------------------
+
+def coquantile_cuts(X_raw, q, norm="L2"):
+    """fruits/cache.py:16-22,34-40 (_coquantile over _L1_sum/_L2_sum of dim 0)."""
+    Y = increments(X_raw, 1)[:, 0, :]
+    s = np.cumsum(np.abs(Y) if norm == "L1" else Y * Y, axis=1)
+    return np.sum(s <= q * s[:, -1:], axis=1).astype(np.int64)
+
+
+def transformed_cuts(N, T, cut, X_raw=None, norm="L2"):
+    """fruits/sieving/segment.py:51-64 (_get_transformed_cuts)."""
+    cut = tuple(cut) if isinstance(cut, (list, tuple)) else (cut,)
+    new = np.zeros((N, len(cut) + 1))
+    for i, c in enumerate(cut):
+        if isinstance(c, float):
+            new[:, i + 1] = coquantile_cuts(X_raw, c, norm)
+        else:
+            new[:, i + 1] = c if c >= 0 else T + c + 1
+    return np.sort(new).astype(np.int64)
+
+
+def fit_quantiles(q, sample=None):
+    """fruits/sieving/segment.py:66-85 (_fit / _get_unfitted_quantiles)."""
+    qs = np.zeros(len(q))
+    fitted = False
+    for i, v in enumerate(q):
+        if v == 1.0:
+            qs[i] = np.inf
+        elif v == -1.0:
+            qs[i] = -np.inf
+        elif v != 0:
+            if sample is None:
+                raise RuntimeError("Sieve has not been fitted properly")
+            qs[i] = np.quantile(sample, v)
+            fitted = True
+    if fitted or sample is not None:
+        qs = np.sort(qs)
+    return qs
+
+
+def requires_fitting(q):
+    """fruits/sieving/segment.py:44-49."""
+    return any(v not in (-1, 0, 1) for v in q)
+
+
+def pre_transform(A, inc):
+    """fruits/sieving/increment.py:63-71 (IncrementSieve._pre_transform)."""
+    arr = A.copy()
+    if inc > 0:
+        for _ in range(inc):
+            arr = increments(arr[:, None, :], 1)[:, 0, :]
+    elif inc < 0:
+        for _ in range(-inc):
+            arr = np.cumsum(arr, axis=1)
+    return arr
+
+
+def npi_backend(A, cuts, quantiles):
+    """fruits/sieving/increment.py:107-129 (NPI._backend)."""
+    N = A.shape[0]
+    C, Q = cuts.shape[1] - 1, len(quantiles) - 1
+    out = np.zeros((N, C * Q))
+    for i in range(N):
+        for j in range(C):
+            seg = A[i, cuts[i, j]:cuts[i, j + 1]]
+            for k in range(Q):
+                out[i, j * Q + k] = np.sum(
+                    np.logical_and(quantiles[k] < seg, seg <= quantiles[k + 1]))
+    return out
+
+
+def mpi_backend(A, cuts, quantiles):
+    """fruits/sieving/increment.py:138-163 (MPI._backend)."""
+    N = A.shape[0]
+    C, Q = cuts.shape[1] - 1, len(quantiles) - 1
+    out = np.zeros((N, C * Q))
+    for i in range(N):
+        for j in range(C):
+            seg = A[i, cuts[i, j]:cuts[i, j + 1]]
+            for k in range(Q):
+                sel = seg[np.logical_and(quantiles[k] < seg,
+                                         seg <= quantiles[k + 1])]
+                out[i, j * Q + k] = 0 if sel.size == 0 else np.mean(sel)
+    return out
+
+
+def end_transform(A, cuts):
+    """fruits/sieving/segment.py:210-219 (END._transform)."""
+    out = np.zeros((A.shape[0], cuts.shape[1] - 1))
+    for j in range(cuts.shape[1] - 1):
+        out[:, j] = np.take_along_axis(A, cuts[:, j + 1:j + 2] - 1, axis=1)[:, 0]
+    return out
+
+
+class SieveOracle:
+    """One sieve (NPI / MPI / END) with the reference's fit/transform contract
+    (fruits/sieving/segment.py:14-104, increment.py:14-98)."""
+
+    def __init__(self, kind, cut=-1, q=None, inc=1, coquantile_norm="L2"):
+        self.kind = kind
+        self.cut = tuple(cut) if isinstance(cut, (list, tuple)) else (cut,)
+        if kind in ("NPI", "MPI"):
+            self.q = tuple(q) if q is not None else (0.0, 1.0)
+        else:
+            self.q = tuple(q) if q is not None else (-1.0, 1.0)
+        self.inc = inc if kind in ("NPI", "MPI") else 0
+        self.norm = coquantile_norm
+        self.quantiles = None
+
+    def nfeatures(self):
+        return len(self.cut) * (len(self.q) - 1)
+
+    def copy(self):
+        return SieveOracle(self.kind, self.cut, self.q, self.inc, self.norm)
+
+    def fit(self, A):
+        self.quantiles = fit_quantiles(self.q, pre_transform(A, self.inc))
+
+    def transform(self, A, X_raw=None):
+        if self.kind == "END":
+            cuts = transformed_cuts(A.shape[0], A.shape[1], self.cut, X_raw,
+                                    self.norm)
+            return end_transform(A, cuts)
+        if not requires_fitting(self.q):
+            self.quantiles = fit_quantiles(self.q)
+        arr = pre_transform(A, self.inc)
+        cuts = transformed_cuts(A.shape[0], A.shape[1], self.cut, X_raw,
+                                self.norm)
+        fn = npi_backend if self.kind == "NPI" else mpi_backend
+        return fn(arr, cuts, self.quantiles)
+
+
+# --------------------------------------------------------------------------
+# whole pipeline (the spec format of tests/golden/golden.json "fruit" cases)
+# --------------------------------------------------------------------------
+
+def _apply_preps(X, preps):
+    for p in preps:
+        kind = p["kind"]
+        if kind == "INC":
+            X = inc_transform(X, p.get("shift", 1), p.get("depth", 1),
+                              p.get("zero_padding", True))
+        elif kind == "STD":
+            X = std_transform(X, p.get("var", True), p.get("std_eps", 1e-5))
+        elif kind == "NEW":
+            inner = p.get("inner")
+            fn = None if inner is None else (
+                lambda Y, inner=inner: _apply_preps(Y, [inner]))
+            X = new_transform(X, fn)
+        else:
+            raise NotImplementedError(kind)
+    return X
+
+
+def _weight_lookup(spec, X_prepared, X_raw):
+    if spec is None:
+        return None, False
+    kind = spec["kind"]
+    total = spec.get("total", False)
+    scale = spec.get("scale", 50)
+    if kind == "Indices":
+        return lookup_indices(X_prepared.shape[0], X_prepared.shape[2],
+                              spec.get("relative", True), scale), total
+    if kind == "L1":
+        src = X_prepared if spec.get("on_prepared", False) else X_raw
+        return lookup_l1(src, spec.get("relative", False), scale), total
+    raise NotImplementedError(kind)
+
+
+def _iterate_iss(X, iss_list, X_raw, idx=0):
+    """fruits/fruit.py:440-454 (_iterate_iss): chained ISS, one (N,T) at a time."""
+    if idx == len(iss_list):
+        yield X[:, 0, :]
+        return
+    i = iss_list[idx]
+    lookup, total = _weight_lookup(i.get("weighting"), X, X_raw)
+    its = iss_transform(X, i["words"], i["mode"], i.get("alphas"), lookup, total)
+    for itsum in its:
+        yield from _iterate_iss(itsum[:, None, :], iss_list, X_raw, idx + 1)
+
+
+def _make_sieves(slice_spec):
+    out = []
+    for s in slice_spec["sieves"]:
+        kw = {k: v for k, v in s.items() if k != "kind"}
+        out.append(SieveOracle(s["kind"], **kw))
+    return out
+
+
+def fruit_fit(spec, X, np_seed=None):
+    """fruits/fruit.py:121-136, 456-496 (Fruit.fit / FruitSlice.fit)."""
+    if np_seed is not None:
+        np.random.seed(np_seed)
+    fitted = []
+    for sl in spec["slices"]:
+        fss = sl.get("fit_sample_size", 1)
+        if isinstance(fss, int) and fss == 1:
+            ind = np.random.randint(0, X.shape[0])
+            sample_raw = X[ind:ind + 1]
+        else:
+            s = max(int(fss * X.shape[0]), 1)
+            sample_raw = X[np.random.choice(X.shape[0], size=s, replace=False)]
+        sample = _apply_preps(sample_raw, sl.get("preps", []))
+        sieves = _make_sieves(sl)
+        ext = []
+        if any(requires_fitting(s.q) for s in sieves):
+            # NB: the L1 lookup during fit uses the fruit-level cache, i.e. the
+            # FULL raw input X (fruits/fruit.py:132-135, cache.py:98-112).
+            for itsum in _iterate_iss(sample, sl["iss"], X):
+                cp = [s.copy() for s in sieves]
+                for s in cp:
+                    s.fit(itsum)
+                ext.append(cp)
+        fitted.append((sieves, ext))
+    return fitted
+
+
+def fruit_transform(spec, fitted, X):
+    """fruits/fruit.py:138-173, 498-553 (Fruit.transform / FruitSlice.transform)."""
+    blocks = []
+    for sl, (sieves, ext) in zip(spec["slices"], fitted):
+        P = _apply_preps(X, sl.get("preps", []))
+        cols = []
+        for i, itsum in enumerate(_iterate_iss(P, sl["iss"], X)):
+            for s in (ext[i] if ext else sieves):
+                cols.append(s.transform(itsum, X))
+        blocks.append(np.concatenate(cols, axis=1))
+    res = np.concatenate(blocks, axis=1)
+    return np.nan_to_num(res, copy=False, nan=0.0)

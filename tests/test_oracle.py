@@ -1,0 +1,108 @@
+"""The oracle (oracle/ref_numpy.py) pinned against vectors produced by the
+reference itself (tests/golden/make_golden.py) and the hand-computed vectors of
+the reference's own tests."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import ref_numpy as orc
+
+G = load_golden()
+RT = dict(rtol=1e-12, atol=1e-12)
+
+
+def _lookup(case, X, X_raw=None):
+    return orc._weight_lookup(case.get("weighting"), X, X if X_raw is None else X_raw)
+
+
+def test_x1_hand_computed():
+    # reference tests/signature/test_simple.py:11-34
+    out = orc.iss_transform(G["X_1"], ["[1]", "[2]", "[11]", "[12]", "[1][1]", "[1][2]"])
+    np.testing.assert_allclose(out, G["iss/x1_six_words_expected"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("key", sorted(G.manifest["words"]))
+def test_of_weight_and_plan(key):
+    w, d = map(int, key.split(","))
+    ent = G.manifest["words"][key]
+    mine = orc.of_weight_strings(w, d)
+    assert sorted(mine) == sorted(ent["words"])
+    assert mine == ent["words"]          # same CPython set order here
+    assert orc.cache_plan(ent["words"]) == ent["plan"]
+    assert [orc.parse_word(s) for s in ent["words"]] == ent["exps"]
+
+
+def test_cache_plan_golden():
+    for ent in G.manifest["cacheplan"]:
+        plan = orc.cache_plan(ent["words"])
+        assert plan == ent["plan"]
+        assert orc.plan_labels(ent["words"], plan) == ent["labels"]
+    assert G.manifest["cacheplan"][0]["plan"] == [4, 5, 2, 3, 3, 1, 1, 1, 2]
+
+
+def test_parse():
+    for s, rows in G.manifest["parse"].items():
+        assert orc.parse_word(s) == rows
+    with pytest.raises(ValueError):
+        orc.parse_word("[1][")
+
+
+@pytest.mark.parametrize("case", G.cases("iss"), ids=lambda c: c["name"])
+def test_iss_cases(case):
+    X = G.x_of(case)
+    lookup, total = _lookup(case, X)
+    out = orc.iss_transform(X, case["words"], case["mode"], case["alphas"],
+                            lookup, total)
+    assert out.shape[0] == case["K"]
+    if "series" in case:
+        out = out[:, case["series"], :]
+    np.testing.assert_allclose(out, G[case["out"]], **RT)
+
+
+def test_operator_entry():
+    Z = G["U_6_3_40"]
+    word = np.array(orc.parse_word("[12][2][33]"), dtype=np.int32)
+    alpha = np.array([.6, .2, .5], dtype=np.float32)
+    lk = orc.lookup_indices(6, 40, True, 2.0)
+    np.testing.assert_allclose(lk, G["op/lookup"], **RT)
+    np.testing.assert_allclose(
+        orc.iterated_sum_fast(Z, word, alpha, lk, 2, False),
+        G["op/fast_nontotal_E2"], **RT)
+    np.testing.assert_allclose(
+        orc.iterated_sum_fast(Z, word, alpha, lk, 3, True),
+        G["op/fast_total_E3"], **RT)
+
+
+@pytest.mark.parametrize("case", G.cases("l1"), ids=lambda c: c["name"])
+def test_l1_lookup(case):
+    kw = case["kw"]
+    out = orc.lookup_l1(G[case["x"]], kw.get("relative", False), kw.get("scale", 50))
+    np.testing.assert_allclose(out, G[case["out"]], **RT)
+
+
+@pytest.mark.parametrize("case", G.cases("inc"), ids=lambda c: c["name"])
+def test_inc(case):
+    out = orc.inc_transform(G[case["x"]], **case["kw"])
+    np.testing.assert_allclose(out, G[case["out"]], **RT)
+
+
+@pytest.mark.parametrize("case", G.cases("sieve"), ids=lambda c: c["name"])
+def test_sieves(case):
+    sv = orc.SieveOracle(case["kind"], **case["kw"])
+    A = G[case["x"]]
+    sv.fit(G[case["fit"]] if case["fit"] else A)
+    out = sv.transform(A)
+    np.testing.assert_allclose(out, G[case["out"]], **RT)
+
+
+@pytest.mark.parametrize("case", G.cases("fruit"), ids=lambda c: c["name"])
+def test_fruit(case):
+    X = G[case["x"]]
+    fitted = orc.fruit_fit(case["spec"], X, case["np_seed"])
+    out = orc.fruit_transform(case["spec"], fitted, X)
+    assert out.shape[1] == case["nfeatures"]
+    np.testing.assert_allclose(out, G[case["out"]], **RT)
+    if "x_test" in case:
+        np.testing.assert_allclose(
+            orc.fruit_transform(case["spec"], fitted, G[case["x_test"]]),
+            G[case["out_test"]], **RT)
