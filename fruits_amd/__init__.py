@@ -1,0 +1,14 @@
+"""fruits_amd - the FRUITS iterated-sums hot path on AMD MI355X (gfx950).
+
+Same public surface as the reference package for the path
+``INC -> ISS (Reals, SimpleWords, optional Indices / L1 weighting) -> NPI / END``
+(plus NEW, STD and MPI): ``fruits_amd.ISS(...).fit_transform(X)`` and
+``fruits_amd.Fruit.fit / transform``.  All arithmetic runs in hand-written HIP
+kernels behind the C ABI of ``include/fruits_hip.h``; there is no CPU fallback.
+"""
+from . import cache, callback, iss, preparation, seed, sieving
+from .fruit import Fruit, FruitSlice
+from .iss import semiring, words
+from .iss.iss import ISS, ISSMode
+
+__version__ = "0.1.0"

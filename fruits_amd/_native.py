@@ -1,0 +1,332 @@
+"""ctypes binding of libfruits_hip.so (the C ABI of include/fruits_hip.h).
+
+This is the only door between the Python host code and the HIP kernels.  There
+is NO CPU fallback: if the library is missing or no HIP device is present every
+compute entry raises.  PyTorch is used for plumbing only - device memory
+(``torch.empty(..., device="cuda")``), the current HIP stream and, in
+``fruits_amd.parallel``, ``torch.distributed``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfruits_hip.so")
+
+FR_W_NONE, FR_W_NONTOTAL, FR_W_TOTAL = 0, 1, 2
+FR_SIEVE_NPI, FR_SIEVE_MPI, FR_SIEVE_END = 0, 1, 2
+(FR_INFO_ROWS, FR_INFO_NODES, FR_INFO_LEVELS, FR_INFO_DIMS_USED, FR_INFO_MAX_DIM,
+ FR_INFO_ALPHAS, FR_INFO_GROUPS, FR_INFO_SHARED) = range(8)
+FR_E_ARG, FR_E_DIM, FR_E_HIP, FR_E_NOMEM, FR_E_LIMIT = -1, -2, -3, -4, -5
+
+EXPORTS = [
+    "fr_last_error", "fr_version", "fr_device_count", "fr_malloc", "fr_free",
+    "fr_memcpy_h2d", "fr_memcpy_d2h", "fr_stream_sync", "fr_plan_create",
+    "fr_plan_destroy", "fr_plan_info", "fr_plan_dump", "fr_plan_workspace_bytes",
+    "fr_iss_run", "fr_iterated_sum_fast_host", "fr_increments",
+    "fr_pathlen_lookup", "fr_sieve", "fr_pre_transform", "fr_standardize",
+]
+
+_lib = None
+_torch = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def torch():
+    """torch is imported before the library so both share ONE HIP runtime
+    (torch bundles libamdhip64.so.7; the loader resolves our DT_NEEDED entry to
+    the copy that is already mapped)."""
+    global _torch
+    if _torch is None:
+        import torch as _t
+        _torch = _t
+    return _torch
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            "fruits_amd/libfruits_hip.so is missing - build it with "
+            "`python -m fruits_amd.build` (hipcc, gfx950). There is no CPU fallback.")
+    torch()
+    L = C.CDLL(LIB_PATH)
+    L.fr_last_error.restype = C.c_char_p
+    L.fr_plan_create.restype = C.c_void_p
+    L.fr_plan_destroy.restype = None
+    L.fr_plan_destroy.argtypes = [C.c_void_p]
+    L.fr_plan_info.restype = C.c_int64
+    L.fr_plan_info.argtypes = [C.c_void_p, C.c_int32]
+    L.fr_plan_dump.restype = C.c_int32
+    L.fr_plan_workspace_bytes.restype = C.c_int64
+    L.fr_plan_workspace_bytes.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().fr_last_error().decode()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc >= 0:
+        return
+    msg = last_error()
+    if rc == FR_E_DIM:
+        raise IndexError(msg)
+    if rc in (FR_E_ARG, FR_E_LIMIT):
+        raise ValueError(msg)
+    if rc == FR_E_NOMEM:
+        raise MemoryError(msg)
+    raise NativeError(f"{what}: {msg}" if what else msg)
+
+
+def device_count() -> int:
+    return int(lib().fr_device_count())
+
+
+def require_device():
+    """Returns the torch device to run on; raises when there is no GPU."""
+    t = torch()
+    if not t.cuda.is_available() or device_count() == 0:
+        raise NativeError(
+            "fruits_amd needs a HIP device (MI355X / gfx950); none is visible and "
+            "there is deliberately no CPU fallback")
+    return t.device("cuda", t.cuda.current_device())
+
+
+def stream_ptr() -> C.c_void_p:
+    return C.c_void_p(torch().cuda.current_stream().cuda_stream)
+
+
+def dptr(t) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def to_device(arr, dtype=None):
+    """numpy (or torch) -> contiguous device tensor (float64 unless given)."""
+    t = torch()
+    dev = require_device()
+    if isinstance(arr, t.Tensor):
+        x = arr.to(device=dev)
+        if dtype is not None:
+            x = x.to(dtype)
+        return x.contiguous()
+    a = np.ascontiguousarray(arr, dtype=dtype or np.float64)
+    return t.from_numpy(a).to(dev)
+
+
+def to_host(x) -> np.ndarray:
+    return x.detach().cpu().numpy()
+
+
+# ----------------------------------------------------------------------- plan
+class Plan:
+    """Compiled device program of a word list (fr_plan_create)."""
+
+    def __init__(self, words: Sequence[np.ndarray], depths: Sequence[int],
+                 alphas: Optional[Sequence[np.ndarray]] = None, weighting: int = FR_W_NONE,
+                 share_prefixes: bool = True):
+        L = lib()
+        self._h = None
+        mats = [np.ascontiguousarray(w, dtype=np.int32) for w in words]
+        for m in mats:
+            if m.ndim != 2:
+                raise ValueError("word tables must be (L, Dw) int32")
+        W = len(mats)
+        exps = (np.concatenate([m.ravel() for m in mats]) if W else
+                np.zeros(0, np.int32)).astype(np.int32)
+        Ls = np.array([m.shape[0] for m in mats], dtype=np.int32)
+        Dws = np.array([m.shape[1] for m in mats], dtype=np.int32)
+        dep = np.asarray(depths, dtype=np.int32)
+        if dep.shape != (W,):
+            raise ValueError("one depth per word")
+        al = None
+        if weighting != FR_W_NONE:
+            if alphas is None:
+                raise ValueError("weighted plan needs alphas")
+            al = np.concatenate([np.asarray(a, dtype=np.float32).ravel()
+                                 for a in alphas]).astype(np.float32)
+            if al.size != int(Ls.sum()):
+                raise ValueError("Size of alpha array does not match word length")
+        ip = C.POINTER(C.c_int32)
+        h = L.fr_plan_create(
+            C.c_int32(W), exps.ctypes.data_as(ip), Ls.ctypes.data_as(ip),
+            Dws.ctypes.data_as(ip),
+            al.ctypes.data_as(C.POINTER(C.c_float)) if al is not None else None,
+            dep.ctypes.data_as(ip), C.c_int32(weighting),
+            C.c_int32(1 if share_prefixes else 0))
+        if not h:
+            raise ValueError(last_error())
+        self._h = C.c_void_p(h)
+        self.weighting = weighting
+        self.n_words = W
+
+    def __del__(self):
+        try:
+            if self._h is not None and _lib is not None:
+                _lib.fr_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def info(self, what: int) -> int:
+        return int(lib().fr_plan_info(self._h, C.c_int32(what)))
+
+    @property
+    def rows(self) -> int:
+        return self.info(FR_INFO_ROWS)
+
+    @property
+    def nodes(self) -> int:
+        return self.info(FR_INFO_NODES)
+
+    @property
+    def max_dim(self) -> int:
+        return self.info(FR_INFO_MAX_DIM)
+
+    @property
+    def dims_used(self) -> int:
+        return self.info(FR_INFO_DIMS_USED)
+
+    def dump(self) -> np.ndarray:
+        n = self.nodes
+        buf = np.zeros((max(n, 1), 8), dtype=np.int32)
+        got = lib().fr_plan_dump(self._h, buf.ctypes.data_as(C.POINTER(C.c_int32)),
+                                 C.c_int32(buf.size))
+        return buf[:got]
+
+    def workspace_bytes(self, N: int, T: int, lookup_rows: int) -> int:
+        return int(lib().fr_plan_workspace_bytes(self._h, N, T, lookup_rows))
+
+    def run(self, Xd, lookup_d=None, out=None, layout: str = "KNT", groups: int = 0,
+            work=None):
+        """Launches the trie walk on the current stream.
+
+        Xd (N,D,T) f64 cuda; lookup_d (1|N, T) f64 cuda or None.
+        layout "KNT" -> (K,N,T) (fruits/iss/iss.py:46), "NKT" -> (N,K,T)
+        (fruits/iss/semiring.py:177)."""
+        t = torch()
+        if Xd.dtype != t.float64 or Xd.dim() != 3 or not Xd.is_contiguous():
+            raise TypeError("X must be a contiguous float64 (N, D, T) device tensor")
+        N, D, T = Xd.shape
+        K = self.rows
+        if out is None:
+            shape = (K, N, T) if layout == "KNT" else (N, K, T)
+            out = t.empty(shape, dtype=t.float64, device=Xd.device)
+        if layout == "KNT":
+            sk, sn = N * T, T
+        else:
+            sk, sn = T, K * T
+        rows = 0
+        if self.weighting != FR_W_NONE:
+            if lookup_d is None:
+                raise ValueError("weighted plan needs a lookup")
+            rows = int(lookup_d.shape[0])
+            if lookup_d.shape[-1] != T or not lookup_d.is_contiguous():
+                raise ValueError("lookup must be contiguous (1|N, T)")
+        wb = self.workspace_bytes(N, T, rows)
+        if wb > 0 and (work is None or work.numel() < wb):
+            work = t.empty(wb, dtype=t.uint8, device=Xd.device)
+        rc = lib().fr_iss_run(
+            self._h, dptr(Xd), C.c_int64(N), C.c_int64(D), C.c_int64(T),
+            dptr(lookup_d if self.weighting != FR_W_NONE else None), C.c_int64(rows),
+            dptr(out), C.c_int64(sk), C.c_int64(sn), dptr(work if wb > 0 else None),
+            C.c_int64(wb), C.c_int32(groups), stream_ptr())
+        check(rc, "fr_iss_run")
+        return out
+
+
+# ----------------------------------------------------------------------- kernels
+def iterated_sum_fast_host(Z, word, alpha, lookup, extended, total_weighting):
+    """fr_iterated_sum_fast_host: host arrays in / out (the literal drop-in of
+    Semiring.iterated_sum_fast, fruits/iss/semiring.py:43-52)."""
+    require_device()
+    Z = np.ascontiguousarray(Z, dtype=np.float64)
+    word = np.ascontiguousarray(word, dtype=np.int32)
+    N, D, T = Z.shape
+    Lw, Dw = word.shape
+    out = np.zeros((N, int(extended), T))
+    al = None if alpha is None else np.ascontiguousarray(alpha, dtype=np.float32)
+    lk = None if lookup is None else np.ascontiguousarray(lookup, dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    rc = lib().fr_iterated_sum_fast_host(
+        Z.ctypes.data_as(dp), C.c_int64(N), C.c_int64(D), C.c_int64(T),
+        word.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(Lw), C.c_int32(Dw),
+        al.ctypes.data_as(C.POINTER(C.c_float)) if al is not None else None,
+        lk.ctypes.data_as(dp) if lk is not None else None, C.c_int64(int(extended)),
+        C.c_int32(1 if total_weighting else 0), out.ctypes.data_as(dp))
+    check(rc, "fr_iterated_sum_fast_host")
+    return out
+
+
+def increments(Xd, shift: int, head_src=None, head: int = 0, out=None):
+    t = torch()
+    if out is None:
+        out = t.empty_like(Xd)
+    T = Xd.shape[-1]
+    rows = Xd.numel() // T if T else 0
+    rc = lib().fr_increments(dptr(Xd), C.c_int64(rows), C.c_int64(T), C.c_int64(shift),
+                             dptr(out), dptr(head_src), C.c_int64(head), stream_ptr())
+    check(rc, "fr_increments")
+    return out
+
+
+def pathlen_lookup(Xd, norm: int = 1, relative: int = 0, scale: float = 50.0):
+    """relative: 0 plain, 1 divide by (last + 1e-5) first, 2 = raw cumulative
+    path length without normalisation (the SharedSeedCache entry)."""
+    t = torch()
+    N, D, T = Xd.shape
+    out = t.empty((N, T), dtype=t.float64, device=Xd.device)
+    rc = lib().fr_pathlen_lookup(dptr(Xd), C.c_int64(N), C.c_int64(D), C.c_int64(T),
+                                 C.c_int32(norm), C.c_int32(relative), C.c_double(scale),
+                                 dptr(out), stream_ptr())
+    check(rc, "fr_pathlen_lookup")
+    return out
+
+
+def sieve(kind: int, Ad, inc: int, cuts_d, q_d, out, out_col: int = 0):
+    """Writes the features of one sieve on a (N, T) device array into columns
+    [out_col, out_col + nfeatures) of the (N, F) device tensor ``out``."""
+    N, T = Ad.shape
+    C1 = int(cuts_d.shape[1])
+    Q1 = int(q_d.numel()) if q_d is not None else 0
+    base = out.data_ptr() + 8 * out_col
+    rc = lib().fr_sieve(C.c_int32(kind), dptr(Ad), C.c_int64(N), C.c_int64(T),
+                        C.c_int64(Ad.stride(0)), C.c_int32(inc), dptr(cuts_d),
+                        C.c_int64(cuts_d.shape[0]), C.c_int32(C1), dptr(q_d), C.c_int32(Q1),
+                        C.c_void_p(base), C.c_int64(out.stride(0)), stream_ptr())
+    check(rc, "fr_sieve")
+    return out
+
+
+def pre_transform(Ad, inc: int):
+    """IncrementSieve._pre_transform for inc >= 0 on a (N, T) device array."""
+    t = torch()
+    out = t.empty_like(Ad)
+    N, T = Ad.shape
+    rc = lib().fr_pre_transform(dptr(Ad), C.c_int64(N), C.c_int64(T), C.c_int64(Ad.stride(0)),
+                                C.c_int32(inc), dptr(out), stream_ptr())
+    check(rc, "fr_pre_transform")
+    return out
+
+
+def standardize(Xd, div_std: bool, eps: float):
+    t = torch()
+    out = t.empty_like(Xd)
+    T = Xd.shape[-1]
+    rows = Xd.numel() // T if T else 0
+    rc = lib().fr_standardize(dptr(Xd), C.c_int64(rows), C.c_int64(T),
+                              C.c_int32(1 if div_std else 0), C.c_double(eps), dptr(out),
+                              stream_ptr())
+    check(rc, "fr_standardize")
+    return out

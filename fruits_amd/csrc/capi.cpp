@@ -1,0 +1,401 @@
+// C ABI of libfruits_hip.so (see include/fruits_hip.h for the contract and the
+// reference interfaces each entry point replaces).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fruits_hip.h"
+#include "kernels.h"
+#include "plan.h"
+
+struct fr_plan {
+  fr::Plan *p;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+int hip_fail(hipError_t e, const char *what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return FR_E_HIP;
+}
+
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t e_ = (expr);                             \
+    if (e_ != hipSuccess) return hip_fail(e_, #expr);   \
+  } while (0)
+
+int env_int(const char *name, int dflt) {
+  const char *v = std::getenv(name);
+  return v && *v ? std::atoi(v) : dflt;
+}
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Uploads the node order for G groups once per plan (allocates: call
+// fr_plan_prepare before graph capture).
+int ensure_device_program(fr::Plan &p, fr::GroupedProgram &gp) {
+  if (gp.d_blob) return FR_OK;
+  const size_t n_nodes = gp.nodes.size();
+  size_t off = 0;
+  const size_t o_nodes = off;       off = align_up(off + n_nodes * sizeof(fr::NodeDesc), 64);
+  const size_t o_ids = off;         off = align_up(off + n_nodes * 4, 64);
+  const size_t o_gb = off;          off = align_up(off + gp.group_begin.size() * 4, 64);
+  const size_t o_fac = off;         off = align_up(off + p.factors.size() * 4, 64);
+  const size_t o_emit = off;        off = align_up(off + p.emit_rows.size() * 4, 64);
+  const size_t o_rows = off;        off = align_up(off + p.row_src.size() * 4, 64);
+  const size_t o_alpha = off;       off = align_up(off + p.alphas.size() * 4, 64);
+  std::vector<char> host(off + 64, 0);
+  std::memcpy(host.data() + o_nodes, gp.nodes.data(), n_nodes * sizeof(fr::NodeDesc));
+  std::memcpy(host.data() + o_ids, gp.node_ids.data(), n_nodes * 4);
+  std::memcpy(host.data() + o_gb, gp.group_begin.data(), gp.group_begin.size() * 4);
+  std::memcpy(host.data() + o_fac, p.factors.data(), p.factors.size() * 4);
+  std::memcpy(host.data() + o_emit, p.emit_rows.data(), p.emit_rows.size() * 4);
+  std::memcpy(host.data() + o_rows, p.row_src.data(), p.row_src.size() * 4);
+  std::memcpy(host.data() + o_alpha, p.alphas.data(), p.alphas.size() * 4);
+  void *d = nullptr;
+  HIP_TRY(hipMalloc(&d, host.size()));
+  hipError_t e = hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    return hip_fail(e, "hipMemcpy(program)");
+  }
+  char *b = static_cast<char *>(d);
+  gp.d_blob = d;
+  gp.d_nodes = reinterpret_cast<const fr::NodeDesc *>(b + o_nodes);
+  gp.d_node_ids = reinterpret_cast<const int32_t *>(b + o_ids);
+  gp.d_group_begin = reinterpret_cast<const int32_t *>(b + o_gb);
+  gp.d_factors = reinterpret_cast<const int32_t *>(b + o_fac);
+  gp.d_emit_rows = reinterpret_cast<const int32_t *>(b + o_emit);
+  gp.d_row_src = reinterpret_cast<const int32_t *>(b + o_rows);
+  gp.d_alphas = reinterpret_cast<const float *>(b + o_alpha);
+  return FR_OK;
+}
+
+int choose_groups(const fr::Plan &p, int64_t N, int requested) {
+  const int U = p.units();
+  if (U <= 1) return 1;
+  int G = requested;
+  if (G <= 0) G = env_int("FRUITS_HIP_GROUPS", 0);
+  if (G <= 0) {
+    // aim for a few thousand workgroups (256 CUs x several resident each)
+    const int64_t target = 4096;
+    G = (int)((target + N - 1) / (N > 0 ? N : 1));
+  }
+  if (G > U) G = U;
+  if (G < 1) G = 1;
+  return G;
+}
+
+struct WorkLayout {
+  size_t aux_bytes = 0, carry_bytes = 0;
+  size_t total() const { return aux_bytes + carry_bytes; }
+};
+
+WorkLayout work_layout(const fr::Plan &p, int64_t N, int64_t T, int64_t lookup_rows) {
+  WorkLayout w;
+  if (p.weighting != 0)
+    w.aux_bytes = align_up((size_t)(2 * p.alphas.size()) * (size_t)lookup_rows * (size_t)T * 8, 256);
+  if (T > fr::walk_chunk_elems(T))
+    w.carry_bytes = align_up((size_t)N * 2 * p.nodes.size() * 8, 256);
+  return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *fr_last_error(void) { return g_err.c_str(); }
+
+int fr_version(void) { return 100; }
+
+int fr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int fr_malloc(void **d_ptr, int64_t bytes) {
+  if (!d_ptr || bytes < 0) return fail(FR_E_ARG, "fr_malloc: bad argument");
+  *d_ptr = nullptr;
+  if (bytes == 0) return FR_OK;
+  hipError_t e = hipMalloc(d_ptr, (size_t)bytes);
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    return fail(FR_E_NOMEM, "fr_malloc: out of device memory");
+  }
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+  return FR_OK;
+}
+
+int fr_free(void *d_ptr) {
+  if (!d_ptr) return FR_OK;
+  HIP_TRY(hipFree(d_ptr));
+  return FR_OK;
+}
+
+int fr_memcpy_h2d(void *d_dst, const void *h_src, int64_t bytes, void *stream) {
+  if (bytes == 0) return FR_OK;
+  if (!d_dst || !h_src || bytes < 0) return fail(FR_E_ARG, "fr_memcpy_h2d: bad argument");
+  HIP_TRY(hipMemcpyAsync(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return FR_OK;
+}
+
+int fr_memcpy_d2h(void *h_dst, const void *d_src, int64_t bytes, void *stream) {
+  if (bytes == 0) return FR_OK;
+  if (!h_dst || !d_src || bytes < 0) return fail(FR_E_ARG, "fr_memcpy_d2h: bad argument");
+  HIP_TRY(hipMemcpyAsync(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return FR_OK;
+}
+
+int fr_stream_sync(void *stream) {
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return FR_OK;
+}
+
+fr_plan_t *fr_plan_create(int32_t W, const int32_t *exps, const int32_t *L, const int32_t *Dw,
+                          const float *alpha, const int32_t *depth, int32_t weighting,
+                          int32_t flags) {
+  std::string err;
+  fr::Plan *p = fr::build_plan(W, exps, L, Dw, alpha, depth, weighting, flags, err);
+  if (!p) {
+    g_err = err;
+    return nullptr;
+  }
+  fr_plan_t *h = new fr_plan_t;
+  h->p = p;
+  return h;
+}
+
+void fr_plan_destroy(fr_plan_t *plan) {
+  if (!plan) return;
+  if (plan->p) {
+    for (auto &kv : plan->p->programs)
+      if (kv.second.d_blob) (void)hipFree(kv.second.d_blob);
+    delete plan->p;
+  }
+  delete plan;
+}
+
+int64_t fr_plan_info(const fr_plan_t *plan, int32_t what) {
+  if (!plan || !plan->p) return fail(FR_E_ARG, "fr_plan_info: null plan");
+  const fr::Plan &p = *plan->p;
+  switch (what) {
+    case FR_INFO_ROWS: return p.K;
+    case FR_INFO_NODES: return (int64_t)p.nodes.size();
+    case FR_INFO_LEVELS: return p.levels;
+    case FR_INFO_DIMS_USED: return p.dims_used;
+    case FR_INFO_MAX_DIM: return p.max_dim;
+    case FR_INFO_ALPHAS: return (int64_t)p.alphas.size();
+    case FR_INFO_GROUPS: return p.units();
+    case FR_INFO_SHARED: return p.shared ? 1 : 0;
+    default: return fail(FR_E_ARG, "fr_plan_info: unknown selector");
+  }
+}
+
+int32_t fr_plan_dump(const fr_plan_t *plan, int32_t *buf, int32_t cap) {
+  if (!plan || !plan->p) return fail(FR_E_ARG, "fr_plan_dump: null plan");
+  const fr::Plan &p = *plan->p;
+  const int32_t n = (int32_t)p.nodes.size();
+  for (int32_t i = 0; i < n && buf && (i + 1) * 8 <= cap; ++i) {
+    const fr::NodeDesc &nd = p.nodes[i];
+    int32_t *o = buf + (size_t)i * 8;
+    o[0] = nd.level;
+    o[1] = nd.flags;
+    o[2] = nd.fac_count;
+    o[3] = nd.emit_count;
+    o[4] = nd.emit_count ? p.emit_rows[nd.emit_begin] : -1;
+    o[5] = nd.emit_mul;
+    o[6] = nd.z_mul;
+    o[7] = p.unit_of[i];
+  }
+  return n;
+}
+
+int64_t fr_plan_workspace_bytes(const fr_plan_t *plan, int64_t N, int64_t T, int64_t lookup_rows) {
+  if (!plan || !plan->p || N < 0 || T < 0 || lookup_rows < 0)
+    return fail(FR_E_ARG, "fr_plan_workspace_bytes: bad argument");
+  return (int64_t)work_layout(*plan->p, N, T, lookup_rows).total();
+}
+
+int fr_iss_run(fr_plan_t *plan, const double *d_X, int64_t N, int64_t D, int64_t T,
+               const double *d_lookup, int64_t lookup_rows, double *d_out, int64_t out_k_stride,
+               int64_t out_n_stride, void *d_work, int64_t work_bytes, int32_t groups,
+               void *stream) {
+  if (!plan || !plan->p) return fail(FR_E_ARG, "fr_iss_run: null plan");
+  fr::Plan &p = *plan->p;
+  if (N < 0 || D < 1 || T < 0) return fail(FR_E_ARG, "fr_iss_run: bad shape");
+  if (p.max_dim > D)
+    return fail(FR_E_DIM, "fr_iss_run: a word references dimension " + std::to_string(p.max_dim) +
+                              " but the input has only " + std::to_string(D));
+  if (N == 0 || T == 0 || p.K == 0 || p.nodes.empty()) return FR_OK;
+  if (!d_X || !d_out) return fail(FR_E_ARG, "fr_iss_run: null device pointer");
+  if (p.weighting != 0) {
+    if (!d_lookup) return fail(FR_E_ARG, "fr_iss_run: weighted plan needs a lookup");
+    if (lookup_rows != 1 && lookup_rows != N)
+      return fail(FR_E_ARG, "fr_iss_run: lookup_rows must be 1 or N");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const WorkLayout wl = work_layout(p, N, T, p.weighting ? lookup_rows : 0);
+  if (wl.total() > 0 && (!d_work || (size_t)work_bytes < wl.total()))
+    return fail(FR_E_NOMEM, "fr_iss_run: workspace too small (need " +
+                                std::to_string(wl.total()) + " bytes)");
+  const int G = choose_groups(p, N, groups);
+  fr::GroupedProgram &gp = fr::grouped(p, G);
+  int rc = ensure_device_program(p, gp);
+  if (rc != FR_OK) return rc;
+
+  fr::IssArgs a{};
+  a.X = d_X;
+  a.out = d_out;
+  a.N = N;
+  a.D = D;
+  a.T = T;
+  a.out_k_stride = out_k_stride;
+  a.out_n_stride = out_n_stride;
+  a.nodes = gp.d_nodes;
+  a.node_ids = gp.d_node_ids;
+  a.factors = gp.d_factors;
+  a.emit_rows = gp.d_emit_rows;
+  a.group_begin = gp.d_group_begin;
+  a.row_src = gp.d_row_src;
+  a.G = gp.groups;
+  a.R = p.rows_staged();
+  a.total_nodes = (int32_t)p.nodes.size();
+  char *work = static_cast<char *>(d_work);
+  if (p.weighting != 0) {
+    double *aux = reinterpret_cast<double *>(work);
+    const int64_t count = lookup_rows * T;
+    hipError_t e = fr::launch_exp_tables(d_lookup, count, gp.d_alphas, (int)p.alphas.size(), aux, st);
+    if (e != hipSuccess) return hip_fail(e, "exp_tables launch");
+    a.aux = aux;
+    a.aux_tab_stride = count;
+    a.aux_n_stride = lookup_rows == 1 ? 0 : T;
+  }
+  if (wl.carry_bytes) a.carry = reinterpret_cast<double *>(work + wl.aux_bytes);
+  a.vec_ok = (T % 2 == 0) && aligned16(d_X) && aligned16(d_out) && (out_k_stride % 2 == 0) &&
+             (out_n_stride % 2 == 0) && (!a.aux || aligned16(a.aux));
+  a.xcd_map = (a.G > 1 && N % 8 == 0) ? 1 : 0;
+  a.nt_store = env_int("FRUITS_HIP_NT", 0);
+  hipError_t e = fr::launch_iss_walk(a, p.levels, st);
+  if (e != hipSuccess) return hip_fail(e, "iss_walk launch");
+  return FR_OK;
+}
+
+int fr_iterated_sum_fast_host(const double *h_Z, int64_t N, int64_t D, int64_t T,
+                              const int32_t *word, int32_t L, int32_t Dw, const float *alpha,
+                              const double *h_lookup, int64_t extended, int32_t total_weighting,
+                              double *h_out) {
+  if (!h_Z || !word || !h_out || N < 0 || D < 1 || T < 0 || L < 1 || Dw < 1)
+    return fail(FR_E_ARG, "fr_iterated_sum_fast_host: bad argument");
+  if (extended < 1 || extended > L)
+    return fail(FR_E_ARG, "fr_iterated_sum_fast_host: extended must be in [1, L]");
+  const int weighting = h_lookup ? (total_weighting ? FR_W_TOTAL : FR_W_NONTOTAL) : FR_W_NONE;
+  if (weighting != FR_W_NONE && !alpha)
+    return fail(FR_E_ARG, "fr_iterated_sum_fast_host: weighted call needs alpha");
+  const int32_t depth = (int32_t)extended;
+  fr_plan_t *plan = fr_plan_create(1, word, &L, &Dw, alpha, &depth, weighting, 0);
+  if (!plan) return FR_E_ARG;
+  int rc = FR_OK;
+  void *dZ = nullptr, *dL = nullptr, *dO = nullptr, *dW = nullptr;
+  const int64_t zb = N * D * T * 8, lb = h_lookup ? N * T * 8 : 0, ob = N * extended * T * 8;
+  const int64_t wb = fr_plan_workspace_bytes(plan, N, T, h_lookup ? N : 0);
+  do {
+    if (N == 0 || T == 0) break;
+    if ((rc = fr_malloc(&dZ, zb)) != FR_OK) break;
+    if ((rc = fr_malloc(&dO, ob)) != FR_OK) break;
+    if (lb && (rc = fr_malloc(&dL, lb)) != FR_OK) break;
+    if (wb && (rc = fr_malloc(&dW, wb)) != FR_OK) break;
+    if ((rc = fr_memcpy_h2d(dZ, h_Z, zb, nullptr)) != FR_OK) break;
+    if (lb && (rc = fr_memcpy_h2d(dL, h_lookup, lb, nullptr)) != FR_OK) break;
+    rc = fr_iss_run(plan, (const double *)dZ, N, D, T, (const double *)dL, h_lookup ? N : 0,
+                    (double *)dO, /*k stride*/ T, /*n stride*/ extended * T, dW, wb, 0, nullptr);
+    if (rc != FR_OK) break;
+    if ((rc = fr_memcpy_d2h(h_out, dO, ob, nullptr)) != FR_OK) break;
+    rc = fr_stream_sync(nullptr);
+  } while (0);
+  const std::string keep = g_err;
+  (void)hipFree(dZ);
+  (void)hipFree(dL);
+  (void)hipFree(dO);
+  (void)hipFree(dW);
+  fr_plan_destroy(plan);
+  if (rc != FR_OK) g_err = keep;
+  return rc;
+}
+
+int fr_increments(const double *d_X, int64_t rows, int64_t T, int64_t shift, double *d_out,
+                  const double *d_head_src, int64_t head, void *stream) {
+  if (rows < 0 || T < 0 || shift < 0) return fail(FR_E_ARG, "fr_increments: bad shape");
+  if (rows == 0 || T == 0) return FR_OK;
+  if (!d_X || !d_out) return fail(FR_E_ARG, "fr_increments: null device pointer");
+  hipError_t e = fr::launch_increments(d_X, rows, T, shift, d_out, d_head_src, head,
+                                       (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "increments launch");
+  return FR_OK;
+}
+
+int fr_pathlen_lookup(const double *d_X, int64_t N, int64_t D, int64_t T, int32_t norm,
+                      int32_t relative, double scale, double *d_out, void *stream) {
+  if (N < 0 || D < 1 || T < 0 || (norm != 1 && norm != 2))
+    return fail(FR_E_ARG, "fr_pathlen_lookup: bad argument");
+  if (N == 0 || T == 0) return FR_OK;
+  if (!d_X || !d_out) return fail(FR_E_ARG, "fr_pathlen_lookup: null device pointer");
+  hipError_t e = fr::launch_pathlen_lookup(d_X, N, D, T, norm, relative, scale, d_out,
+                                           (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "pathlen_lookup launch");
+  return FR_OK;
+}
+
+int fr_sieve(int32_t kind, const double *d_A, int64_t N, int64_t T, int64_t a_stride, int32_t inc,
+             const int64_t *d_cuts, int64_t cut_rows, int32_t C1, const double *d_q, int32_t Q1,
+             double *d_out, int64_t out_stride, void *stream) {
+  if (kind < 0 || kind > 2) return fail(FR_E_ARG, "fr_sieve: unknown kind");
+  if (N < 0 || T < 1 || C1 < 2 || (cut_rows != 1 && cut_rows != N))
+    return fail(FR_E_ARG, "fr_sieve: bad shape");
+  if (kind != FR_SIEVE_END && (Q1 < 2 || !d_q)) return fail(FR_E_ARG, "fr_sieve: bad quantiles");
+  if (inc < 0 || inc > 8) return fail(FR_E_LIMIT, "fr_sieve: inc must be in [0, 8]");
+  if (N == 0) return FR_OK;
+  if (!d_A || !d_cuts || !d_out) return fail(FR_E_ARG, "fr_sieve: null device pointer");
+  hipError_t e = fr::launch_sieve(kind, d_A, N, T, a_stride, inc, d_cuts, cut_rows, C1, d_q, Q1,
+                                  d_out, out_stride, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "sieve launch");
+  return FR_OK;
+}
+
+int fr_pre_transform(const double *d_A, int64_t N, int64_t T, int64_t a_stride, int32_t inc,
+                     double *d_out, void *stream) {
+  if (N < 0 || T < 0 || inc < 0 || inc > 8) return fail(FR_E_ARG, "fr_pre_transform: bad argument");
+  if (N == 0 || T == 0) return FR_OK;
+  if (!d_A || !d_out) return fail(FR_E_ARG, "fr_pre_transform: null device pointer");
+  hipError_t e = fr::launch_pre_transform(d_A, N, T, a_stride, inc, d_out, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "pre_transform launch");
+  return FR_OK;
+}
+
+int fr_standardize(const double *d_X, int64_t rows, int64_t T, int32_t div_std, double eps,
+                   double *d_out, void *stream) {
+  if (rows < 0 || T < 0) return fail(FR_E_ARG, "fr_standardize: bad shape");
+  if (rows == 0 || T == 0) return FR_OK;
+  if (!d_X || !d_out) return fail(FR_E_ARG, "fr_standardize: null device pointer");
+  hipError_t e = fr::launch_standardize(d_X, rows, T, div_std, eps, d_out, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "standardize launch");
+  return FR_OK;
+}
+
+}  // extern "C"

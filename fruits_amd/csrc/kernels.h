@@ -1,0 +1,57 @@
+// Internal interface between the C ABI (capi.cpp) and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "plan.h"
+
+namespace fr {
+
+constexpr int kWalkThreads = 256;
+
+constexpr int FR_SIEVE_NPI_K = 0;
+constexpr int FR_SIEVE_MPI_K = 1;
+constexpr int FR_SIEVE_END_K = 2;
+
+struct IssArgs {
+  const double *X;          // (N, D, T)
+  const double *aux;        // exp tables [2A][aux rows][T] or nullptr
+  double *out;
+  double *carry;            // (N, 2*total_nodes) chunk carries or nullptr (single chunk)
+  const NodeDesc *nodes;
+  const int32_t *node_ids;
+  const int32_t *factors;
+  const int32_t *emit_rows;
+  const int32_t *group_begin;
+  const int32_t *row_src;
+  int64_t N, D, T;
+  int64_t aux_tab_stride;   // elements between two exp tables
+  int64_t aux_n_stride;     // T for per-series lookups, 0 for a broadcast lookup
+  int64_t out_k_stride, out_n_stride;
+  int32_t G;                // groups per series
+  int32_t R;                // staged rows
+  int32_t total_nodes;
+  int32_t vec_ok;           // 16-byte accesses are aligned
+  int32_t nchunks;
+  int32_t xcd_map;
+  int32_t nt_store;
+};
+
+int walk_chunk_elems(int64_t T);
+hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st);
+hipError_t launch_exp_tables(const double *g, int64_t count, const float *alphas, int n_alpha,
+                             double *aux, hipStream_t st);
+hipError_t launch_increments(const double *X, int64_t rows, int64_t T, int64_t shift, double *out,
+                             const double *head_src, int64_t head, hipStream_t st);
+hipError_t launch_pathlen_lookup(const double *X, int64_t N, int64_t D, int64_t T, int norm,
+                                 int relative, double scale, double *out, hipStream_t st);
+hipError_t launch_sieve(int kind, const double *A, int64_t N, int64_t T, int64_t a_stride, int inc,
+                        const int64_t *cuts, int64_t cut_rows, int C1, const double *q, int Q1,
+                        double *out, int64_t out_stride, hipStream_t st);
+hipError_t launch_pre_transform(const double *A, int64_t N, int64_t T, int64_t a_stride, int inc,
+                                double *out, hipStream_t st);
+hipError_t launch_standardize(const double *X, int64_t rows, int64_t T, int div_std, double eps,
+                              double *out, hipStream_t st);
+
+}  // namespace fr

@@ -1,0 +1,268 @@
+// Plan compiler: word list -> prefix trie -> DFS program (see plan.h).
+#include "plan.h"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+namespace fr {
+namespace {
+
+struct TrieNode {
+  std::vector<int32_t> exps;  // exponents, trailing zeros trimmed
+  uint32_t alpha_bits = 0;    // bit pattern of this letter's alpha (0 when unweighted)
+  int parent = -1;
+  int depth = 0;              // letters from the root (1 = first letter)
+  std::vector<int> children;
+  std::vector<int32_t> emit;  // output rows
+};
+
+struct Key {
+  std::vector<int32_t> exps;
+  uint32_t alpha_bits;
+  bool operator<(const Key &o) const {
+    if (alpha_bits != o.alpha_bits) return alpha_bits < o.alpha_bits;
+    return exps < o.exps;
+  }
+};
+
+uint32_t fbits(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  return u;
+}
+
+struct Builder {
+  Plan *p;
+  std::vector<TrieNode> trie;                 // trie[0] = root
+  std::vector<std::map<Key, int>> child_map;  // only used when sharing
+  std::map<uint32_t, int> alpha_index;        // alpha bits -> index in p->alphas
+  std::map<int, int> dim_row;                 // X dimension -> LDS row
+
+  int alpha_id(uint32_t bits) {
+    auto it = alpha_index.find(bits);
+    if (it != alpha_index.end()) return it->second;
+    float f;
+    std::memcpy(&f, &bits, 4);
+    int id = (int)p->alphas.size();
+    p->alphas.push_back(f);
+    alpha_index[bits] = id;
+    return id;
+  }
+  int row_plus(uint32_t bits) { return p->dims_used + 2 * alpha_id(bits); }
+  int row_minus(uint32_t bits) { return p->dims_used + 2 * alpha_id(bits) + 1; }
+
+  void emit_node(int t, int level, int chain, int unit) {
+    const TrieNode &tn = trie[t];
+    NodeDesc nd{};
+    nd.level = level;
+    nd.flags = (chain ? F_CHAIN : 0) | (tn.children.empty() ? 0 : F_CHILDREN);
+    nd.fac_begin = (int32_t)p->factors.size();
+    nd.emit_mul = -1;
+    nd.z_mul = -1;
+    const bool weighted = p->weighting != 0;
+    const bool has_parent = tn.depth > 1;
+    // total weighting: the factor exp(-g*alpha_{k-1}) is applied right after the
+    // shift, before the letters (fruits/iss/semiring.py:154-157, then :143-149)
+    if (weighted && p->weighting == 2 && has_parent)
+      p->factors.push_back(row_minus(trie[tn.parent].alpha_bits));
+    for (size_t d = 0; d < tn.exps.size(); ++d) {
+      int occ = tn.exps[d];
+      for (int r = 0; r < std::abs(occ); ++r)
+        p->factors.push_back(dim_row[(int)d] | (occ < 0 ? FAC_DIV : 0));
+    }
+    if (weighted && p->weighting == 1) {
+      // non-total: letters, then exp(-g*alpha_{k-1}) (semiring.py:111-119); the
+      // child scan runs over s*exp(+g*alpha_k) (:122-124)
+      if (has_parent) p->factors.push_back(row_minus(trie[tn.parent].alpha_bits));
+      if (!tn.children.empty()) nd.z_mul = row_plus(tn.alpha_bits);
+    } else if (weighted) {
+      // total: letters, then exp(+g*alpha_k), scan, emit * exp(-g*alpha_k)
+      // (semiring.py:150-153)
+      p->factors.push_back(row_plus(tn.alpha_bits));
+      nd.emit_mul = row_minus(tn.alpha_bits);
+    }
+    nd.fac_count = (int32_t)p->factors.size() - nd.fac_begin;
+    nd.emit_begin = (int32_t)p->emit_rows.size();
+    for (int32_t r : tn.emit) p->emit_rows.push_back(r);
+    nd.emit_count = (int32_t)tn.emit.size();
+    p->nodes.push_back(nd);
+    p->unit_of.push_back(unit);
+    p->levels = std::max(p->levels, level + 1);
+    if (tn.children.size() == 1) {
+      emit_node(tn.children[0], level, 1, unit);
+    } else {
+      for (int c : tn.children) emit_node(c, level + 1, 0, unit);
+    }
+  }
+};
+
+double node_cost(const NodeDesc &nd) {
+  const bool has_children = nd.flags & F_CHILDREN;
+  const bool need2 = has_children && nd.z_mul >= 0;
+  const bool need1 = nd.emit_count > 0 || (has_children && !need2);
+  return (need1 ? 1.0 : 0.0) + (need2 ? 1.0 : 0.0) + 1.0 * nd.emit_count +
+         0.1 * nd.fac_count;
+}
+
+}  // namespace
+
+Plan *build_plan(int W, const int32_t *exps, const int32_t *L, const int32_t *Dw,
+                 const float *alpha, const int32_t *depth, int weighting, int flags,
+                 std::string &err) {
+  if (W < 0 || (W > 0 && (!exps || !L || !Dw || !depth))) {
+    err = "fr_plan_create: null argument";
+    return nullptr;
+  }
+  if (weighting < 0 || weighting > 2) {
+    err = "fr_plan_create: weighting must be 0, 1 or 2";
+    return nullptr;
+  }
+  if (weighting != 0 && !alpha) {
+    err = "fr_plan_create: weighted plan needs alpha";
+    return nullptr;
+  }
+  for (int i = 0; i < W; ++i) {
+    if (L[i] < 1 || Dw[i] < 1 || depth[i] < 1 || depth[i] > L[i]) {
+      err = "fr_plan_create: word " + std::to_string(i) + " has invalid L/Dw/depth";
+      return nullptr;
+    }
+  }
+
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const bool share = (flags & 1) && attempt == 0;
+    Plan *p = new Plan();
+    p->W = W;
+    p->weighting = weighting;
+    p->shared = share;
+    Builder b;
+    b.p = p;
+    b.trie.emplace_back();
+    b.child_map.emplace_back();
+
+    // dimensions used -> LDS rows, ascending
+    {
+      std::vector<char> used;
+      const int32_t *e = exps;
+      for (int i = 0; i < W; ++i) {
+        if ((int)used.size() < Dw[i]) used.resize(Dw[i], 0);
+        for (int k = 0; k < L[i]; ++k)
+          for (int d = 0; d < Dw[i]; ++d)
+            if (e[k * Dw[i] + d] != 0) used[d] = 1;
+        e += (size_t)L[i] * Dw[i];
+      }
+      for (size_t d = 0; d < used.size(); ++d)
+        if (used[d]) {
+          b.dim_row[(int)d] = (int)p->row_src.size();
+          p->row_src.push_back((int32_t)d);
+          p->max_dim = (int)d + 1;
+        }
+      p->dims_used = (int)p->row_src.size();
+    }
+
+    // trie
+    const int32_t *e = exps;
+    const float *a = alpha;
+    int row = 0;
+    for (int i = 0; i < W; ++i) {
+      int cur = 0;
+      for (int k = 0; k < L[i]; ++k) {
+        Key key;
+        key.exps.assign(e + (size_t)k * Dw[i], e + (size_t)(k + 1) * Dw[i]);
+        while (!key.exps.empty() && key.exps.back() == 0) key.exps.pop_back();
+        key.alpha_bits = weighting ? fbits(a[k]) : 0u;
+        int nxt = -1;
+        if (share) {
+          auto it = b.child_map[cur].find(key);
+          if (it != b.child_map[cur].end()) nxt = it->second;
+        }
+        if (nxt < 0) {
+          nxt = (int)b.trie.size();
+          TrieNode tn;
+          tn.exps = key.exps;
+          tn.alpha_bits = key.alpha_bits;
+          tn.parent = cur;
+          tn.depth = k + 1;
+          b.trie.push_back(tn);
+          b.child_map.emplace_back();
+          b.trie[cur].children.push_back(nxt);
+          if (share) b.child_map[cur][key] = nxt;
+        }
+        cur = nxt;
+        // prefix of length k+1 is output iff L-k <= depth (semiring.py:120,152)
+        if (L[i] - k <= depth[i]) b.trie[cur].emit.push_back(row + depth[i] - (L[i] - k));
+      }
+      row += depth[i];
+      e += (size_t)L[i] * Dw[i];
+      if (a) a += L[i];
+    }
+    p->K = row;
+
+    // register all alphas up front so LDS row numbers are final before emission
+    if (weighting)
+      for (size_t t = 1; t < b.trie.size(); ++t) b.alpha_id(b.trie[t].alpha_bits);
+    for (size_t j = 0; j < p->alphas.size(); ++j) {
+      p->row_src.push_back(-(int32_t)(1 + 2 * j));
+      p->row_src.push_back(-(int32_t)(2 + 2 * j));
+    }
+
+    // DFS program, one unit per root child
+    p->unit_begin.push_back(0);
+    int unit = 0;
+    for (int c : b.trie[0].children) {
+      b.emit_node(c, 0, 0, unit++);
+      p->unit_begin.push_back((int32_t)p->nodes.size());
+    }
+    for (int u = 0; u < p->units(); ++u) {
+      double cst = 0;
+      for (int i = p->unit_begin[u]; i < p->unit_begin[u + 1]; ++i) cst += node_cost(p->nodes[i]);
+      p->unit_cost.push_back(cst);
+    }
+    if (p->row_src.size() > (size_t)FAC_ROW_MASK) {
+      err = "fr_plan_create: too many staged rows";
+      delete p;
+      return nullptr;
+    }
+    if (p->levels <= kMaxLevels) return p;
+    // too deep for the register-frame walk: fall back to one chain per word
+    delete p;
+    if (!share) break;
+  }
+  err = "fr_plan_create: plan exceeds the frame limit";
+  return nullptr;
+}
+
+GroupedProgram &grouped(Plan &p, int G) {
+  G = std::max(1, std::min(G, std::max(1, p.units())));
+  auto it = p.programs.find(G);
+  if (it != p.programs.end()) return it->second;
+  GroupedProgram gp;
+  gp.groups = G;
+  const int U = p.units();
+  // LPT: heaviest unit first onto the lightest group (ties: lowest index), then
+  // each group keeps its units in plan order
+  std::vector<int> order(U);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(),
+                   [&](int x, int y) { return p.unit_cost[x] > p.unit_cost[y]; });
+  std::vector<double> load(G, 0.0);
+  std::vector<std::vector<int>> members(G);
+  for (int u : order) {
+    int g = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+    load[g] += p.unit_cost[u];
+    members[g].push_back(u);
+  }
+  gp.group_begin.push_back(0);
+  for (int g = 0; g < G; ++g) {
+    std::sort(members[g].begin(), members[g].end());
+    for (int u : members[g])
+      for (int i = p.unit_begin[u]; i < p.unit_begin[u + 1]; ++i) {
+        gp.nodes.push_back(p.nodes[i]);
+        gp.node_ids.push_back(i);
+      }
+    gp.group_begin.push_back((int32_t)gp.nodes.size());
+  }
+  return p.programs.emplace(G, std::move(gp)).first->second;
+}
+
+}  // namespace fr

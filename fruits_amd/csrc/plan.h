@@ -1,0 +1,83 @@
+// Host-side plan compiler for the ISS trie walk (internal header).
+//
+// A plan is the device "program" that replaces the reference's Python word loop
+// (_calculate_ISS, fruits/iss/iss.py:21-67): the words are merged into a prefix
+// trie (what CachePlan, fruits/iss/cache.py:6-81, only uses to drop duplicate
+// OUTPUTS is used here to drop duplicate WORK), laid out in DFS preorder and
+// annotated with register-frame levels so a workgroup can walk it with the
+// running prefixes held in registers.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace fr {
+
+// node flags
+constexpr int32_t F_CHAIN = 1;     // only child: processed in place in its parent's frame
+constexpr int32_t F_CHILDREN = 2;  // the exclusive prefix of this node is consumed by children
+// factor word: LDS row in the low 16 bits, bit 30 = divide instead of multiply
+constexpr int32_t FAC_DIV = 1 << 30;
+constexpr int32_t FAC_ROW_MASK = 0xffff;
+
+constexpr int kMaxLevels = 12;  // deepest register-frame stack a kernel variant supports
+
+struct NodeDesc {  // 32 bytes, read by the kernel with scalar loads
+  int32_t level;       // register frame this node writes (reads level-1; level 0 reads ones)
+  int32_t flags;       // F_*
+  int32_t fac_begin;   // [fac_begin, fac_begin+fac_count) in the factor table
+  int32_t fac_count;
+  int32_t emit_begin;  // [emit_begin, emit_begin+emit_count) in the emit-row table
+  int32_t emit_count;
+  int32_t emit_mul;    // LDS row multiplied into emitted values (total weighting) or -1
+  int32_t z_mul;       // LDS row multiplied into the summand of the child scan (non-total) or -1
+};
+
+struct GroupedProgram {       // node order for one choice of G (groups per series)
+  int groups = 0;
+  std::vector<NodeDesc> nodes;        // concatenation of the groups' units
+  std::vector<int32_t> node_ids;      // global node id of nodes[i] (carry slot)
+  std::vector<int32_t> group_begin;   // G+1 offsets into nodes
+  // device copies
+  void *d_blob = nullptr;
+  const NodeDesc *d_nodes = nullptr;
+  const int32_t *d_node_ids = nullptr;
+  const int32_t *d_group_begin = nullptr;
+  const int32_t *d_factors = nullptr;
+  const int32_t *d_emit_rows = nullptr;
+  const int32_t *d_row_src = nullptr;
+  const float *d_alphas = nullptr;
+};
+
+struct Plan {
+  int W = 0;
+  int weighting = 0;
+  bool shared = true;
+  int K = 0;                 // output rows
+  int levels = 0;            // register frames needed
+  int max_dim = 0;           // highest dimension referenced (1-based)
+  std::vector<NodeDesc> nodes;       // DFS preorder, unit after unit
+  std::vector<int32_t> unit_of;      // unit (root sub-trie) index of each node
+  std::vector<int32_t> unit_begin;   // U+1 offsets into nodes
+  std::vector<double> unit_cost;
+  std::vector<int32_t> factors;
+  std::vector<int32_t> emit_rows;
+  std::vector<int32_t> row_src;      // LDS row -> source: d (>=0) = X dimension d, -(1+j) = aux table j
+  std::vector<float> alphas;         // distinct alphas; aux table 2a = exp(+g*alpha_a), 2a+1 = exp(-g*alpha_a)
+  int dims_used = 0;
+  std::map<int, GroupedProgram> programs;  // per G
+  int device = -1;
+
+  int units() const { return (int)unit_begin.size() - 1; }
+  int rows_staged() const { return (int)row_src.size(); }
+};
+
+// Builds the plan; returns nullptr and sets `err` on invalid input.
+Plan *build_plan(int W, const int32_t *exps, const int32_t *L, const int32_t *Dw,
+                 const float *alpha, const int32_t *depth, int weighting, int flags,
+                 std::string &err);
+// Node order for G groups (LPT assignment of units to groups), cached in the plan.
+GroupedProgram &grouped(Plan &p, int G);
+
+}  // namespace fr

@@ -1,0 +1,456 @@
+"""Pipeline orchestration: ``Fruit`` and ``FruitSlice`` (mirrors fruits/fruit.py).
+
+The public behaviour is the reference's - slices of preparateurs -> ISS ->
+sieves, per-iterated-sum fitted sieve copies, feature column order (slice, then
+iterated sum, then sieve, then the sieve's own (segment, band) order) and the
+final ``nan_to_num``.  The execution is not: the batch is uploaded to HBM once,
+every stage runs as HIP kernels on device tensors, iterated sums are produced
+by one launch per word batch instead of one numba call per word, sieves write
+straight into the ``(N, F)`` feature tensor, and only that tensor travels back.
+"""
+from __future__ import annotations
+
+import inspect
+from typing import Callable, Generator, Literal, Optional, Union
+
+import numpy as np
+
+from . import _native as nat
+from .cache import SharedSeedCache
+from .callback import AbstractCallback
+from .iss.iss import ISS
+from .preparation.abstract import Preparateur
+from .seed import Seed
+from .sieving.abstract import FeatureSieve
+
+
+def _check_batch(X) -> np.ndarray:
+    if not isinstance(X, np.ndarray) or X.ndim != 3:
+        raise TypeError("input has to be an array of shape (N, D, T)")
+    if X.dtype != np.float64:
+        raise TypeError("input has to be float64 (the reference's numba kernels "
+                        "accept nothing else)")
+    return X
+
+
+class Fruit:
+    """Feature extractor made of one or more :class:`FruitSlice` objects whose
+    features are concatenated.
+
+    .. code-block:: python
+
+        fruit = fruits_amd.Fruit("My Fruit")
+        fruit.add(fruits_amd.preparation.INC)
+        fruit.add(fruits_amd.ISS(fruits_amd.words.of_weight(2, dim=3),
+                                 mode=fruits_amd.ISSMode.EXTENDED))
+        fruit.add(fruits_amd.sieving.NPI(q=(0.5, 1.0)), fruits_amd.sieving.END)
+        fruit.fit(X)
+        features = fruit.transform(X)
+    """
+
+    def __init__(self, name: str = "") -> None:
+        self.name: str = name
+        self._slices: list[FruitSlice] = []
+        self._slc_index: int = 0
+        self._fitted: bool = False
+        self._cursor: int = -1
+
+    # ---- structure ------------------------------------------------------------
+    def cut(self, slice: Optional["FruitSlice"] = None) -> None:
+        """Appends a (new, empty) slice and makes it the current one."""
+        self._slices.append(FruitSlice() if slice is None else slice)
+        self._slc_index = len(self._slices) - 1
+        self._fitted = False
+
+    def copycut(self) -> None:
+        self.cut(self.get_slice().deepcopy())
+
+    def get_slice(self, index: Optional[int] = None) -> "FruitSlice":
+        return self._slices[self._slc_index if index is None else index]
+
+    def switch_slice(self, index: int) -> None:
+        if not (0 <= index < len(self._slices)):
+            raise IndexError("Index has to be in [0, len(self)-1]")
+        self._slc_index = index
+
+    def add(self, *objects: Union[Seed, Callable[[], Seed]]) -> None:
+        """Adds preparateurs, ISS or sieves to the current slice."""
+        if not self._slices:
+            self.cut()
+        self._slices[self._slc_index].add(*objects)
+        self._fitted = False
+
+    def nfeatures(self) -> int:
+        return sum(slc.nfeatures() for slc in self._slices)
+
+    # ---- fit / transform ----------------------------------------------------
+    def fit(self, X: np.ndarray, cache: Optional[SharedSeedCache] = None) -> None:
+        X = _check_batch(X)
+        cache_ = SharedSeedCache(X) if cache is None else cache
+        for slc in self._slices:
+            slc.fit(X, cache=cache_)
+        self._fitted = True
+
+    def transform(self, X: np.ndarray,
+                  callbacks: Optional[list[AbstractCallback]] = None,
+                  cache: Optional[SharedSeedCache] = None) -> np.ndarray:
+        """``(N, nfeatures)`` features of all slices.
+
+        Raises:
+            RuntimeError: if :meth:`fit` was not called.
+        """
+        callbacks = callbacks or []
+        if not self._fitted:
+            raise RuntimeError("Missing call of self.fit")
+        X = _check_batch(X)
+        cache_ = SharedSeedCache(X) if cache is None else cache
+        result = np.zeros((X.shape[0], self.nfeatures()))
+        col = 0
+        for slc in self._slices:
+            for cb in callbacks:
+                cb.on_next_slice()
+            k = slc.nfeatures()
+            result[:, col:col + k] = slc.transform(X, callbacks, cache_)
+            col += k
+        return np.nan_to_num(result, copy=False, nan=0.0)
+
+    def fit_transform(self, X: np.ndarray,
+                      callbacks: Optional[list[AbstractCallback]] = None) -> np.ndarray:
+        self.fit(X)
+        return self.transform(X, callbacks=callbacks)
+
+    # ---- introspection ------------------------------------------------------
+    def summary(self) -> str:
+        bar = 80 * "="
+        ident = "Fruit" + (f" {self.name!r}" if self.name != "" else "")
+        ident += f" -> Features: {self.nfeatures()}"
+        text = bar + "\n<" + f"{ident: ^78}" + ">\n" + bar + "\n"
+        rule = "|" + 38 * "-"
+        pairs = len(self._slices) - len(self._slices) % 2
+        for i in range(0, pairs, 2):
+            left = self._slices[i].summary().split("\n")
+            right = self._slices[i + 1].summary().split("\n")
+            height = max(len(left), len(right))
+            left += [38 * " "] * (height - len(left))
+            right += [38 * " "] * (height - len(right))
+            text += rule + "|" + rule + "|\n"
+            text += "\n".join(f"|{a}||{b}|" for a, b in zip(left, right))
+            text += "\n" + rule + "|" + rule + "|\n"
+        if len(self._slices) % 2:
+            text += rule + "|\n|"
+            text += self._slices[-1].summary().replace("\n", "|\n|")
+            text += "|\n" + rule + "|\n"
+        return text + bar
+
+    def copy(self) -> "Fruit":
+        dup = Fruit(self.name + " (Copy)")
+        for slc in self._slices:
+            dup.cut(slc.copy())
+        return dup
+
+    def deepcopy(self) -> "Fruit":
+        dup = Fruit(self.name + " (Deepcopy)")
+        for slc in self._slices:
+            dup.cut(slc.deepcopy())
+        return dup
+
+    def label(self, index: int,
+              level: Literal["prepared", "iterated sums", "features"] = "features",
+              verbose: Literal[1, 2] = 1) -> str:
+        """Label of one feature (or prepared input / iterated sum, by ``level``)."""
+        for slc in self._slices:
+            if level == "prepared":
+                total = len(slc.get_preparateurs())
+            elif level == "iterated sums":
+                total = slc.niteratedsums()
+            else:
+                total = slc.nfeatures()
+            if index < total:
+                return slc.label(index, level, verbose)
+            index -= total
+        raise RuntimeError("Label index out of range")
+
+    def __len__(self) -> int:
+        return len(self._slices)
+
+    def __iter__(self) -> "Fruit":
+        self._cursor = -1
+        return self
+
+    def __next__(self) -> "FruitSlice":
+        if self._cursor + 1 < len(self._slices):
+            self._cursor += 1
+            return self._slices[self._cursor]
+        raise StopIteration()
+
+    def __getitem__(self, index: int) -> "FruitSlice":
+        return self.get_slice(index)
+
+
+class FruitSlice:
+    """One slice: preparateurs -> (chained) ISS -> sieves."""
+
+    def __init__(self) -> None:
+        self._preparateurs: list[Preparateur] = []
+        self._iss: list[ISS] = []
+        self._sieves: list[FeatureSieve] = []
+        # one list of fitted sieve copies per iterated sum
+        self._sieves_extended: list[list[FeatureSieve]] = []
+        self._fitted: bool = False
+        self.fit_sample_size: Union[float, int] = 1
+
+    # ---- configuration ------------------------------------------------------
+    def add_preparateur(self, preparateur: Preparateur) -> None:
+        if not isinstance(preparateur, Preparateur):
+            raise TypeError
+        self._preparateurs.append(preparateur)
+        self._fitted = False
+
+    def get_preparateurs(self) -> list[Preparateur]:
+        return self._preparateurs
+
+    def clear_preparateurs(self) -> None:
+        self._preparateurs = []
+        self._fitted = False
+
+    def add_iss(self, iss: ISS) -> None:
+        if not isinstance(iss, ISS):
+            raise TypeError
+        self._iss.append(iss)
+        self._fitted = False
+
+    def get_iss(self) -> list[ISS]:
+        return self._iss
+
+    def clear_iss(self) -> None:
+        self._iss = []
+        self._sieves_extended = []
+        self._fitted = False
+
+    def add_sieve(self, sieve: FeatureSieve) -> None:
+        if not isinstance(sieve, FeatureSieve):
+            raise TypeError
+        self._sieves.append(sieve)
+        self._fitted = False
+
+    def get_sieves(self) -> list[FeatureSieve]:
+        return self._sieves
+
+    def clear_sieves(self) -> None:
+        self._sieves = []
+        self._sieves_extended = []
+        self._fitted = False
+
+    def add(self, *objects: Union[Seed, Callable[[], Seed]]) -> None:
+        for obj in objects:
+            if inspect.isclass(obj):
+                obj = obj()
+            if isinstance(obj, Preparateur):
+                self.add_preparateur(obj)
+            elif isinstance(obj, ISS):
+                self.add_iss(obj)
+            elif isinstance(obj, FeatureSieve):
+                self.add_sieve(obj)
+            else:
+                raise TypeError(f"Cannot add variable of type {type(obj)}")
+
+    def clear(self) -> None:
+        self.clear_preparateurs()
+        self.clear_iss()
+        self.clear_sieves()
+        self.iss_mode = "single"
+        self.fit_sample_size = 1
+
+    def nfeatures(self) -> int:
+        return sum(s.nfeatures() for s in self._sieves) * self.niteratedsums()
+
+    def niteratedsums(self) -> int:
+        return int(np.prod([iss.n_iterated_sums() for iss in self._iss]))
+
+    def _compile(self) -> None:
+        if not self._iss:
+            raise RuntimeError("No ISS given")
+        if not self._sieves:
+            raise RuntimeError("No feature sieves given")
+
+    def _select_fit_sample(self, X: np.ndarray) -> np.ndarray:
+        # same draws from numpy's global generator as the reference
+        # (fruits/fruit.py:430-438) so a seeded run picks the same series
+        if isinstance(self.fit_sample_size, int) and self.fit_sample_size == 1:
+            ind = np.random.randint(0, X.shape[0])
+            return X[ind:ind + 1, :, :]
+        s = max(int(self.fit_sample_size * X.shape[0]), 1)
+        indices = np.random.choice(X.shape[0], size=s, replace=False)
+        return X[indices, :, :]
+
+    # ---- device pipeline --------------------------------------------------------
+    def _prepare_device(self, Xd, cache, callbacks=(), fit_on=None):
+        for prep in self._preparateurs:
+            prep._cache = cache
+            if fit_on is not None:
+                needs_host = type(prep)._fit is not Preparateur._fit
+                prep.fit(nat.to_host(Xd) if needs_host else fit_on)
+            Xd = prep._transform_device(Xd)
+            for cb in callbacks:
+                cb.on_preparateur(nat.to_host(Xd))
+        return Xd
+
+    def _iterate_iss_device(self, Xd, iss_index: int = 0) -> Generator:
+        """Yields every iterated sum as an (N, T) device tensor, in the order of
+        fruits/fruit.py:440-454 (chained ISS feed each row to the next ISS)."""
+        if iss_index == len(self._iss):
+            yield Xd[:, 0, :]
+            return
+        iss = self._iss[iss_index]
+        lookup = iss.lookup_device(Xd)
+        for s, e in iss.word_batches(int(Xd.shape[0]), int(Xd.shape[2])):
+            block = iss.transform_device(Xd, s, e, lookup)
+            for k in range(block.shape[0]):
+                if iss_index + 1 == len(self._iss):
+                    yield block[k]
+                else:
+                    yield from self._iterate_iss_device(block[k].unsqueeze(1), iss_index + 1)
+
+    def _attach(self, cache) -> None:
+        for iss in self._iss:
+            iss._cache = cache
+            iss._attach_cache(None)
+
+    # ---- fit / transform ----------------------------------------------------
+    def fit(self, X: np.ndarray, cache: Optional[SharedSeedCache] = None) -> None:
+        self._compile()
+        X = _check_batch(X)
+        if cache is None:
+            cache = SharedSeedCache(X)
+        sample = self._select_fit_sample(X)
+        Sd = self._prepare_device(nat.to_device(sample), cache, fit_on=sample)
+        self._attach(cache)
+        for iss in self._iss:
+            if iss.requires_fitting:
+                iss.fit(nat.to_host(Sd))
+        if not any(sieve.requires_fitting for sieve in self._sieves):
+            self._fitted = True
+            return
+        self._sieves_extended = []
+        for itsum in self._iterate_iss_device(Sd):
+            host = None
+            fitted = [sieve.copy() for sieve in self._sieves]
+            for sieve in fitted:
+                sieve._cache = cache
+                if sieve.requires_fitting:
+                    if host is None:
+                        host = nat.to_host(itsum)
+                    sieve.fit(host)
+            self._sieves_extended.append(fitted)
+        self._fitted = True
+
+    def transform(self, X: np.ndarray,
+                  callbacks: Optional[list[AbstractCallback]] = None,
+                  cache: Optional[SharedSeedCache] = None) -> np.ndarray:
+        callbacks = callbacks or []
+        if not self._fitted:
+            raise RuntimeError("Missing call of self.fit")
+        X = _check_batch(X)
+        if cache is None:
+            cache = SharedSeedCache(X)
+        t = nat.torch()
+        Xd = cache.input_device(X) if cache._input is X else nat.to_device(X)
+        Pd = self._prepare_device(Xd, cache, callbacks)
+        for cb in callbacks:
+            cb.on_preparation_end(nat.to_host(Pd))
+        feats = t.zeros((X.shape[0], self.nfeatures()), dtype=t.float64, device=Pd.device)
+        self._attach(cache)
+        col = 0
+        for i, itsum in enumerate(self._iterate_iss_device(Pd)):
+            for cb in callbacks:
+                cb.on_iterated_sum(nat.to_host(itsum))
+            sieves = self._sieves_extended[i] if self._sieves_extended else self._sieves
+            for sieve in sieves:
+                sieve._cache = cache
+                nf = sieve.nfeatures()
+                sieve.transform_device(itsum, feats, col)
+                for cb in callbacks:
+                    cb.on_sieve(nat.to_host(feats[col:col + nf]))
+                col += nf
+        out = nat.to_host(feats)
+        for cb in callbacks:
+            cb.on_sieving_end(out)
+        return out
+
+    def fit_transform(self, X: np.ndarray) -> np.ndarray:
+        self.fit(X)
+        return self.transform(X)
+
+    # ---- introspection ------------------------------------------------------
+    def summary(self) -> str:
+        def line(s: str) -> str:
+            return f"{s: <38}"
+
+        rows = [f"{f'FruitSlice -> {self.nfeatures()}': ^38}", 38 * "-",
+                line(f"Preparateurs ({len(self._preparateurs)}):")]
+        text = "\n".join(rows) + "\n"
+        text += "\n".join(line(f"    + {p}") for p in self._preparateurs)
+        if not self._preparateurs:
+            text += 38 * " "
+        text += "\n" + line(f"ISS Calculators ({len(self._iss)}):")
+        if not self._iss:
+            text += 38 * " "
+        for iss in self._iss:
+            text += "\n" + line(f"    + {iss} -> {iss.n_iterated_sums()}")
+            text += "\n" + line(f"       | words: {len(iss.words)}")
+            text += "\n" + line(f"       | semiring: {iss.semiring.__class__.__name__}")
+            wname = "None" if iss.weighting is None else iss.weighting.__class__.__name__
+            text += "\n" + line(f"       | weighting: {wname}")
+        if not self._iss:
+            text += "\n"
+        text += "\n" + line(f"Sieves ({len(self._sieves)}):")
+        if not self._sieves:
+            text += "\n" + 38 * " "
+        for sv in self._sieves:
+            text += "\n" + line(f"    + {sv.__class__.__name__} -> {sv.nfeatures()}")
+        return text
+
+    def copy(self) -> "FruitSlice":
+        dup = FruitSlice()
+        dup.add(*self._preparateurs, *self._iss, *self._sieves)
+        return dup
+
+    def deepcopy(self) -> "FruitSlice":
+        dup = FruitSlice()
+        for seed in (*self._preparateurs, *self._iss, *self._sieves):
+            dup.add(seed.copy())
+        dup.fit_sample_size = self.fit_sample_size
+        return dup
+
+    def label(self, index: int,
+              level: Literal["prepared", "iterated sums", "features"] = "features",
+              verbose: Literal[1, 2] = 1) -> str:
+        def short(label: str, sep: str) -> str:
+            return label.split(sep)[0] if verbose == 1 else label
+
+        if level == "prepared":
+            parts = [short(p.label(), "(") for p in self._preparateurs[:index + 1]]
+            return " -> ".join(parts) if parts else "input"
+        text = " -> ".join(short(p.label(), "(") for p in self._preparateurs)
+        if text:
+            text += " | "
+        findex = 0
+        if level == "features":
+            per_sum = int(np.sum([s.nfeatures() for s in self._sieves]))
+            index, findex = map(int, divmod(index, per_sum))
+        remaining = self.niteratedsums()
+        words = []
+        for iss in self._iss:
+            k = iss.n_iterated_sums()
+            words.append(short(iss.label(int((index % remaining) // (remaining / k))), " : "))
+            remaining /= k
+        text += " -> ".join(words)
+        if level == "iterated sums":
+            return text if text else "input"
+        if text:
+            text += " | "
+        for sieve in self._sieves:
+            if findex < sieve.nfeatures():
+                return text + sieve.label(findex)
+            findex -= sieve.nfeatures()
+        raise RuntimeError("Feature index out of range")

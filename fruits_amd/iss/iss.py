@@ -1,0 +1,199 @@
+"""The ISS stage (mirrors fruits/iss/iss.py).
+
+``ISS(words, mode=..., semiring=..., weighting=...)`` computes the iterated sums
+``(K, N, T)`` of a batch ``(N, D, T)``.  Where the reference loops over the words
+in Python and calls one numba kernel per word (fruits/iss/iss.py:49-65), this
+stage compiles the whole word list into ONE device program (a prefix trie in DFS
+order, csrc/plan.cpp) and walks it in one HIP launch; the result has the
+reference's row order and layout (iss.py:46).
+"""
+from __future__ import annotations
+
+import os
+from enum import Enum, auto
+from typing import Generator, Optional, Sequence
+
+import numpy as np
+
+from .. import _native as nat
+from ..cache import SharedSeedCache
+from ..seed import Seed
+from .cache import CachePlan
+from .semiring import Arctic, Reals, Semiring
+from .weighting import Weighting
+from .words.word import SimpleWord, Word
+
+
+class ISSMode(Enum):
+    """SINGLE: one iterated sum per word.  EXTENDED: additionally every prefix
+    of every word that no earlier word already produced."""
+
+    SINGLE = auto()
+    EXTENDED = auto()
+
+
+def _device_budget_bytes() -> int:
+    return int(float(os.environ.get("FRUITS_AMD_ISS_GIB", "8")) * (1 << 30))
+
+
+class ISS(Seed):
+    def __init__(self, words: Sequence[Word], /, *, mode: ISSMode = ISSMode.SINGLE,
+                 semiring: Optional[Semiring] = None,
+                 weighting: Optional[Weighting] = None) -> None:
+        self.words = words
+        self.mode = mode
+        self.semiring = semiring if semiring is not None else Reals()
+        self._cache_plan = CachePlan(self.words if mode == ISSMode.EXTENDED else [])
+        self.weighting = weighting
+        self._plans: dict = {}
+
+    @property
+    def requires_fitting(self) -> bool:
+        return False
+
+    def _fit(self, X: np.ndarray) -> None:
+        pass
+
+    # ------------------------------------------------------------------ plans
+    def _depth(self, i: int) -> int:
+        return self._cache_plan.unique_el_depth(i) if self.mode == ISSMode.EXTENDED else 1
+
+    def _rows_of(self, start: int, stop: int) -> int:
+        return sum(self._depth(i) for i in range(start, stop))
+
+    def _check_supported(self) -> None:
+        if isinstance(self.semiring, Arctic) and self.semiring._argmax \
+                and self.mode == ISSMode.SINGLE:
+            raise NotImplementedError(
+                "Arctic argmax is not implemented when using ISSMode.SINGLE")
+        if not isinstance(self.semiring, Reals):
+            raise NotImplementedError(
+                f"semiring {type(self.semiring).__name__} is not on the MI355X hot path")
+        for w in self.words:
+            if not isinstance(w, SimpleWord):
+                raise NotImplementedError(
+                    "only SimpleWord is supported by the MI355X implementation")
+
+    def _plan(self, start: int, stop: int) -> nat.Plan:
+        if self.weighting is None:
+            wmode, alphas = nat.FR_W_NONE, None
+        else:
+            wmode = nat.FR_W_TOTAL if self.weighting.total else nat.FR_W_NONTOTAL
+            alphas = [np.asarray(self.words[i].alpha, dtype=np.float32)
+                      for i in range(start, stop)]
+        key = (start, stop, self.mode, wmode,
+               None if alphas is None else tuple(a.tobytes() for a in alphas))
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = nat.Plan([self.words[i].table() for i in range(start, stop)],
+                            [self._depth(i) for i in range(start, stop)],
+                            alphas, wmode)
+            self._plans[key] = plan
+        return plan
+
+    # ------------------------------------------------------------------ device path
+    def _attach_cache(self, X) -> None:
+        if self.weighting is None:
+            return
+        if hasattr(self, "_cache"):
+            self.weighting._cache = self._cache
+        else:
+            self.weighting._cache = SharedSeedCache(X)
+
+    def lookup_device(self, Xd):
+        """(rows, T) device lookup of the weighting, rows in {1, N}; when the
+        cache holds more series than Xd (fit on a sub-sample) the leading rows
+        are used - the reference indexes ``lookup[j]`` by position
+        (fruits/iss/semiring.py:185-199)."""
+        if self.weighting is None:
+            return None
+        lk = self.weighting.lookup_device(Xd)
+        n = int(Xd.shape[0])
+        if lk.shape[0] != 1:
+            if lk.shape[0] < n:
+                raise IndexError("weighting lookup has fewer rows than the input")
+            lk = lk[:n]
+        return lk.contiguous()
+
+    def word_batches(self, N: int, T: int, batch_size: Optional[int] = None):
+        """[start, stop) word ranges: ``batch_size`` words each, or as many as
+        fit the device budget."""
+        W = len(self.words)
+        if batch_size is not None:
+            return [(s, min(s + batch_size, W)) for s in range(0, W, batch_size)]
+        budget = max(_device_budget_bytes() // max(8 * N * T, 1), 1)
+        out, s = [], 0
+        while s < W:
+            e, rows = s, 0
+            while e < W and (e == s or rows + self._depth(e) <= budget):
+                rows += self._depth(e)
+                e += 1
+            out.append((s, e))
+            s = e
+        return out
+
+    def transform_device(self, Xd, start: int = 0, stop: Optional[int] = None,
+                         lookup_d="auto", out=None, groups: int = 0):
+        """Iterated sums of words [start, stop) as a (K, N, T) device tensor."""
+        self._check_supported()
+        stop = len(self.words) if stop is None else stop
+        plan = self._plan(start, stop)
+        if plan.max_dim > Xd.shape[1]:
+            raise IndexError(
+                f"a word references dimension {plan.max_dim} but the input has "
+                f"only {Xd.shape[1]}")
+        if isinstance(lookup_d, str):
+            lookup_d = self.lookup_device(Xd)
+        return plan.run(Xd, lookup_d, out=out, layout="KNT", groups=groups)
+
+    # ------------------------------------------------------------------ reference API
+    @staticmethod
+    def _validate(X) -> np.ndarray:
+        if not isinstance(X, np.ndarray) or X.dtype != np.float64 or X.ndim != 3:
+            raise TypeError("input has to be a float64 array of shape (N, D, T)")
+        return X
+
+    def _transform(self, X: np.ndarray) -> np.ndarray:
+        X = self._validate(X)
+        self._attach_cache(X)
+        Xd = nat.to_device(X)
+        return nat.to_host(self.transform_device(Xd))
+
+    def n_iterated_sums(self) -> int:
+        """Number of iterated sums ``transform`` returns."""
+        if self.mode == ISSMode.EXTENDED:
+            if isinstance(self.semiring, Arctic) and self.semiring._argmax:
+                return sum(len(w) + len(w) * (len(w) + 1) // 2 for w in self.words)
+            return self._cache_plan.n_iterated_sums()
+        if isinstance(self.semiring, Arctic) and self.semiring._argmax:
+            raise NotImplementedError(
+                "Arctic argmax is not implemented when using ISSMode.SINGLE")
+        return len(self.words)
+
+    def batch_transform(self, X: np.ndarray,
+                        batch_size: int = 1) -> Generator[np.ndarray, None, None]:
+        """Yields ``(k, N, T)`` arrays, the iterated sums of ``batch_size`` words
+        at a time (fruits/iss/iss.py:152-185)."""
+        if batch_size > len(self.words):
+            raise ValueError("batch_size too large, has to be < len(words)")
+        X = self._validate(X)
+        self._attach_cache(X)
+        Xd = nat.to_device(X)
+        lookup_d = self.lookup_device(Xd)
+        for s, e in self.word_batches(X.shape[0], X.shape[2], batch_size):
+            yield nat.to_host(self.transform_device(Xd, s, e, lookup_d))
+
+    def _copy(self) -> "ISS":
+        return ISS(self.words, mode=self.mode, semiring=self.semiring,
+                   weighting=self.weighting)
+
+    def _label(self, index: int) -> str:
+        if self.mode == ISSMode.EXTENDED:
+            text = self._cache_plan.get_word_string(index)
+        else:
+            text = str(self.words[index])
+        if not isinstance(self.semiring, Reals):
+            text += " : " + self.semiring.__class__.__name__
+        if self.weighting is not None:
+            text += " : " + self.weighting.__class__.__name__
+        return text

@@ -1,0 +1,193 @@
+/*
+ * fruits_hip.h - C ABI of libfruits_hip.so: the MI355X (gfx950) implementation
+ * of the FRUITS iterated-sums hot path (INC -> Reals ISS over SimpleWords ->
+ * NPI / END [+ MPI]).
+ *
+ * Plain C: pointers, sizes, opaque handles.  No torch / HIP types in any
+ * signature.  Every entry point names the reference interface it replaces
+ * (paths relative to the irkri/fruits tree @ 2025-09-05).
+ *
+ * Conventions
+ *   - "d_" pointers are DEVICE pointers (hipMalloc / torch CUDA tensors);
+ *     "h_" pointers are HOST pointers.  All float data is IEEE binary64,
+ *     C-contiguous, exactly like the reference's numba signatures
+ *     (f8 arrays; i4 word tables; f4 alpha; i8 cuts).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *     Device entry points only ENQUEUE work; they never allocate, free or
+ *     synchronise, so they may be captured into a hipGraph.
+ *   - Return value: 0 = ok, <0 = error (FR_E_*); fr_last_error() returns a
+ *     thread-local message.  Nothing here ever falls back to a CPU path: with
+ *     no HIP device every compute call fails with FR_E_HIP.
+ */
+#ifndef FRUITS_HIP_H
+#define FRUITS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FR_OK 0
+#define FR_E_ARG (-1)    /* bad shape / null pointer / out-of-range value      */
+#define FR_E_DIM (-2)    /* a word names a dimension > D (the reference reads
+                            out of bounds silently, fruits/iss/semiring.py:146) */
+#define FR_E_HIP (-3)    /* HIP runtime error (no device, launch failure, ...)  */
+#define FR_E_NOMEM (-4)  /* workspace too small / allocation failure            */
+#define FR_E_LIMIT (-5)  /* plan exceeds a compiled-in limit                    */
+
+/* weighting modes of fr_plan_create */
+#define FR_W_NONE 0      /* weighting is None  -> semiring.py:27-28,35 (alpha=0, lookup=0, total) */
+#define FR_W_NONTOTAL 1  /* Weighting(total=False) -> _reals_single, semiring.py:93-125           */
+#define FR_W_TOTAL 2     /* Weighting(total=True)  -> _total_weighted_reals_single, :128-158      */
+
+/* plan flags */
+#define FR_PLAN_SHARE_PREFIXES 1 /* walk the prefix trie (K scans); 0 = one chain
+                                    per word, prefixes recomputed like the reference */
+
+/* fr_plan_info selectors */
+#define FR_INFO_ROWS 0       /* K = number of output rows (iterated sums)        */
+#define FR_INFO_NODES 1      /* scan passes the device performs                  */
+#define FR_INFO_LEVELS 2     /* register frames the walk needs                   */
+#define FR_INFO_DIMS_USED 3  /* distinct input dimensions referenced             */
+#define FR_INFO_MAX_DIM 4    /* highest dimension referenced (1-based)           */
+#define FR_INFO_ALPHAS 5     /* distinct alpha values (exp tables = 2 per alpha) */
+#define FR_INFO_GROUPS 6     /* independent sub-tries (upper bound of `groups`)  */
+#define FR_INFO_SHARED 7     /* 1 if prefixes are shared                         */
+
+/* sieve kinds of fr_sieve_* and the fused pipeline */
+#define FR_SIEVE_NPI 0 /* fruits/sieving/increment.py:101-129 */
+#define FR_SIEVE_MPI 1 /* fruits/sieving/increment.py:132-163 */
+#define FR_SIEVE_END 2 /* fruits/sieving/segment.py:203-225   */
+
+typedef struct fr_plan fr_plan_t;
+
+/* ------------------------------------------------------------------ misc */
+const char *fr_last_error(void);
+int fr_version(void);
+/* Number of HIP devices (0 when there is none; never an error). */
+int fr_device_count(void);
+/* Convenience for callers without their own allocator (cgo, plain ctypes). */
+int fr_malloc(void **d_ptr, int64_t bytes);
+int fr_free(void *d_ptr);
+int fr_memcpy_h2d(void *d_dst, const void *h_src, int64_t bytes, void *stream);
+int fr_memcpy_d2h(void *h_dst, const void *d_src, int64_t bytes, void *stream);
+int fr_stream_sync(void *stream);
+
+/* ------------------------------------------------------------------ plan
+ * Replaces the word loop of _calculate_ISS (fruits/iss/iss.py:21-67) plus the
+ * per-word marshalling of Semiring.iterated_sums (fruits/iss/semiring.py:14-41)
+ * and CachePlan's depths (fruits/iss/cache.py:17-43).
+ *
+ *   W        number of words
+ *   exps     concatenated exponent tables; word i is (L[i], Dw[i]) int32
+ *            row-major == np.array(list(word), dtype=np.int32) (semiring.py:31)
+ *   alpha    concatenated per-letter alphas (sum of L[i] floats) == word.alpha
+ *            (fruits/iss/words/word.py:71-82); NULL when weighting == FR_W_NONE
+ *   depth    depth[i] = CachePlan.unique_el_depth(i) in EXTENDED mode, 1 in
+ *            SINGLE mode: number of trailing prefixes of word i that are output
+ *   Output row order is the reference's: words in order, within a word the
+ *   shortest emitted prefix first (iss.py:55-63).
+ */
+fr_plan_t *fr_plan_create(int32_t W, const int32_t *exps, const int32_t *L,
+                          const int32_t *Dw, const float *alpha,
+                          const int32_t *depth, int32_t weighting, int32_t flags);
+void fr_plan_destroy(fr_plan_t *plan);
+int64_t fr_plan_info(const fr_plan_t *plan, int32_t what);
+/* Debug / test view of the compiled program: writes up to `cap` int32 words
+ * (8 per node: level, flags, n_factors, n_emit, first_emit_row, emit_mul,
+ * z_mul, group) and returns the number of nodes. */
+int32_t fr_plan_dump(const fr_plan_t *plan, int32_t *buf, int32_t cap);
+/* Bytes of device workspace fr_iss_run needs for this plan and shape
+ * (exp tables for weighted plans, chunk carries for T > one chunk). */
+int64_t fr_plan_workspace_bytes(const fr_plan_t *plan, int64_t N, int64_t T,
+                                int64_t lookup_rows);
+
+/* ------------------------------------------------------------------ ISS
+ * Replaces Reals._iterated_sum_fast for ALL words of the plan in one launch
+ * (fruits/iss/semiring.py:167-201, called per word from iss.py:55-63).
+ *
+ *   d_X            (N, D, T) f64
+ *   d_lookup       (lookup_rows, T) f64, lookup_rows in {1, N}: Weighting.get_lookup
+ *                  (fruits/iss/weighting.py:100-110, 148-160); a 1-row lookup is
+ *                  broadcast over N (Indices); NULL iff the plan is FR_W_NONE
+ *   d_out          element (k, n, t) is written at
+ *                  d_out[k*out_k_stride + n*out_n_stride + t];
+ *                  (K,N,T) results of iss.py:46 => strides (N*T, T);
+ *                  (N,E,T) result of semiring.py:177 => strides (T, E*T)
+ *   d_work         workspace of >= fr_plan_workspace_bytes() bytes (may be NULL
+ *                  when that is 0)
+ *   groups         0 = choose; otherwise number of sub-trie groups per series
+ */
+int fr_iss_run(fr_plan_t *plan, const double *d_X, int64_t N, int64_t D, int64_t T,
+               const double *d_lookup, int64_t lookup_rows, double *d_out,
+               int64_t out_k_stride, int64_t out_n_stride, void *d_work,
+               int64_t work_bytes, int32_t groups, void *stream);
+
+/* Drop-in for Semiring.iterated_sum_fast (fruits/iss/semiring.py:43-52,203-219),
+ * host arrays in, host array out, synchronous:
+ *   Z (N,D,T) f64, word (L,Dw) i32, alpha (L) f32, lookup (N,T) f64 or NULL
+ *   (NULL = the unweighted call of semiring.py:27-28), extended in [1,L],
+ *   total_weighting -> out (N, extended, T) f64 (caller allocated). */
+int fr_iterated_sum_fast_host(const double *h_Z, int64_t N, int64_t D, int64_t T,
+                              const int32_t *word, int32_t L, int32_t Dw,
+                              const float *alpha, const double *h_lookup,
+                              int64_t extended, int32_t total_weighting,
+                              double *h_out);
+
+/* ------------------------------------------------------------------ INC
+ * Replaces _increments (fruits/cache.py:8-13) as used by INC._transform
+ * (fruits/preparation/transform.py:60-75): rows = N*D series of length T,
+ * out[r, t] = x[r, t] - x[r, t-shift] for t >= shift, else 0; when
+ * keep_head != 0 the first `head` values are copied from d_head_src instead
+ * (zero_padding=False, transform.py:73-74). */
+int fr_increments(const double *d_X, int64_t rows, int64_t T, int64_t shift,
+                  double *d_out, const double *d_head_src, int64_t head, void *stream);
+
+/* ------------------------------------------------------------------ lookups
+ * L1.get_lookup (fruits/iss/weighting.py:148-160) on top of _L1_sum
+ * (fruits/cache.py:25-31) and NRM (fruits/preparation/transform.py:184-198):
+ * g[n,t] = scale * minmax_t(cumsum_t |x_0[t]-x_0[t-1]|), optionally divided by
+ * (last + 1e-5) first (relative = 1); constant rows give 0.  relative = 2 returns
+ * the raw cumulative path length (the SharedSeedCache entry, cache.py:108-112).
+ * d_X is (N, D, T), only dimension 0 is read (cache.py:27).
+ * norm: 1 = L1 (abs), 2 = L2 (square). */
+int fr_pathlen_lookup(const double *d_X, int64_t N, int64_t D, int64_t T,
+                      int32_t norm, int32_t relative, double scale,
+                      double *d_out /* (N,T) */, void *stream);
+
+/* ------------------------------------------------------------------ sieves
+ * Replace IncrementSieve._pre_transform + NPI/MPI._backend
+ * (fruits/sieving/increment.py:63-71, 107-129, 138-163) and END._transform
+ * (fruits/sieving/segment.py:210-219) on a materialised (N, T) iterated sum.
+ *
+ *   d_A      (N, T) f64, row stride a_stride elements
+ *   inc      >= 0: number of increment passes fused into the load
+ *   d_cuts   (cut_rows, C1) i64, cut_rows in {1, N}; sorted, leading 0
+ *            (segment.py:51-64); a 1-row table is broadcast over N
+ *   d_q      (Q1) f64 sorted quantile thresholds (segment.py:66-85)
+ *   d_out    feature (n, j*(Q1-1)+k) at d_out[n*out_stride + j*(Q1-1)+k]
+ *            (END: Q1 is ignored, feature j at d_out[n*out_stride + j])
+ */
+int fr_sieve(int32_t kind, const double *d_A, int64_t N, int64_t T, int64_t a_stride,
+             int32_t inc, const int64_t *d_cuts, int64_t cut_rows, int32_t C1,
+             const double *d_q, int32_t Q1, double *d_out, int64_t out_stride,
+             void *stream);
+
+/* IncrementSieve._pre_transform alone (fruits/sieving/increment.py:63-71, inc >= 0),
+ * materialised: d_out (N, T) contiguous.  Used by fit, which needs the values for
+ * np.quantile (fruits/sieving/segment.py:66-75). */
+int fr_pre_transform(const double *d_A, int64_t N, int64_t T, int64_t a_stride, int32_t inc,
+                     double *d_out, void *stream);
+
+/* ------------------------------------------------------------------ STD ("next" row)
+ * STD._transform with separately=True (fruits/preparation/transform.py:141-147):
+ * every one of the rows = N*D series becomes (x - mean) / (std + eps); std is the
+ * population standard deviation (np.std), or 1 when div_std == 0. */
+int fr_standardize(const double *d_X, int64_t rows, int64_t T, int32_t div_std, double eps,
+                   double *d_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRUITS_HIP_H */
