@@ -123,7 +123,7 @@ Plan *build_plan(int W, const int32_t *exps, const int32_t *L, const int32_t *Dw
     return nullptr;
   }
   for (int i = 0; i < W; ++i) {
-    if (L[i] < 1 || Dw[i] < 1 || depth[i] < 1 || depth[i] > L[i]) {
+    if (L[i] < 1 || Dw[i] < 1 || depth[i] < 0 || depth[i] > L[i]) {
       err = "fr_plan_create: word " + std::to_string(i) + " has invalid L/Dw/depth";
       return nullptr;
     }
@@ -166,7 +166,9 @@ Plan *build_plan(int W, const int32_t *exps, const int32_t *L, const int32_t *Dw
     int row = 0;
     for (int i = 0; i < W; ++i) {
       int cur = 0;
-      for (int k = 0; k < L[i]; ++k) {
+      // depth 0: every prefix of the word was already output by an earlier word
+      // (CachePlan can say so); the word contributes neither rows nor work
+      for (int k = 0; k < (depth[i] > 0 ? L[i] : 0); ++k) {
         Key key;
         key.exps.assign(e + (size_t)k * Dw[i], e + (size_t)(k + 1) * Dw[i]);
         while (!key.exps.empty() && key.exps.back() == 0) key.exps.pop_back();

@@ -86,6 +86,8 @@ int fr_stream_sync(void *stream);
  *            (fruits/iss/words/word.py:71-82); NULL when weighting == FR_W_NONE
  *   depth    depth[i] = CachePlan.unique_el_depth(i) in EXTENDED mode, 1 in
  *            SINGLE mode: number of trailing prefixes of word i that are output
+ *            (0 is legal: CachePlan gives 0 to a word that is a prefix of an
+ *            earlier word; it then contributes no rows)
  *   Output row order is the reference's: words in order, within a word the
  *   shortest emitted prefix first (iss.py:55-63).
  */

@@ -270,8 +270,9 @@ def compare_features(got, ref, labels, rtol=RTOL):
     is_count = np.array(["NPI" in lb for lb in labels])
     val = ~is_count
     if val.any():
-        scale = np.maximum(np.abs(ref[:, val]).max(axis=0, keepdims=True), 1e-300)
-        assert np.max(np.abs(got[:, val] - ref[:, val]) / scale) <= rtol
+        # atol: END of e.g. <[1]> on standardised data is an exact-zero sum, i.e.
+        # pure rounding noise (1e-15) in the reference and here
+        np.testing.assert_allclose(got[:, val], ref[:, val], rtol=rtol, atol=1e-9)
     if is_count.any():
         d = np.abs(got[:, is_count] - ref[:, is_count])
         assert d.max() <= 1
