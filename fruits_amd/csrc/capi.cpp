@@ -91,7 +91,7 @@ int choose_groups(const fr::Plan &p, int64_t N, int requested) {
   if (G <= 0) G = env_int("FRUITS_HIP_GROUPS", 0);
   if (G <= 0) {
     // aim for a few thousand workgroups (256 CUs x several resident each)
-    const int64_t target = 4096;
+    const int64_t target = 2048;
     G = (int)((target + N - 1) / (N > 0 ? N : 1));
   }
   if (G > U) G = U;

@@ -20,6 +20,18 @@ namespace fr {
 
 typedef double vd2 __attribute__((ext_vector_type(2)));
 
+// The program tables are read-only for the whole launch.  Reading them through
+// the constant address space makes every (wave-uniform) access a scalar load
+// (s_load, counted by lgkmcnt).  As plain global loads they would be VECTOR loads
+// counted by vmcnt, and waiting for one of those also waits for every output
+// store issued before it - serialising the store stream node by node.
+template <class T>
+using cptr = const T __attribute__((address_space(4))) *;
+template <class T>
+__device__ __forceinline__ cptr<T> as_const(const T *p) {
+  return (cptr<T>)(p);
+}
+
 // ---------------------------------------------------------------- wave scan
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_fetch(double v) {
@@ -44,9 +56,18 @@ __device__ __forceinline__ double wave_shift_right1(double v) {
   return dpp_fetch<0x138, 0xf>(v);  // wave_shr:1, lane 0 gets 0.0
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for
+// vmcnt(0), i.e. for the acknowledgement of every global store the wave has in
+// flight - that would serialise each node's output stores with the next node's
+// scan.  Waiting for lgkmcnt(0) alone keeps the stores streaming.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---------------------------------------------------------------- walk kernel
-template <int E_, int P_, int MAXLV_>
+template <int E_, int P_, int MAXLV_, bool MULTI_>
 struct WalkCfg {
+  static constexpr bool MULTI = MULTI_;  // more than one time chunk (carries in memory)
   static constexpr int E = E_;          // contiguous elements per thread per piece
   static constexpr int P = P_;          // pieces per thread
   static constexpr int EP = E_ * P_;
@@ -91,8 +112,10 @@ __device__ __forceinline__ void block_scan(WalkCtx &cx, const double (&s)[C::EP]
     for (int h = 0; h < P; ++h) tot[h * NW + cx.wave] = incl[h];
   }
   double run = 0.0;
-  if (cx.carry != nullptr && !cx.first_chunk) run = cx.carry[carry_slot];
-  __syncthreads();
+  if constexpr (C::MULTI) {
+    if (!cx.first_chunk) run = cx.carry[carry_slot];
+  }
+  lds_barrier();
   double base[P] = {};
 #pragma unroll
   for (int h = 0; h < P; ++h) {
@@ -104,7 +127,9 @@ __device__ __forceinline__ void block_scan(WalkCtx &cx, const double (&s)[C::EP]
   }
   cx.buf ^= 1;
   // every wave stores the same value; a wave only ever re-reads its own store
-  if (cx.carry != nullptr && cx.lane == 0) cx.carry[carry_slot] = run;
+  if constexpr (C::MULTI) {
+    if (cx.lane == 0) cx.carry[carry_slot] = run;
+  }
 #pragma unroll
   for (int h = 0; h < P; ++h) {
     const double off = base[h] + excl[h];
@@ -156,7 +181,7 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const NodeDesc &nd, in
 #pragma unroll
   for (int i = 0; i < EP; ++i) s[i] = pin[i];
   for (int f = 0; f < nd.fac_count; ++f) {
-    const int fe = a.factors[nd.fac_begin + f];
+    const int fe = as_const(a.factors)[nd.fac_begin + f];
     const double *row = cx.rows + (fe & FAC_ROW_MASK) * C::CHUNK + cx.tid * E;
     if (fe & FAC_DIV) {
 #pragma unroll
@@ -185,7 +210,7 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const NodeDesc &nd, in
           for (int e = 0; e < E; ++e) c[h * E + e] = c[h * E + e] * row[h * C::PIECE + e];
       }
       for (int j = 0; j < nd.emit_count; ++j) {
-        const int64_t k = a.emit_rows[nd.emit_begin + j];
+        const int64_t k = as_const(a.emit_rows)[nd.emit_begin + j];
         emit_store<C>(cx, c, cx.out_base + k * a.out_k_stride);
       }
     }
@@ -209,11 +234,10 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const NodeDesc &nd, in
 
 __device__ __forceinline__ NodeDesc load_node(const NodeDesc *nodes, int pc) {
   // uniform address -> scalar loads
-  const int4 *q = reinterpret_cast<const int4 *>(nodes + pc);
-  int4 lo = q[0], hi = q[1];
+  cptr<int32_t> q = as_const(reinterpret_cast<const int32_t *>(nodes + pc));
   NodeDesc nd;
-  nd.level = lo.x; nd.flags = lo.y; nd.fac_begin = lo.z; nd.fac_count = lo.w;
-  nd.emit_begin = hi.x; nd.emit_count = hi.y; nd.emit_mul = hi.z; nd.z_mul = hi.w;
+  nd.level = q[0]; nd.flags = q[1]; nd.fac_begin = q[2]; nd.fac_count = q[3];
+  nd.emit_begin = q[4]; nd.emit_count = q[5]; nd.emit_mul = q[6]; nd.z_mul = q[7];
   return nd;
 }
 
@@ -224,17 +248,17 @@ __device__ __forceinline__ void walk(WalkCtx &cx, const double (&pin)[C::EP], in
     NodeDesc nd = load_node(a.nodes, pc);
     if (nd.level != LV) break;
     double pout[C::EP];
-    process_node<C>(cx, nd, a.node_ids[pc], pin, pout);
+    process_node<C>(cx, nd, as_const(a.node_ids)[pc], pin, pout);
     ++pc;
     // only children continue in place in this frame
     while (pc < cx.node_end) {
       NodeDesc nc = load_node(a.nodes, pc);
       if (!(nc.flags & F_CHAIN) || nc.level != LV) break;
-      process_node<C>(cx, nc, a.node_ids[pc], pout, pout);
+      process_node<C>(cx, nc, as_const(a.node_ids)[pc], pout, pout);
       ++pc;
     }
     if constexpr (LV + 1 < C::MAXLV) {
-      if (pc < cx.node_end && a.nodes[pc].level == LV + 1) walk<C, LV + 1>(cx, pout, pc);
+      if (pc < cx.node_end && load_node(a.nodes, pc).level == LV + 1) walk<C, LV + 1>(cx, pout, pc);
     }
   }
 }
@@ -269,8 +293,8 @@ __global__ __launch_bounds__(kWalkThreads) void iss_walk_kernel(const IssArgs a)
   cx.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   cx.buf = 0;
   cx.carry = a.carry ? a.carry + n * (2 * (int64_t)a.total_nodes) : nullptr;
-  const int node_begin = a.group_begin[g];
-  cx.node_end = a.group_begin[g + 1];
+  const int node_begin = as_const(a.group_begin)[g];
+  cx.node_end = as_const(a.group_begin)[g + 1];
   double *rows_w = lds;
 
   for (int64_t chunk = 0; chunk < a.nchunks; ++chunk) {
@@ -278,10 +302,10 @@ __global__ __launch_bounds__(kWalkThreads) void iss_walk_kernel(const IssArgs a)
     cx.t0 = t0;
     cx.first_chunk = chunk == 0;
     cx.out_base = a.out + n * a.out_n_stride + t0;
-    if (chunk > 0) __syncthreads();
+    if (chunk > 0) lds_barrier();
     // stage the referenced rows of this chunk
     for (int r = 0; r < a.R; ++r) {
-      const int src = a.row_src[r];
+      const int src = as_const(a.row_src)[r];
       const double *gp = src >= 0
                              ? a.X + (n * a.D + src) * a.T
                              : a.aux + (int64_t)(-src - 1) * a.aux_tab_stride + n * a.aux_n_stride;
@@ -557,9 +581,9 @@ __global__ __launch_bounds__(256) void standardize_kernel(const double *__restri
 }
 
 // ---------------------------------------------------------------- launchers
-template <int E, int P, int LV>
+template <int E, int P, int LV, bool MULTI>
 static hipError_t launch_walk_cfg(const IssArgs &a, int64_t blocks, hipStream_t st) {
-  using C = WalkCfg<E, P, LV>;
+  using C = WalkCfg<E, P, LV, MULTI>;
   const size_t lds = ((size_t)a.R * C::CHUNK + 2 * P * (kWalkThreads / 64)) * sizeof(double);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (lds > 64 * 1024) {
@@ -571,12 +595,12 @@ static hipError_t launch_walk_cfg(const IssArgs &a, int64_t blocks, hipStream_t 
   return hipGetLastError();
 }
 
-template <int E, int P>
+template <int E, int P, bool MULTI>
 static hipError_t launch_walk_lv(const IssArgs &a, int levels, int64_t blocks, hipStream_t st) {
-  if (levels <= 2) return launch_walk_cfg<E, P, 2>(a, blocks, st);
-  if (levels <= 4) return launch_walk_cfg<E, P, 4>(a, blocks, st);
-  if (levels <= 8) return launch_walk_cfg<E, P, 8>(a, blocks, st);
-  return launch_walk_cfg<E, P, kMaxLevels>(a, blocks, st);
+  if (levels <= 2) return launch_walk_cfg<E, P, 2, MULTI>(a, blocks, st);
+  if (levels <= 4) return launch_walk_cfg<E, P, 4, MULTI>(a, blocks, st);
+  if (levels <= 8) return launch_walk_cfg<E, P, 8, MULTI>(a, blocks, st);
+  return launch_walk_cfg<E, P, kMaxLevels, MULTI>(a, blocks, st);
 }
 
 int walk_chunk_elems(int64_t T) { return T <= 512 ? 512 : 1024; }
@@ -587,8 +611,10 @@ hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st) {
   const int64_t blocks = a.N * a.G;
   if (blocks <= 0) return hipSuccess;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-  if (chunk == 512) return launch_walk_lv<2, 1>(a, levels, blocks, st);
-  return launch_walk_lv<2, 2>(a, levels, blocks, st);
+  if (chunk == 512) return launch_walk_lv<2, 1, false>(a, levels, blocks, st);
+  if (a.nchunks == 1) return launch_walk_lv<2, 2, false>(a, levels, blocks, st);
+  if (a.carry == nullptr) return hipErrorInvalidValue;
+  return launch_walk_lv<2, 2, true>(a, levels, blocks, st);
 }
 
 hipError_t launch_exp_tables(const double *g, int64_t count, const float *alphas, int n_alpha,
