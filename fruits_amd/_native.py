@@ -209,7 +209,7 @@ class Plan:
         return int(lib().fr_plan_workspace_bytes(self._h, N, T, lookup_rows))
 
     def run(self, Xd, lookup_d=None, out=None, layout: str = "KNT", groups: int = 0,
-            work=None):
+            work=None, strides=None):
         """Launches the trie walk on the current stream.
 
         Xd (N,D,T) f64 cuda; lookup_d (1|N, T) f64 cuda or None.
@@ -223,7 +223,9 @@ class Plan:
         if out is None:
             shape = (K, N, T) if layout == "KNT" else (N, K, T)
             out = t.empty(shape, dtype=t.float64, device=Xd.device)
-        if layout == "KNT":
+        if strides is not None:
+            sk, sn = strides   # caller-laid-out buffer (element strides of k and n)
+        elif layout == "KNT":
             sk, sn = N * T, T
         else:
             sk, sn = T, K * T
@@ -240,8 +242,9 @@ class Plan:
         rc = lib().fr_iss_run(
             self._h, dptr(Xd), C.c_int64(N), C.c_int64(D), C.c_int64(T),
             dptr(lookup_d if self.weighting != FR_W_NONE else None), C.c_int64(rows),
-            dptr(out), C.c_int64(sk), C.c_int64(sn), dptr(work if wb > 0 else None),
-            C.c_int64(wb), C.c_int32(groups), stream_ptr())
+            dptr(out), C.c_int64(sk), C.c_int64(sn), dptr(work),
+            C.c_int64(work.numel() if work is not None else 0), C.c_int32(groups),
+            stream_ptr())
         check(rc, "fr_iss_run")
         return out
 

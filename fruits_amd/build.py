@@ -35,7 +35,7 @@ def needs_build() -> bool:
 def build_native(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + (["-DFRUITS_HIP_TIMING_BUILD"] if os.environ.get("FRUITS_HIP_TIMING_BUILD") else []) + [
            "-Wall", "-Wno-unused-function", "-o", LIB + ".tmp"]
     cmd += ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:

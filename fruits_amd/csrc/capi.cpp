@@ -48,18 +48,16 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 // fr_plan_prepare before graph capture).
 int ensure_device_program(fr::Plan &p, fr::GroupedProgram &gp) {
   if (gp.d_blob) return FR_OK;
-  const size_t n_nodes = gp.nodes.size();
+  const size_t n_recs = gp.recs.size();
   size_t off = 0;
-  const size_t o_nodes = off;       off = align_up(off + n_nodes * sizeof(fr::NodeDesc), 64);
-  const size_t o_ids = off;         off = align_up(off + n_nodes * 4, 64);
+  const size_t o_nodes = off;       off = align_up(off + n_recs * sizeof(fr::NodeRec), 64);
   const size_t o_gb = off;          off = align_up(off + gp.group_begin.size() * 4, 64);
   const size_t o_fac = off;         off = align_up(off + p.factors.size() * 4, 64);
   const size_t o_emit = off;        off = align_up(off + p.emit_rows.size() * 4, 64);
   const size_t o_rows = off;        off = align_up(off + p.row_src.size() * 4, 64);
   const size_t o_alpha = off;       off = align_up(off + p.alphas.size() * 4, 64);
   std::vector<char> host(off + 64, 0);
-  std::memcpy(host.data() + o_nodes, gp.nodes.data(), n_nodes * sizeof(fr::NodeDesc));
-  std::memcpy(host.data() + o_ids, gp.node_ids.data(), n_nodes * 4);
+  std::memcpy(host.data() + o_nodes, gp.recs.data(), n_recs * sizeof(fr::NodeRec));
   std::memcpy(host.data() + o_gb, gp.group_begin.data(), gp.group_begin.size() * 4);
   std::memcpy(host.data() + o_fac, p.factors.data(), p.factors.size() * 4);
   std::memcpy(host.data() + o_emit, p.emit_rows.data(), p.emit_rows.size() * 4);
@@ -74,8 +72,7 @@ int ensure_device_program(fr::Plan &p, fr::GroupedProgram &gp) {
   }
   char *b = static_cast<char *>(d);
   gp.d_blob = d;
-  gp.d_nodes = reinterpret_cast<const fr::NodeDesc *>(b + o_nodes);
-  gp.d_node_ids = reinterpret_cast<const int32_t *>(b + o_ids);
+  gp.d_recs = reinterpret_cast<const fr::NodeRec *>(b + o_nodes);
   gp.d_group_begin = reinterpret_cast<const int32_t *>(b + o_gb);
   gp.d_factors = reinterpret_cast<const int32_t *>(b + o_fac);
   gp.d_emit_rows = reinterpret_cast<const int32_t *>(b + o_emit);
@@ -268,8 +265,7 @@ int fr_iss_run(fr_plan_t *plan, const double *d_X, int64_t N, int64_t D, int64_t
   a.T = T;
   a.out_k_stride = out_k_stride;
   a.out_n_stride = out_n_stride;
-  a.nodes = gp.d_nodes;
-  a.node_ids = gp.d_node_ids;
+  a.recs = gp.d_recs;
   a.factors = gp.d_factors;
   a.emit_rows = gp.d_emit_rows;
   a.group_begin = gp.d_group_begin;
@@ -291,7 +287,15 @@ int fr_iss_run(fr_plan_t *plan, const double *d_X, int64_t N, int64_t D, int64_t
   a.vec_ok = (T % 2 == 0) && aligned16(d_X) && aligned16(d_out) && (out_k_stride % 2 == 0) &&
              (out_n_stride % 2 == 0) && (!a.aux || aligned16(a.aux));
   a.xcd_map = (a.G > 1 && N % 8 == 0) ? 1 : 0;
-  a.nt_store = env_int("FRUITS_HIP_NT", 0);
+  a.debug = env_int("FRUITS_HIP_DEBUG", 0);
+  if (a.debug & 16) {
+    // diagnostic build only: stamps go to the tail of the workspace if the caller
+    // sized it with FRUITS_HIP_DBG_BYTES extra bytes
+    const int64_t extra = env_int("FRUITS_HIP_DBG_BYTES", 0);
+    if (extra > 0 && d_work && work_bytes >= (int64_t)wl.total() + extra)
+      a.dbg = reinterpret_cast<unsigned long long *>(work + align_up(wl.total(), 256));
+  }
+  a.persistent = env_int("FRUITS_HIP_PERSIST", 1);
   hipError_t e = fr::launch_iss_walk(a, p.levels, st);
   if (e != hipSuccess) return hip_fail(e, "iss_walk launch");
   return FR_OK;

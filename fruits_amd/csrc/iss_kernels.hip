@@ -33,12 +33,19 @@ __device__ __forceinline__ cptr<T> as_const(const T *p) {
 }
 
 // ---------------------------------------------------------------- wave scan
+// DPP fetch of a double: the value of the source lane, 0.0 where the lane has no
+// source.  FULL = all rows enabled: bound_ctrl supplies the zeros and no "old"
+// value has to be materialised; otherwise disabled rows keep old = 0.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_fetch(double v) {
-  // value of the DPP source lane, 0.0 where there is no source / row disabled
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  if constexpr (ROW_MASK == 0xf) {
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  } else {
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  }
   return __hiloint2double(hi, lo);
 }
 
@@ -52,8 +59,32 @@ __device__ __forceinline__ double wave_inclusive_scan(double v) {
   return v;
 }
 
+// P independent scans, advanced step by step so their DPP latencies overlap
+template <int P>
+__device__ __forceinline__ void wave_inclusive_scan_multi(double (&v)[P]) {
+#pragma unroll
+  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x111, 0xf>(v[h]);
+#pragma unroll
+  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x112, 0xf>(v[h]);
+#pragma unroll
+  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x114, 0xf>(v[h]);
+#pragma unroll
+  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x118, 0xf>(v[h]);
+#pragma unroll
+  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x142, 0xa>(v[h]);
+#pragma unroll
+  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x143, 0xc>(v[h]);
+}
+
 __device__ __forceinline__ double wave_shift_right1(double v) {
   return dpp_fetch<0x138, 0xf>(v);  // wave_shr:1, lane 0 gets 0.0
+}
+
+__device__ __forceinline__ double wave_last_lane(double v) {
+  // lane 63's value as a wave-uniform (scalar) double
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for
@@ -65,37 +96,105 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // ---------------------------------------------------------------- walk kernel
-template <int E_, int P_, int MAXLV_, bool MULTI_>
+// Time layout of one chunk: wave w owns the contiguous span [w*SPAN, (w+1)*SPAN);
+// the span is P pieces of 64*E elements; lane l holds E consecutive elements of
+// every piece.  So every 16-byte global access of a wave is lane-contiguous
+// (E = 2: 1 KiB per instruction) and only NW wave totals cross waves.
+template <int E_, int P_, int MAXLV_, bool MULTI_, bool VEC_, bool WEIGHTED_>
 struct WalkCfg {
-  static constexpr bool MULTI = MULTI_;  // more than one time chunk (carries in memory)
-  static constexpr int E = E_;          // contiguous elements per thread per piece
-  static constexpr int P = P_;          // pieces per thread
+  static constexpr bool WEIGHTED = WEIGHTED_;  // exp tables in play (emit_mul / z_mul)
+  static constexpr bool VEC = VEC_;      // 16-byte global accesses are aligned
+  static constexpr int E = E_;          // contiguous elements per lane per piece
+  static constexpr int P = P_;          // pieces per wave
   static constexpr int EP = E_ * P_;
   static constexpr int MAXLV = MAXLV_;
-  static constexpr int PIECE = kWalkThreads * E_;  // elements per piece
-  static constexpr int CHUNK = PIECE * P_;         // elements per time chunk
+  static constexpr bool MULTI = MULTI_;  // more than one time chunk (carries in memory)
+  static constexpr int NW = kWalkThreads / 64;
+  static constexpr int PIECE = 64 * E_;          // elements per wave piece
+  static constexpr int SPAN = PIECE * P_;        // elements per wave
+  static constexpr int CHUNK = SPAN * NW;        // elements per time chunk
 };
+
+// LDS position of chunk element i (i even: 16-byte units never straddle).  For
+// E = 4 the two halves of a lane's 4 elements live in two planes so that every
+// ds_read_b128 of a wave is lane-contiguous (bank-conflict free).
+template <class C>
+__device__ __forceinline__ int lds_pos(int i) {
+  if constexpr (C::E == 2) {
+    return i;
+  } else {
+    static_assert(C::E == 4, "E must be 2 or 4");
+    const int blk = i >> 8, r = i & 255;
+    return (blk << 8) + ((r & 2) << 6) + ((r >> 2) << 1) + (r & 1);
+  }
+}
 
 struct WalkCtx {
   const IssArgs *a;
   const double *rows;   // LDS: staged rows [R][CHUNK]
-  double *tot;          // LDS: wave totals [2][P*NW]
+  double *tot;          // LDS: wave totals [2][NW]
   double *out_base;     // out + n*out_n_stride + t0
   double *carry;        // carry slots of this series (multi-chunk) or nullptr
   int64_t t0;           // first time index of the chunk
-  int node_end;
   int tid, lane, wave;
   int buf;
   bool first_chunk;
+  bool full_chunk;      // every element of the chunk is < T (no per-lane bounds checks)
+#ifdef FRUITS_HIP_TIMING_BUILD
+  unsigned long long seg[8];   // s_memtime sums per code segment (diagnostic build only)
+  unsigned long long last;
+#endif
 };
+
+#ifdef FRUITS_HIP_TIMING_BUILD
+__device__ __forceinline__ unsigned long long stamp_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define STAMP(cx, i)                                  \
+  do {                                                \
+    if ((cx).a->debug & 16) {                         \
+      const unsigned long long t_ = stamp_now();      \
+      (cx).seg[i] += t_ - (cx).last;                  \
+      (cx).last = t_;                                 \
+    }                                                 \
+  } while (0)
+#else
+#define STAMP(cx, i) do { } while (0)
+#endif
+
+// reads the lane's EP elements of staged row `row`
+template <class C>
+__device__ __forceinline__ void read_row(const WalkCtx &cx, int row, double (&v)[C::EP]) {
+  constexpr int E = C::E, P = C::P;
+  const double *base = cx.rows + row * C::CHUNK + cx.wave * C::SPAN;
+#pragma unroll
+  for (int h = 0; h < P; ++h) {
+    if constexpr (E == 2) {
+      const vd2 q = *reinterpret_cast<const vd2 *>(base + h * C::PIECE + cx.lane * 2);
+      v[h * 2] = q.x;
+      v[h * 2 + 1] = q.y;
+    } else {
+      const vd2 q0 = *reinterpret_cast<const vd2 *>(base + h * C::PIECE + cx.lane * 2);
+      const vd2 q1 = *reinterpret_cast<const vd2 *>(base + h * C::PIECE + 128 + cx.lane * 2);
+      v[h * 4] = q0.x;
+      v[h * 4 + 1] = q0.y;
+      v[h * 4 + 2] = q1.x;
+      v[h * 4 + 3] = q1.y;
+    }
+  }
+}
 
 template <class C>
 __device__ __forceinline__ void block_scan(WalkCtx &cx, const double (&s)[C::EP],
                                            double (&c)[C::EP], double (&x)[C::EP],
                                            int carry_slot) {
-  constexpr int E = C::E, P = C::P, NW = kWalkThreads / 64;
+  constexpr int E = C::E, P = C::P, NW = C::NW;
   double l[C::EP];
-  double incl[P], excl[P];
+  double incl[P], excl[P], ptot[P];
 #pragma unroll
   for (int h = 0; h < P; ++h) {
     l[h * E] = s[h * E];
@@ -103,36 +202,39 @@ __device__ __forceinline__ void block_scan(WalkCtx &cx, const double (&s)[C::EP]
     for (int e = 1; e < E; ++e) l[h * E + e] = l[h * E + e - 1] + s[h * E + e];
   }
 #pragma unroll
-  for (int h = 0; h < P; ++h) incl[h] = wave_inclusive_scan(l[h * E + E - 1]);
+  for (int h = 0; h < P; ++h) incl[h] = l[h * E + E - 1];
+  wave_inclusive_scan_multi<P>(incl);
 #pragma unroll
-  for (int h = 0; h < P; ++h) excl[h] = wave_shift_right1(incl[h]);
-  double *tot = cx.tot + cx.buf * (P * NW);
-  if (cx.lane == 63) {
-#pragma unroll
-    for (int h = 0; h < P; ++h) tot[h * NW + cx.wave] = incl[h];
+  for (int h = 0; h < P; ++h) {
+    excl[h] = wave_shift_right1(incl[h]);
+    ptot[h] = wave_last_lane(incl[h]);
   }
-  double run = 0.0;
+  double wave_total = ptot[0];
+#pragma unroll
+  for (int h = 1; h < P; ++h) wave_total += ptot[h];
+  STAMP(cx, 2);  // local sums + wave scans
+  double *tot = cx.tot + cx.buf * NW;
+  if (cx.lane == 0) tot[cx.wave] = wave_total;
+  double carry_in = 0.0;
   if constexpr (C::MULTI) {
-    if (!cx.first_chunk) run = cx.carry[carry_slot];
+    if (!cx.first_chunk) carry_in = cx.carry[carry_slot];
   }
   lds_barrier();
-  double base[P] = {};
-#pragma unroll
-  for (int h = 0; h < P; ++h) {
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      if (w == cx.wave) base[h] = run;
-      run += tot[h * NW + w];
-    }
-  }
+  STAMP(cx, 3);  // LDS write + barrier
+  // exclusive prefix of the wave totals (NW = 4)
+  static_assert(NW == 4, "cross-wave prefix is written for 4 waves");
+  const double t0 = tot[0], t1 = tot[1], t2 = tot[2], t3 = tot[3];
+  const double p2 = t0 + t1, p3 = p2 + t2;
+  double base = cx.wave == 0 ? 0.0 : (cx.wave == 1 ? t0 : (cx.wave == 2 ? p2 : p3));
   cx.buf ^= 1;
-  // every wave stores the same value; a wave only ever re-reads its own store
   if constexpr (C::MULTI) {
-    if (cx.lane == 0) cx.carry[carry_slot] = run;
+    base += carry_in;
+    // every wave stores the same value; a wave only ever re-reads its own store
+    if (cx.lane == 0) cx.carry[carry_slot] = carry_in + (p3 + t3);
   }
 #pragma unroll
   for (int h = 0; h < P; ++h) {
-    const double off = base[h] + excl[h];
+    const double off = base + excl[h];
     x[h * E] = off;
     c[h * E] = off + l[h * E];
 #pragma unroll
@@ -140,7 +242,9 @@ __device__ __forceinline__ void block_scan(WalkCtx &cx, const double (&s)[C::EP]
       x[h * E + e] = c[h * E + e - 1];
       c[h * E + e] = off + l[h * E + e];
     }
+    base += ptot[h];
   }
+  STAMP(cx, 4);  // cross-wave prefix + final adds
 }
 
 template <class C>
@@ -150,115 +254,176 @@ __device__ __forceinline__ void emit_store(const WalkCtx &cx, const double (&v)[
   const int64_t T = cx.a->T;
 #pragma unroll
   for (int h = 0; h < P; ++h) {
-    const int idx = h * C::PIECE + cx.tid * E;
-    const int64_t t = cx.t0 + idx;
-    if (cx.a->vec_ok) {
-      static_assert(E % 2 == 0, "pieces are stored as double2");
+    const int idx = cx.wave * C::SPAN + h * C::PIECE + cx.lane * E;
+#ifdef FRUITS_HIP_TIMING_BUILD
+    // timing experiments only: keep the arithmetic alive, drop the stores
+    if ((cx.a->debug & 1) && v[h * E] != 1.2345678e300) continue;
+#endif
+    if constexpr (C::VEC) {
 #pragma unroll
-      for (int e = 0; e < E; e += 2)
-        if (t + e < T) {
-          vd2 val = {v[h * E + e], v[h * E + e + 1]};
-          if (cx.a->nt_store)
-            __builtin_nontemporal_store(val, reinterpret_cast<vd2 *>(dst + idx + e));
-          else
-            *reinterpret_cast<vd2 *>(dst + idx + e) = val;
-        }
+      for (int e = 0; e < E; e += 2) {
+        const vd2 val = {v[h * E + e], v[h * E + e + 1]};
+        if (cx.full_chunk || cx.t0 + idx + e < T)
+          *reinterpret_cast<vd2 *>(dst + idx + e) = val;
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < E; ++e)
-        if (t + e < T) dst[idx + e] = v[h * E + e];
+        if (cx.full_chunk || cx.t0 + idx + e < T) dst[idx + e] = v[h * E + e];
+    }
+  }
+}
+
+// a NodeRec in registers (all wave-uniform, i.e. SGPRs)
+struct Rec {
+  int32_t w[16];
+  __device__ __forceinline__ int level() const { return w[0] & 0xff; }
+  __device__ __forceinline__ int flags() const { return w[0] >> 8; }
+  __device__ __forceinline__ int fac_count() const { return w[1]; }
+  __device__ __forceinline__ int emit_count() const { return w[6]; }
+  __device__ __forceinline__ int node_id() const { return w[9]; }
+  __device__ __forceinline__ int emit_mul() const { return w[10]; }
+  __device__ __forceinline__ int z_mul() const { return w[11]; }
+  __device__ __forceinline__ int fac_begin() const { return w[12]; }
+  __device__ __forceinline__ int emit_begin() const { return w[13]; }
+};
+
+__device__ __forceinline__ Rec load_rec(const NodeRec *recs, int pc) {
+  // uniform, 64-byte aligned address in the constant address space -> one
+  // s_load_dwordx16; issued one node ahead of its use (see walk)
+  cptr<int32_t> q = as_const(reinterpret_cast<const int32_t *>(
+      __builtin_assume_aligned(recs + pc, 64)));
+  Rec r;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r.w[i] = q[i];
+  return r;
+}
+
+template <class C>
+__device__ __forceinline__ void mul_row(const WalkCtx &cx, int row, double (&s)[C::EP]) {
+  double v[C::EP];
+  read_row<C>(cx, row, v);
+#pragma unroll
+  for (int i = 0; i < C::EP; ++i) s[i] = s[i] * v[i];
+}
+
+// Letters with a reciprocal factor or more than kRecInlineFactors factors: walk
+// the factor table (codes row | FAC_DIV), one factor at a time, in order.
+template <class C>
+__device__ __forceinline__ void slow_factors(const WalkCtx &cx, int fac_begin, int nf,
+                                          double (&s)[C::EP]) {
+  for (int f = 0; f < nf; ++f) {
+    const int code = as_const(cx.a->factors)[fac_begin + f];
+    double v[C::EP];
+    read_row<C>(cx, code & FAC_ROW_MASK, v);
+    if (code & FAC_DIV) {
+#pragma unroll
+      for (int i = 0; i < C::EP; ++i) s[i] = s[i] / v[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::EP; ++i) s[i] = s[i] * v[i];
     }
   }
 }
 
 template <class C>
-__device__ __forceinline__ void process_node(WalkCtx &cx, const NodeDesc &nd, int node_slot,
+__device__ __forceinline__ void emit_all(const WalkCtx &cx, const Rec &nd,
+                                         const double (&c)[C::EP]) {
+  const IssArgs &a = *cx.a;
+  const int ne = nd.emit_count();
+  if (ne > 0) emit_store<C>(cx, c, cx.out_base + (int64_t)nd.w[7] * a.out_k_stride);
+  if (ne > 1) {
+    emit_store<C>(cx, c, cx.out_base + (int64_t)nd.w[8] * a.out_k_stride);
+    for (int j = kRecInlineEmits; j < ne; ++j) {
+      const int64_t k = as_const(a.emit_rows)[nd.emit_begin() + j];
+      emit_store<C>(cx, c, cx.out_base + k * a.out_k_stride);
+    }
+  }
+}
+
+template <class C>
+__device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd,
                                              const double (&pin)[C::EP],
                                              double (&pout)[C::EP]) {
-  constexpr int E = C::E, P = C::P, EP = C::EP;
-  const IssArgs &a = *cx.a;
+  constexpr int EP = C::EP;
   double s[EP];
 #pragma unroll
   for (int i = 0; i < EP; ++i) s[i] = pin[i];
-  for (int f = 0; f < nd.fac_count; ++f) {
-    const int fe = as_const(a.factors)[nd.fac_begin + f];
-    const double *row = cx.rows + (fe & FAC_ROW_MASK) * C::CHUNK + cx.tid * E;
-    if (fe & FAC_DIV) {
-#pragma unroll
-      for (int h = 0; h < P; ++h)
-#pragma unroll
-        for (int e = 0; e < E; ++e) s[h * E + e] = s[h * E + e] / row[h * C::PIECE + e];
-    } else {
-#pragma unroll
-      for (int h = 0; h < P; ++h)
-#pragma unroll
-        for (int e = 0; e < E; ++e) s[h * E + e] = s[h * E + e] * row[h * C::PIECE + e];
+  const int nf = nd.fac_count();
+  if (nd.flags() & F_SLOW) {
+    slow_factors<C>(cx, nd.fac_begin(), nf, s);
+  } else {
+    // multiply-only letter, factors in the reference's order (ascending dimension)
+    if (nf > 0) mul_row<C>(cx, nd.w[2], s);
+    if (nf > 1) {
+      mul_row<C>(cx, nd.w[3], s);
+      if (nf > 2) mul_row<C>(cx, nd.w[4], s);
+      if (nf > 3) mul_row<C>(cx, nd.w[5], s);
     }
   }
-  const bool has_children = (nd.flags & F_CHILDREN) != 0;
-  const bool need2 = has_children && nd.z_mul >= 0;
-  const bool need1 = nd.emit_count > 0 || (has_children && !need2);
+  STAMP(cx, 1);  // factors
+  const bool has_children = (nd.flags() & F_CHILDREN) != 0;
+  const int z_mul = nd.z_mul(), emit_mul = nd.emit_mul();
+  const bool need2 = C::WEIGHTED && has_children && z_mul >= 0;
+  const bool need1 = nd.emit_count() > 0 || (has_children && !need2);
+#ifdef FRUITS_HIP_TIMING_BUILD
+  if (cx.a->debug & 2) {  // timing experiments only: stores without the scan
+    emit_all<C>(cx, nd, s);
+#pragma unroll
+    for (int i = 0; i < EP; ++i) pout[i] = s[i];
+    return;
+  }
+#endif
   if (need1) {
     double c[EP], x[EP];
-    block_scan<C>(cx, s, c, x, 2 * node_slot);
-    if (nd.emit_count > 0) {
-      if (nd.emit_mul >= 0) {
-        const double *row = cx.rows + nd.emit_mul * C::CHUNK + cx.tid * E;
-#pragma unroll
-        for (int h = 0; h < P; ++h)
-#pragma unroll
-          for (int e = 0; e < E; ++e) c[h * E + e] = c[h * E + e] * row[h * C::PIECE + e];
-      }
-      for (int j = 0; j < nd.emit_count; ++j) {
-        const int64_t k = as_const(a.emit_rows)[nd.emit_begin + j];
-        emit_store<C>(cx, c, cx.out_base + k * a.out_k_stride);
-      }
+    block_scan<C>(cx, s, c, x, 2 * nd.node_id());
+    if (nd.emit_count() > 0) {
+      if (C::WEIGHTED && emit_mul >= 0) mul_row<C>(cx, emit_mul, c);
+      emit_all<C>(cx, nd, c);
+      STAMP(cx, 5);  // stores
     }
     if (has_children && !need2) {
 #pragma unroll
       for (int i = 0; i < EP; ++i) pout[i] = x[i];
     }
   }
-  if (need2) {
-    const double *row = cx.rows + nd.z_mul * C::CHUNK + cx.tid * E;
-    double s2[EP], c[EP], x[EP];
+  if constexpr (C::WEIGHTED) {
+    if (need2) {
+      double s2[EP], c[EP], x[EP];
 #pragma unroll
-    for (int h = 0; h < P; ++h)
+      for (int i = 0; i < EP; ++i) s2[i] = s[i];
+      mul_row<C>(cx, z_mul, s2);
+      block_scan<C>(cx, s2, c, x, 2 * nd.node_id() + 1);
 #pragma unroll
-      for (int e = 0; e < E; ++e) s2[h * E + e] = s[h * E + e] * row[h * C::PIECE + e];
-    block_scan<C>(cx, s2, c, x, 2 * node_slot + 1);
-#pragma unroll
-    for (int i = 0; i < EP; ++i) pout[i] = x[i];
+      for (int i = 0; i < EP; ++i) pout[i] = x[i];
+    }
   }
 }
 
-__device__ __forceinline__ NodeDesc load_node(const NodeDesc *nodes, int pc) {
-  // uniform address -> scalar loads
-  cptr<int32_t> q = as_const(reinterpret_cast<const int32_t *>(nodes + pc));
-  NodeDesc nd;
-  nd.level = q[0]; nd.flags = q[1]; nd.fac_begin = q[2]; nd.fac_count = q[3];
-  nd.emit_begin = q[4]; nd.emit_count = q[5]; nd.emit_mul = q[6]; nd.z_mul = q[7];
-  return nd;
-}
-
+// Walks the records of one group.  cx.cur always holds the record at cx.pc; the
+// record after it is requested BEFORE the current node is processed, so its
+// scalar-memory latency hides behind the node's vector work.  The sentinel at
+// the end of every group (level 0xff) terminates all loops.
 template <class C, int LV>
-__device__ __forceinline__ void walk(WalkCtx &cx, const double (&pin)[C::EP], int &pc) {
+__device__ __forceinline__ void walk(WalkCtx &cx, Rec &cur, int &pc,
+                                     const double (&pin)[C::EP]) {
   const IssArgs &a = *cx.a;
-  while (pc < cx.node_end) {
-    NodeDesc nd = load_node(a.nodes, pc);
-    if (nd.level != LV) break;
-    double pout[C::EP];
-    process_node<C>(cx, nd, as_const(a.node_ids)[pc], pin, pout);
+  while (cur.level() == LV) {
+    const Rec nd = cur;
     ++pc;
+    cur = load_rec(a.recs, pc);
+    double pout[C::EP];
+    STAMP(cx, 0);  // interpreter: record decode / prefetch issue
+    process_node<C>(cx, nd, pin, pout);
     // only children continue in place in this frame
-    while (pc < cx.node_end) {
-      NodeDesc nc = load_node(a.nodes, pc);
-      if (!(nc.flags & F_CHAIN) || nc.level != LV) break;
-      process_node<C>(cx, nc, as_const(a.node_ids)[pc], pout, pout);
+    while (cur.level() == LV && (cur.flags() & F_CHAIN)) {
+      const Rec nc = cur;
       ++pc;
+      cur = load_rec(a.recs, pc);
+      process_node<C>(cx, nc, pout, pout);
     }
     if constexpr (LV + 1 < C::MAXLV) {
-      if (pc < cx.node_end && load_node(a.nodes, pc).level == LV + 1) walk<C, LV + 1>(cx, pout, pc);
+      if (cur.level() == LV + 1) walk<C, LV + 1>(cx, cur, pc, pout);
     }
   }
 }
@@ -266,24 +431,7 @@ __device__ __forceinline__ void walk(WalkCtx &cx, const double (&pin)[C::EP], in
 template <class C>
 __global__ __launch_bounds__(kWalkThreads) void iss_walk_kernel(const IssArgs a) {
   extern __shared__ double lds[];
-  constexpr int E = C::E, P = C::P, NW = kWalkThreads / 64;
   const int tid = threadIdx.x;
-  // (series, group) of this workgroup.  Workgroups are dealt round-robin over
-  // the 8 XCDs, so b and b+8 share an L2: keep the G groups of one series on
-  // one XCD when N is a multiple of 8 (speed only).
-  int64_t n;
-  int g;
-  {
-    const int64_t b = blockIdx.x;
-    if (a.xcd_map) {
-      const int64_t q = b >> 3, r = b & 7;
-      n = (q / a.G) * 8 + r;
-      g = (int)(q % a.G);
-    } else {
-      n = b / a.G;
-      g = (int)(b % a.G);
-    }
-  }
   WalkCtx cx;
   cx.a = &a;
   cx.rows = lds;
@@ -292,49 +440,99 @@ __global__ __launch_bounds__(kWalkThreads) void iss_walk_kernel(const IssArgs a)
   cx.lane = tid & 63;
   cx.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   cx.buf = 0;
-  cx.carry = a.carry ? a.carry + n * (2 * (int64_t)a.total_nodes) : nullptr;
-  const int node_begin = as_const(a.group_begin)[g];
-  cx.node_end = as_const(a.group_begin)[g + 1];
   double *rows_w = lds;
-
-  for (int64_t chunk = 0; chunk < a.nchunks; ++chunk) {
-    const int64_t t0 = chunk * C::CHUNK;
-    cx.t0 = t0;
-    cx.first_chunk = chunk == 0;
-    cx.out_base = a.out + n * a.out_n_stride + t0;
-    if (chunk > 0) lds_barrier();
-    // stage the referenced rows of this chunk
-    for (int r = 0; r < a.R; ++r) {
-      const int src = as_const(a.row_src)[r];
-      const double *gp = src >= 0
-                             ? a.X + (n * a.D + src) * a.T
-                             : a.aux + (int64_t)(-src - 1) * a.aux_tab_stride + n * a.aux_n_stride;
+  const int64_t units = a.N * a.G;
+  bool first_unit = true;
+#ifdef FRUITS_HIP_TIMING_BUILD
+  if (a.debug & 4) return;
+  for (int i = 0; i < 8; ++i) cx.seg[i] = 0;
+  cx.last = stamp_now();
+  const unsigned long long t_begin = cx.last;
+#endif
+  // Persistent workgroups: the grid holds one resident round of workgroups and
+  // each walks units b, b + grid, ...  A unit is (series n, group g of sub-tries).
+  // Workgroups are dealt round-robin over the 8 XCDs and the grid is a multiple
+  // of 8, so with the mapping below all groups of one series meet in one XCD's
+  // L2 (speed only, never correctness).
+  for (int64_t u = blockIdx.x; u < units; u += gridDim.x) {
+    int64_t n;
+    int g;
+    if (a.xcd_map) {
+      const int64_t q = u >> 3, r = u & 7;
+      n = (q / a.G) * 8 + r;
+      g = (int)(q % a.G);
+    } else {
+      n = u / a.G;
+      g = (int)(u % a.G);
+    }
+    cx.carry = a.carry ? a.carry + n * (2 * (int64_t)a.total_nodes) : nullptr;
+    const int node_begin = as_const(a.group_begin)[g];
+    for (int64_t chunk = 0; chunk < a.nchunks; ++chunk) {
+      const int64_t t0 = chunk * C::CHUNK;
+      cx.t0 = t0;
+      cx.first_chunk = chunk == 0;
+      cx.full_chunk = t0 + C::CHUNK <= a.T;
+      cx.out_base = a.out + n * a.out_n_stride + t0;
+      if (!first_unit || chunk > 0) lds_barrier();  // all reads of the old rows are done
+      // stage the referenced rows of this chunk: coalesced 16-byte units, the
+      // loads of up to 4 rows in flight before the first LDS write
+#ifdef FRUITS_HIP_TIMING_BUILD
+      if (!(a.debug & 8))
+#endif
+      for (int r0 = 0; r0 < a.R; r0 += 4) {
+        constexpr int U = C::CHUNK / 2 / kWalkThreads;
+        vd2 v[4][U];
 #pragma unroll
-      for (int h = 0; h < P; ++h) {
-        const int idx = h * C::PIECE + tid * E;
-        const int64_t t = t0 + idx;
-        if (a.vec_ok) {
+        for (int rr = 0; rr < 4; ++rr) {
+          if (r0 + rr < a.R) {
+            const int src = as_const(a.row_src)[r0 + rr];
+            const double *gp =
+                src >= 0 ? a.X + (n * a.D + src) * a.T
+                         : a.aux + (int64_t)(-src - 1) * a.aux_tab_stride + n * a.aux_n_stride;
 #pragma unroll
-          for (int e = 0; e < E; e += 2) {
-            vd2 v = {0.0, 0.0};
-            if (t + e < a.T) v = *reinterpret_cast<const vd2 *>(gp + t + e);
-            *reinterpret_cast<vd2 *>(rows_w + r * C::CHUNK + idx + e) = v;
+            for (int k = 0; k < U; ++k) {
+              const int i = 2 * (k * kWalkThreads + tid);
+              const int64_t t = t0 + i;
+              v[rr][k] = vd2{0.0, 0.0};
+              if constexpr (C::VEC) {
+                if (cx.full_chunk || t < a.T) v[rr][k] = *reinterpret_cast<const vd2 *>(gp + t);
+              } else {
+                if (t < a.T) v[rr][k].x = gp[t];
+                if (t + 1 < a.T) v[rr][k].y = gp[t + 1];
+              }
+            }
           }
-        } else {
+        }
 #pragma unroll
-          for (int e = 0; e < E; ++e)
-            rows_w[r * C::CHUNK + idx + e] = (t + e < a.T) ? gp[t + e] : 0.0;
+        for (int rr = 0; rr < 4; ++rr) {
+          if (r0 + rr < a.R) {
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+              const int i = 2 * (k * kWalkThreads + tid);
+              *reinterpret_cast<vd2 *>(rows_w + (r0 + rr) * C::CHUNK + lds_pos<C>(i)) = v[rr][k];
+            }
+          }
         }
       }
-    }
-    __syncthreads();
-    double ones[C::EP];
+      __syncthreads();
+      STAMP(cx, 6);  // staging
+      double ones[C::EP];
 #pragma unroll
-    for (int i = 0; i < C::EP; ++i) ones[i] = 1.0;
-    int pc = node_begin;
-    walk<C, 0>(cx, ones, pc);
+      for (int i = 0; i < C::EP; ++i) ones[i] = 1.0;
+      int pc = node_begin;
+      Rec cur = load_rec(a.recs, pc);
+      walk<C, 0>(cx, cur, pc, ones);
+    }
+    first_unit = false;
   }
-  (void)NW;
+#ifdef FRUITS_HIP_TIMING_BUILD
+  if ((a.debug & 16) && a.dbg != nullptr && cx.lane == 0) {
+    unsigned long long *o = a.dbg + ((int64_t)blockIdx.x * C::NW + cx.wave) * 10;
+    for (int i = 0; i < 8; ++i) o[i] = cx.seg[i];
+    o[8] = stamp_now() - t_begin;
+    o[9] = t_begin;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- exp tables
@@ -581,26 +779,77 @@ __global__ __launch_bounds__(256) void standardize_kernel(const double *__restri
 }
 
 // ---------------------------------------------------------------- launchers
-template <int E, int P, int LV, bool MULTI>
-static hipError_t launch_walk_cfg(const IssArgs &a, int64_t blocks, hipStream_t st) {
-  using C = WalkCfg<E, P, LV, MULTI>;
-  const size_t lds = ((size_t)a.R * C::CHUNK + 2 * P * (kWalkThreads / 64)) * sizeof(double);
+static int device_cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+template <int E, int P, int LV, bool MULTI, bool VEC, bool W>
+static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
+  using C = WalkCfg<E, P, LV, MULTI, VEC, W>;
+  const size_t lds = ((size_t)a.R * C::CHUNK + 2 * C::NW) * sizeof(double);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  if (lds > 64 * 1024) {
+  static size_t lds_attr = 0;  // per instantiation
+  if (lds > 64 * 1024 && lds > lds_attr) {
     hipError_t e = hipFuncSetAttribute((const void *)iss_walk_kernel<C>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    lds_attr = lds;
   }
+  const int64_t units = a.N * a.G;
+  int64_t blocks = units;
+  if (a.persistent) {
+    // one resident round of workgroups (a multiple of 8 for the XCD mapping)
+    static size_t cached_lds = (size_t)-1;
+    static int per_cu = 0;
+    if (cached_lds != lds) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iss_walk_kernel<C>, kWalkThreads,
+                                                       lds) != hipSuccess || nb < 1)
+        nb = 1;
+      per_cu = nb;
+      cached_lds = lds;
+    }
+    int64_t resident = (int64_t)per_cu * device_cu_count();
+    resident -= resident % 8;
+    if (resident < 8) resident = 8;
+    if (blocks > resident) blocks = resident;
+  }
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(iss_walk_kernel<C>, dim3((unsigned)blocks), dim3(kWalkThreads), lds, st, a);
   return hipGetLastError();
 }
 
-template <int E, int P, bool MULTI>
-static hipError_t launch_walk_lv(const IssArgs &a, int levels, int64_t blocks, hipStream_t st) {
-  if (levels <= 2) return launch_walk_cfg<E, P, 2, MULTI>(a, blocks, st);
-  if (levels <= 4) return launch_walk_cfg<E, P, 4, MULTI>(a, blocks, st);
-  if (levels <= 8) return launch_walk_cfg<E, P, 8, MULTI>(a, blocks, st);
-  return launch_walk_cfg<E, P, kMaxLevels, MULTI>(a, blocks, st);
+template <int E, int P, int LV, bool MULTI, bool VEC>
+static hipError_t launch_walk_w(const IssArgs &a, hipStream_t st) {
+  return a.aux ? launch_walk_cfg<E, P, LV, MULTI, VEC, true>(a, st)
+               : launch_walk_cfg<E, P, LV, MULTI, VEC, false>(a, st);
+}
+
+template <int E, int P, bool MULTI, bool VEC>
+static hipError_t launch_walk_lv(const IssArgs &a, int levels, hipStream_t st) {
+  if (levels <= 2) return launch_walk_w<E, P, 2, MULTI, VEC>(a, st);
+  if (levels <= 4) return launch_walk_w<E, P, 4, MULTI, VEC>(a, st);
+  if (levels <= 8) return launch_walk_w<E, P, 8, MULTI, VEC>(a, st);
+  return launch_walk_w<E, P, kMaxLevels, MULTI, VEC>(a, st);
+}
+
+template <int E, int P>
+static hipError_t launch_walk_ep(const IssArgs &a, int levels, hipStream_t st) {
+  const bool multi = a.nchunks > 1;
+  if (multi && a.carry == nullptr) return hipErrorInvalidValue;
+  if (multi)
+    return a.vec_ok ? launch_walk_lv<E, P, true, true>(a, levels, st)
+                    : launch_walk_lv<E, P, true, false>(a, levels, st);
+  return a.vec_ok ? launch_walk_lv<E, P, false, true>(a, levels, st)
+                  : launch_walk_lv<E, P, false, false>(a, levels, st);
 }
 
 int walk_chunk_elems(int64_t T) { return T <= 512 ? 512 : 1024; }
@@ -608,13 +857,9 @@ int walk_chunk_elems(int64_t T) { return T <= 512 ? 512 : 1024; }
 hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st) {
   const int chunk = walk_chunk_elems(a.T);
   a.nchunks = (int32_t)((a.T + chunk - 1) / chunk);
-  const int64_t blocks = a.N * a.G;
-  if (blocks <= 0) return hipSuccess;
-  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-  if (chunk == 512) return launch_walk_lv<2, 1, false>(a, levels, blocks, st);
-  if (a.nchunks == 1) return launch_walk_lv<2, 2, false>(a, levels, blocks, st);
-  if (a.carry == nullptr) return hipErrorInvalidValue;
-  return launch_walk_lv<2, 2, true>(a, levels, blocks, st);
+  if (a.N * a.G <= 0) return hipSuccess;
+  if (chunk == 512) return launch_walk_ep<2, 1>(a, levels, st);
+  return launch_walk_ep<2, 2>(a, levels, st);
 }
 
 hipError_t launch_exp_tables(const double *g, int64_t count, const float *alphas, int n_alpha,

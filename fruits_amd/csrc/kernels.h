@@ -19,8 +19,7 @@ struct IssArgs {
   const double *aux;        // exp tables [2A][aux rows][T] or nullptr
   double *out;
   double *carry;            // (N, 2*total_nodes) chunk carries or nullptr (single chunk)
-  const NodeDesc *nodes;
-  const int32_t *node_ids;
+  const NodeRec *recs;       // 64-byte aligned
   const int32_t *factors;
   const int32_t *emit_rows;
   const int32_t *group_begin;
@@ -35,7 +34,9 @@ struct IssArgs {
   int32_t vec_ok;           // 16-byte accesses are aligned
   int32_t nchunks;
   int32_t xcd_map;
-  int32_t nt_store;
+  int32_t persistent;       // grid = one resident round of workgroups
+  unsigned long long *dbg;  // diagnostic stamps (timing build only)
+  int32_t debug;            // timing experiments (FRUITS_HIP_DEBUG), 0 in production
 };
 
 int walk_chunk_elems(int64_t T);

@@ -259,10 +259,29 @@ GroupedProgram &grouped(Plan &p, int G) {
     std::sort(members[g].begin(), members[g].end());
     for (int u : members[g])
       for (int i = p.unit_begin[u]; i < p.unit_begin[u + 1]; ++i) {
-        gp.nodes.push_back(p.nodes[i]);
-        gp.node_ids.push_back(i);
+        const NodeDesc &nd = p.nodes[i];
+        NodeRec r{};
+        bool slow = nd.fac_count > kRecInlineFactors;
+        for (int j = 0; j < nd.fac_count; ++j)
+          if (p.factors[nd.fac_begin + j] & FAC_DIV) slow = true;
+        r.w[0] = (nd.level & 0xff) | (((nd.flags | (slow ? F_SLOW : 0)) & 0xff) << 8);
+        r.w[1] = nd.fac_count;
+        for (int j = 0; j < kRecInlineFactors && j < nd.fac_count; ++j)
+          r.w[2 + j] = p.factors[nd.fac_begin + j] & FAC_ROW_MASK;
+        r.w[6] = nd.emit_count;
+        for (int j = 0; j < kRecInlineEmits && j < nd.emit_count; ++j)
+          r.w[7 + j] = p.emit_rows[nd.emit_begin + j];
+        r.w[9] = i;
+        r.w[10] = nd.emit_mul;
+        r.w[11] = nd.z_mul;
+        r.w[12] = nd.fac_begin;
+        r.w[13] = nd.emit_begin;
+        gp.recs.push_back(r);
       }
-    gp.group_begin.push_back((int32_t)gp.nodes.size());
+    NodeRec end{};
+    end.w[0] = kRecSentinelLevel;
+    gp.recs.push_back(end);
+    gp.group_begin.push_back((int32_t)gp.recs.size());
   }
   return p.programs.emplace(G, std::move(gp)).first->second;
 }

@@ -17,9 +17,9 @@ namespace fr {
 // node flags
 constexpr int32_t F_CHAIN = 1;     // only child: processed in place in its parent's frame
 constexpr int32_t F_CHILDREN = 2;  // the exclusive prefix of this node is consumed by children
-// factor word: LDS row in the low 16 bits, bit 30 = divide instead of multiply
-constexpr int32_t FAC_DIV = 1 << 30;
-constexpr int32_t FAC_ROW_MASK = 0xffff;
+// factor code: LDS row in the low 7 bits, bit 7 = divide instead of multiply
+constexpr int32_t FAC_DIV = 0x80;
+constexpr int32_t FAC_ROW_MASK = 0x7f;
 
 constexpr int kMaxLevels = 12;  // deepest register-frame stack a kernel variant supports
 
@@ -34,15 +34,31 @@ struct NodeDesc {  // 32 bytes, read by the kernel with scalar loads
   int32_t z_mul;       // LDS row multiplied into the summand of the child scan (non-total) or -1
 };
 
+// Device form of a node: one 64-byte record = one s_load_dwordx16, every field a
+// whole dword so the walk needs no bit unpacking.  The records of a group are
+// contiguous in DFS order and end with a sentinel (level 0xff), so the walk
+// prefetches record pc+1 while it works on record pc and needs no bounds checks.
+constexpr int kRecInlineFactors = 4;   // multiply-only factors held in the record
+constexpr int kRecInlineEmits = 2;
+constexpr int kRecSentinelLevel = 0xff;
+constexpr int32_t F_SLOW = 4;          // a division or more than kRecInlineFactors factors:
+                                       // the factor table is walked instead
+struct NodeRec {
+  int32_t w[16];
+  // w[0]  level | flags << 8          w[1]  fac_count
+  // w[2..5]  inline factor rows       w[6]  emit_count
+  // w[7..8]  inline emit rows         w[9]  node id (carry slot)
+  // w[10] emit_mul row or -1          w[11] z_mul row or -1
+  // w[12] fac_begin (factor table: row | FAC_DIV)   w[13] emit_begin (emit-row table)
+};
+
 struct GroupedProgram {       // node order for one choice of G (groups per series)
   int groups = 0;
-  std::vector<NodeDesc> nodes;        // concatenation of the groups' units
-  std::vector<int32_t> node_ids;      // global node id of nodes[i] (carry slot)
-  std::vector<int32_t> group_begin;   // G+1 offsets into nodes
+  std::vector<NodeRec> recs;          // per group: its units' nodes, then a sentinel
+  std::vector<int32_t> group_begin;   // G+1 offsets into recs
   // device copies
   void *d_blob = nullptr;
-  const NodeDesc *d_nodes = nullptr;
-  const int32_t *d_node_ids = nullptr;
+  const NodeRec *d_recs = nullptr;
   const int32_t *d_group_begin = nullptr;
   const int32_t *d_factors = nullptr;
   const int32_t *d_emit_rows = nullptr;

@@ -1,0 +1,32 @@
+"""Diagnostic (timing build): per-segment s_memtime shares of the walk kernel."""
+import os, sys
+import numpy as np
+sys.path.insert(0, '.')
+os.environ["FRUITS_HIP_DEBUG"] = str(16 | int(os.environ.get("DBG_EXTRA", "0")))
+os.environ["FRUITS_HIP_DBG_BYTES"] = str(1 << 22)
+import torch
+import fruits_amd as fr
+from fruits_amd import _native as nat
+N, D, T = [int(v) for v in os.environ.get("TUNE_SHAPE", "2048,3,1024").split(",")]
+words = fr.words.of_weight(2, dim=D)
+iss = fr.ISS(words, mode=fr.ISSMode.EXTENDED)
+plan = iss._plan(0, len(words))
+X = np.random.default_rng(0).standard_normal((N, D, T))
+Xd = nat.to_device(X)
+out = torch.empty((plan.rows, N, T), dtype=torch.float64, device=Xd.device)
+work = torch.zeros((1 << 22) + 4096, dtype=torch.uint8, device=Xd.device)
+for _ in range(3):
+    plan.run(Xd, None, out=out, work=work)
+torch.cuda.synchronize()
+work.zero_()
+plan.run(Xd, None, out=out, work=work); torch.cuda.synchronize()
+raw = work[:].cpu().numpy().view(np.uint64)
+nwaves = min(N, 1536) * 4 if os.environ.get("FRUITS_HIP_PERSIST", "1") != "0" else N * 4
+st = raw[: nwaves * 10].reshape(nwaves, 10).astype(np.float64)
+names = ["interp", "factors", "scan-local", "lds+barrier", "prefix+final", "stores", "staging", "-"]
+tot = st[:, 8]
+print(f"waves {nwaves}  lifetime cycles: median {np.median(tot):.0f}  min {tot.min():.0f}  max {tot.max():.0f}")
+for i, nm in enumerate(names[:7]):
+    print(f"  {nm:14s} median {np.median(st[:, i]):9.0f}  share {np.median(st[:, i]) / np.median(tot) * 100:5.1f}%")
+t0 = raw[: nwaves * 10].reshape(nwaves, 10)[:, 9].astype(np.int64)
+print("start spread (cycles):", int(t0.max() - t0.min()))
