@@ -36,17 +36,22 @@ def cpu_baseline(words, seconds_budget: float = 15.0):
     """The C oracle (oracle/iss_oracle.c, the reference algorithm restated) on
     the host cores, on a bounded sample of the same workload."""
     from oracle import c_oracle as corc
-    threads = corc.num_threads()
+    # the GPU box gives one GPU a 16-core share; never oversubscribe it
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16, corc.num_threads()))
     rng = np.random.default_rng(0)
     n_sample = 256
     X = rng.standard_normal((n_sample, N_DIMS, N_STEPS_T))
     strs = [str(w) for w in words]
-    corc.iss_transform(X[:8], strs, "EXTENDED")  # warm up / build
+    corc.iss_transform(X[:8], strs, "EXTENDED", nthreads=threads)  # warm up / build
     reps, t_total, K = 0, 0.0, 18
     out = None
     while t_total < seconds_budget and reps < 50:
         t0 = time.perf_counter()
-        out = corc.iss_transform(X, strs, "EXTENDED", out=out)
+        out = corc.iss_transform(X, strs, "EXTENDED", out=out, nthreads=threads)
         t_total += time.perf_counter() - t0
         reps += 1
     K = out.shape[0]

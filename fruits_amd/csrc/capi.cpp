@@ -252,7 +252,15 @@ int fr_iss_run(fr_plan_t *plan, const double *d_X, int64_t N, int64_t D, int64_t
   if (wl.total() > 0 && (!d_work || (size_t)work_bytes < wl.total()))
     return fail(FR_E_NOMEM, "fr_iss_run: workspace too small (need " +
                                 std::to_string(wl.total()) + " bytes)");
-  const int G = choose_groups(p, N, groups);
+  const bool vec_ok_pre = (T % 2 == 0) && aligned16(d_X) && aligned16(d_out) &&
+                          (out_k_stride % 2 == 0) && (out_n_stride % 2 == 0);
+  // one wave per row when the plan splits into 4 balanced groups (see WalkCfg::TEAM)
+  const int team_env = env_int("FRUITS_HIP_TEAM", 0);
+  // (opt-in: measured 71 us vs 67 us for the cooperative kernel on config 2; it has
+  // a third of the scalar instructions but only 2 waves/SIMD)
+  const bool wave_rows = team_env == 1 && groups <= 0 && p.units() >= 4 &&
+                         fr::wave_rows_supported(T, p.levels, vec_ok_pre);
+  const int G = wave_rows ? 4 : choose_groups(p, N, groups);
   fr::GroupedProgram &gp = fr::grouped(p, G);
   int rc = ensure_device_program(p, gp);
   if (rc != FR_OK) return rc;
@@ -296,6 +304,7 @@ int fr_iss_run(fr_plan_t *plan, const double *d_X, int64_t N, int64_t D, int64_t
       a.dbg = reinterpret_cast<unsigned long long *>(work + align_up(wl.total(), 256));
   }
   a.persistent = env_int("FRUITS_HIP_PERSIST", 1);
+  a.wave_rows = wave_rows ? 1 : 0;
   hipError_t e = fr::launch_iss_walk(a, p.levels, st);
   if (e != hipSuccess) return hip_fail(e, "iss_walk launch");
   return FR_OK;

@@ -100,8 +100,15 @@ __device__ __forceinline__ void lds_barrier() {
 // the span is P pieces of 64*E elements; lane l holds E consecutive elements of
 // every piece.  So every 16-byte global access of a wave is lane-contiguous
 // (E = 2: 1 KiB per instruction) and only NW wave totals cross waves.
-template <int E_, int P_, int MAXLV_, bool MULTI_, bool VEC_, bool WEIGHTED_>
+template <int E_, int P_, int MAXLV_, bool MULTI_, bool VEC_, bool WEIGHTED_, int TEAM_ = 4>
 struct WalkCfg {
+  // TEAM waves scan one row together.  TEAM = 4: the whole workgroup works on one
+  // (series, group) unit and waves exchange totals through LDS once per node.
+  // TEAM = 1: every wave scans whole rows alone (no barrier, no LDS exchange) and
+  // the 4 waves of a workgroup walk 4 different groups of the SAME series, so they
+  // still share the staged rows.
+  static constexpr int TEAM = TEAM_;
+  static constexpr int TEAMS = (kWalkThreads / 64) / TEAM_;
   static constexpr bool WEIGHTED = WEIGHTED_;  // exp tables in play (emit_mul / z_mul)
   static constexpr bool VEC = VEC_;      // 16-byte global accesses are aligned
   static constexpr int E = E_;          // contiguous elements per lane per piece
@@ -109,7 +116,7 @@ struct WalkCfg {
   static constexpr int EP = E_ * P_;
   static constexpr int MAXLV = MAXLV_;
   static constexpr bool MULTI = MULTI_;  // more than one time chunk (carries in memory)
-  static constexpr int NW = kWalkThreads / 64;
+  static constexpr int NW = TEAM_;
   static constexpr int PIECE = 64 * E_;          // elements per wave piece
   static constexpr int SPAN = PIECE * P_;        // elements per wave
   static constexpr int CHUNK = SPAN * NW;        // elements per time chunk
@@ -136,7 +143,7 @@ struct WalkCtx {
   double *out_base;     // out + n*out_n_stride + t0
   double *carry;        // carry slots of this series (multi-chunk) or nullptr
   int64_t t0;           // first time index of the chunk
-  int tid, lane, wave;
+  int tid, lane, wave, team;   // wave = index inside the team
   int buf;
   bool first_chunk;
   bool full_chunk;      // every element of the chunk is < T (no per-lane bounds checks)
@@ -209,28 +216,40 @@ __device__ __forceinline__ void block_scan(WalkCtx &cx, const double (&s)[C::EP]
     excl[h] = wave_shift_right1(incl[h]);
     ptot[h] = wave_last_lane(incl[h]);
   }
-  double wave_total = ptot[0];
-#pragma unroll
-  for (int h = 1; h < P; ++h) wave_total += ptot[h];
-  STAMP(cx, 2);  // local sums + wave scans
-  double *tot = cx.tot + cx.buf * NW;
-  if (cx.lane == 0) tot[cx.wave] = wave_total;
   double carry_in = 0.0;
   if constexpr (C::MULTI) {
     if (!cx.first_chunk) carry_in = cx.carry[carry_slot];
   }
-  lds_barrier();
-  STAMP(cx, 3);  // LDS write + barrier
-  // exclusive prefix of the wave totals (NW = 4)
-  static_assert(NW == 4, "cross-wave prefix is written for 4 waves");
-  const double t0 = tot[0], t1 = tot[1], t2 = tot[2], t3 = tot[3];
-  const double p2 = t0 + t1, p3 = p2 + t2;
-  double base = cx.wave == 0 ? 0.0 : (cx.wave == 1 ? t0 : (cx.wave == 2 ? p2 : p3));
-  cx.buf ^= 1;
-  if constexpr (C::MULTI) {
-    base += carry_in;
-    // every wave stores the same value; a wave only ever re-reads its own store
-    if (cx.lane == 0) cx.carry[carry_slot] = carry_in + (p3 + t3);
+  double base = 0.0;
+  if constexpr (NW == 1) {
+    STAMP(cx, 2);  // local sums + wave scans
+    if constexpr (C::MULTI) {
+      double total = ptot[0];
+#pragma unroll
+      for (int h = 1; h < P; ++h) total += ptot[h];
+      base = carry_in;
+      if (cx.lane == 0) cx.carry[carry_slot] = carry_in + total;
+    }
+  } else {
+    double wave_total = ptot[0];
+#pragma unroll
+    for (int h = 1; h < P; ++h) wave_total += ptot[h];
+    STAMP(cx, 2);  // local sums + wave scans
+    double *tot = cx.tot + cx.buf * NW;
+    if (cx.lane == 0) tot[cx.wave] = wave_total;
+    lds_barrier();
+    STAMP(cx, 3);  // LDS write + barrier
+    // exclusive prefix of the wave totals
+    static_assert(NW == 1 || NW == 4, "cross-wave prefix is written for 4 waves");
+    const double t0 = tot[0], t1 = tot[1], t2 = tot[2], t3 = tot[3];
+    const double p2 = t0 + t1, p3 = p2 + t2;
+    base = cx.wave == 0 ? 0.0 : (cx.wave == 1 ? t0 : (cx.wave == 2 ? p2 : p3));
+    cx.buf ^= 1;
+    if constexpr (C::MULTI) {
+      base += carry_in;
+      // every wave stores the same value; a wave only ever re-reads its own store
+      if (cx.lane == 0) cx.carry[carry_slot] = carry_in + (p3 + t3);
+    }
   }
 #pragma unroll
   for (int h = 0; h < P; ++h) {
@@ -438,10 +457,15 @@ __global__ __launch_bounds__(kWalkThreads) void iss_walk_kernel(const IssArgs a)
   cx.tot = lds + (int64_t)a.R * C::CHUNK;
   cx.tid = tid;
   cx.lane = tid & 63;
-  cx.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    cx.wave = w % C::TEAM;
+    cx.team = w / C::TEAM;
+  }
   cx.buf = 0;
   double *rows_w = lds;
-  const int64_t units = a.N * a.G;
+  // TEAM = 1: a unit is a series, its G = TEAMS groups go to the 4 waves
+  const int64_t units = C::TEAM == 1 ? a.N : a.N * a.G;
   bool first_unit = true;
 #ifdef FRUITS_HIP_TIMING_BUILD
   if (a.debug & 4) return;
@@ -457,7 +481,10 @@ __global__ __launch_bounds__(kWalkThreads) void iss_walk_kernel(const IssArgs a)
   for (int64_t u = blockIdx.x; u < units; u += gridDim.x) {
     int64_t n;
     int g;
-    if (a.xcd_map) {
+    if constexpr (C::TEAM == 1) {
+      n = u;
+      g = cx.team;
+    } else if (a.xcd_map) {
       const int64_t q = u >> 3, r = u & 7;
       n = (q / a.G) * 8 + r;
       g = (int)(q % a.G);
@@ -527,7 +554,7 @@ __global__ __launch_bounds__(kWalkThreads) void iss_walk_kernel(const IssArgs a)
   }
 #ifdef FRUITS_HIP_TIMING_BUILD
   if ((a.debug & 16) && a.dbg != nullptr && cx.lane == 0) {
-    unsigned long long *o = a.dbg + ((int64_t)blockIdx.x * C::NW + cx.wave) * 10;
+    unsigned long long *o = a.dbg + ((int64_t)blockIdx.x * 4 + cx.team * C::TEAM + cx.wave) * 10;
     for (int i = 0; i < 8; ++i) o[i] = cx.seg[i];
     o[8] = stamp_now() - t_begin;
     o[9] = t_begin;
@@ -791,9 +818,9 @@ static int device_cu_count() {
   return cus;
 }
 
-template <int E, int P, int LV, bool MULTI, bool VEC, bool W>
+template <int E, int P, int LV, bool MULTI, bool VEC, bool W, int TEAM = 4>
 static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
-  using C = WalkCfg<E, P, LV, MULTI, VEC, W>;
+  using C = WalkCfg<E, P, LV, MULTI, VEC, W, TEAM>;
   const size_t lds = ((size_t)a.R * C::CHUNK + 2 * C::NW) * sizeof(double);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static size_t lds_attr = 0;  // per instantiation
@@ -803,7 +830,7 @@ static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
     if (e != hipSuccess) return e;
     lds_attr = lds;
   }
-  const int64_t units = a.N * a.G;
+  const int64_t units = TEAM == 1 ? a.N : a.N * a.G;
   int64_t blocks = units;
   if (a.persistent) {
     // one resident round of workgroups (a multiple of 8 for the XCD mapping)
@@ -854,10 +881,29 @@ static hipError_t launch_walk_ep(const IssArgs &a, int levels, hipStream_t st) {
 
 int walk_chunk_elems(int64_t T) { return T <= 512 ? 512 : 1024; }
 
+// wave-per-row variant (TEAM = 1): single chunk, aligned 16-byte accesses,
+// shallow tries (register frames of 2 * E * P VGPRs per level)
+bool wave_rows_supported(int64_t T, int levels, bool vec_ok) {
+  return vec_ok && T <= 1024 && levels <= 4;
+}
+
+template <int P>
+static hipError_t launch_wave_rows(const IssArgs &a, int levels, hipStream_t st) {
+  if (levels <= 2)
+    return a.aux ? launch_walk_cfg<2, P, 2, false, true, true, 1>(a, st)
+                 : launch_walk_cfg<2, P, 2, false, true, false, 1>(a, st);
+  return a.aux ? launch_walk_cfg<2, P, 4, false, true, true, 1>(a, st)
+               : launch_walk_cfg<2, P, 4, false, true, false, 1>(a, st);
+}
+
 hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st) {
   const int chunk = walk_chunk_elems(a.T);
   a.nchunks = (int32_t)((a.T + chunk - 1) / chunk);
   if (a.N * a.G <= 0) return hipSuccess;
+  if (a.wave_rows) {
+    if (a.G != 4 || !wave_rows_supported(a.T, levels, a.vec_ok != 0)) return hipErrorInvalidValue;
+    return chunk == 512 ? launch_wave_rows<4>(a, levels, st) : launch_wave_rows<8>(a, levels, st);
+  }
   if (chunk == 512) return launch_walk_ep<2, 1>(a, levels, st);
   return launch_walk_ep<2, 2>(a, levels, st);
 }

@@ -35,11 +35,13 @@ struct IssArgs {
   int32_t nchunks;
   int32_t xcd_map;
   int32_t persistent;       // grid = one resident round of workgroups
+  int32_t wave_rows;        // TEAM = 1 kernel: one wave per row, 4 groups per workgroup
   unsigned long long *dbg;  // diagnostic stamps (timing build only)
   int32_t debug;            // timing experiments (FRUITS_HIP_DEBUG), 0 in production
 };
 
 int walk_chunk_elems(int64_t T);
+bool wave_rows_supported(int64_t T, int levels, bool vec_ok);
 hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st);
 hipError_t launch_exp_tables(const double *g, int64_t count, const float *alphas, int n_alpha,
                              double *aux, hipStream_t st);
