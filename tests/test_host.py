@@ -1,0 +1,302 @@
+"""CPU-only tests: host logic of fruits_amd (no compute) and the C ABI surface."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+import fruits_amd as fr
+from fruits_amd import _native as nat
+from oracle import ref_numpy as orc
+
+G = load_golden()
+M = G.manifest
+
+
+# ---------------------------------------------------------------- C ABI surface
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "fruits_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = nat.lib()
+    names = declared_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), f"libfruits_hip.so does not export {name}"
+    assert set(nat.EXPORTS) == set(names)
+    assert lib.fr_version() >= 100
+
+
+def test_no_cpu_fallback():
+    if nat.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    X = np.zeros((2, 1, 8))
+    with pytest.raises(nat.NativeError):
+        fr.ISS([fr.words.SimpleWord("[1]")]).fit_transform(X)
+    with pytest.raises(nat.NativeError):
+        fr.preparation.INC().fit_transform(X)
+    with pytest.raises(nat.NativeError):
+        fr.sieving.NPI().fit_transform(X[:, 0, :])
+    with pytest.raises(nat.NativeError):
+        fr.semiring.Reals().iterated_sum_fast(X, np.array([[1]], np.int32), None, None, 1, True)
+
+
+def test_no_oracle_import_in_product():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "fruits_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("no oracle", ""), (dirpath, f)
+
+
+# ---------------------------------------------------------------- words
+def test_simpleword_parse_golden():
+    for s, rows in M["parse"].items():
+        w = fr.words.SimpleWord(s)
+        assert [list(r) for r in w] == rows
+        assert str(w) == s and len(w) == len(rows)
+        assert w.table().shape == (len(rows), len(rows[0]))
+    pm = M["parse_multiply"]
+    w = fr.words.SimpleWord(pm["first"])
+    assert w._extended_letters == [[-1, 1], [1, -2]]     # reference test_simple.py:62
+    w.multiply(pm["second"])
+    assert w._extended_letters == pm["exps"] and str(w) == pm["name"]
+
+
+def test_simpleword_errors_and_alpha():
+    for bad in ["", "[1", "1]", "[a]", "[1][]", "[()]", "[1] [2]"]:
+        with pytest.raises(ValueError):
+            fr.words.SimpleWord(bad)
+    w = fr.words.SimpleWord("[1][2]")
+    with pytest.raises(NotImplementedError):
+        w.multiply(3)
+    np.testing.assert_array_equal(w.alpha, np.ones(2, np.float32))
+    assert w.alpha.dtype == np.float32
+    with pytest.raises(ValueError):
+        w.alpha = [1.0]
+    w.alpha = [0.5, 2]
+    np.testing.assert_array_equal(w.alpha, np.array([0.5, 2], np.float32))
+    c = w.copy()
+    assert c == w and c is not w and str(c) == "[1][2]"
+    assert fr.words.SimpleWord("[12][122]") == fr.words.SimpleWord("[21][212]")
+
+
+@pytest.mark.parametrize("key", sorted(M["words"]))
+def test_of_weight_and_cacheplan_golden(key):
+    w, d = map(int, key.split(","))
+    ent = M["words"][key]
+    words = fr.words.of_weight(w, dim=d)
+    assert [str(x) for x in words] == ent["words"]
+    assert [[list(r) for r in x] for x in words] == ent["exps"]
+    cp = fr.iss.CachePlan(words)
+    assert cp._plan == ent["plan"] and cp.n_iterated_sums() == ent["K"]
+
+
+def test_word_counts():
+    # reference tests/signature/test_simple.py:54-57
+    for n in range(1, 7):
+        assert len(fr.words.of_weight(n, dim=1)) == 2 ** (n - 1)
+    assert len(fr.words.of_weight(4, dim=2)) == 82
+
+
+def test_alternate_sign_golden():
+    a = M["alternate_sign"]
+    out = fr.words.alternate_sign([fr.words.SimpleWord(s) for s in a["in"]])
+    assert [str(w) for w in out] == a["out"]
+
+
+def test_cacheplan_goldens_and_labels():
+    for ent in M["cacheplan"]:
+        cp = fr.iss.CachePlan([fr.words.SimpleWord(s) for s in ent["words"]])
+        assert cp._plan == ent["plan"]
+        assert [cp.get_word_string(i) for i in range(cp.n_iterated_sums())] == ent["labels"]
+        with pytest.raises(IndexError):
+            cp.get_word_string(cp.n_iterated_sums())
+    assert M["cacheplan"][0]["plan"] == [4, 5, 2, 3, 3, 1, 1, 1, 2]   # test_cache.py:26
+    cp = fr.iss.CachePlan([fr.words.SimpleWord(s) for s in M["cacheplan"][0]["words"]])
+    assert cp.get_word_index(0) == 0 and cp.get_word_index(4) == 1
+    assert cp.n_iterated_sums(range(2)) == 9
+
+
+# ---------------------------------------------------------------- plan compiler (host C++)
+def plan_of(words, mode="EXTENDED", share=True, weighting=nat.FR_W_NONE, alphas=None):
+    ws = [fr.words.SimpleWord(s) for s in words]
+    depths = orc.cache_plan(words) if mode == "EXTENDED" else [1] * len(words)
+    if weighting != nat.FR_W_NONE and alphas is None:
+        alphas = [w.alpha for w in ws]
+    return nat.Plan([w.table() for w in ws], depths, alphas, weighting, share), depths
+
+
+@pytest.mark.parametrize("key", ["2,3", "4,2", "6,2", "9,1", "3,3"])
+def test_plan_is_a_trie_walk(key):
+    ent = M["words"][key]
+    plan, depths = plan_of(ent["words"])
+    K = sum(depths)
+    assert plan.rows == K
+    # of_weight sets contain every prefix they need exactly once: K scans, not sum(L)
+    assert plan.nodes == K
+    assert plan.info(nat.FR_INFO_SHARED) == 1
+    d = plan.dump()
+    assert d.shape == (K, 8)
+    # DFS preorder: a node's level is at most one deeper than its predecessor's
+    lv = d[:, 0]
+    assert lv[0] == 0 and np.all(np.diff(lv) <= 1) and lv.max() + 1 == plan.info(nat.FR_INFO_LEVELS)
+    # every output row is written by exactly one node
+    assert sorted(d[:, 4].tolist()) == list(range(K)) and np.all(d[:, 3] == 1)
+    unshared, _ = plan_of(ent["words"], share=False)
+    assert unshared.nodes == sum(len(e) for e in ent["exps"]) and unshared.rows == K
+    assert unshared.info(nat.FR_INFO_LEVELS) == 1          # chains run in place
+
+
+def test_plan_details():
+    plan, _ = plan_of(["[11]", "[1][2]", "[1][2][3]", "[2]"])
+    d = plan.dump()
+    # nodes: [11] | [1] -> [2] -> [3] (chain, in place) | [2]
+    assert plan.nodes == 5 and plan.rows == 6 - 1
+    assert d[:, 0].tolist() == [0, 0, 0, 0, 0]
+    assert (d[:, 1] & 1).tolist() == [0, 0, 1, 1, 0]        # F_CHAIN
+    assert (d[:, 1] & 2).tolist() == [0, 2, 2, 0, 0]        # F_CHILDREN
+    assert d[:, 2].tolist() == [2, 1, 1, 1, 1]              # factors
+    assert plan.max_dim == 3 and plan.dims_used == 3
+    assert plan.info(nat.FR_INFO_GROUPS) == 3
+    # duplicated words (SINGLE mode): one node, several output rows
+    dup, _ = plan_of(["[12]", "[1]", "[12]", "[21]"], mode="SINGLE")
+    dd = dup.dump()
+    assert dup.rows == 4 and dup.nodes == 2 and sorted(dd[:, 3].tolist()) == [1, 3]
+    # weighted: distinct alphas make distinct nodes and exp tables
+    ws = [fr.words.SimpleWord(s) for s in ["[1][2]", "[1][3]"]]
+    ws[1].alpha = [0.5, 1.0]
+    wp = nat.Plan([w.table() for w in ws], [2, 2], [w.alpha for w in ws], nat.FR_W_NONTOTAL)
+    assert wp.nodes == 4 and wp.info(nat.FR_INFO_ALPHAS) == 2
+    wp2 = nat.Plan([w.table() for w in ws], [2, 1], [np.ones(2, np.float32)] * 2, nat.FR_W_TOTAL)
+    assert wp2.nodes == 3 and wp2.info(nat.FR_INFO_ALPHAS) == 1 and wp2.rows == 3
+    assert plan.workspace_bytes(100, 1024, 0) == 0
+    assert plan.workspace_bytes(100, 4096, 0) >= 100 * 2 * plan.nodes * 8
+    assert wp.workspace_bytes(10, 64, 1) >= 2 * 2 * 64 * 8
+
+
+def test_plan_rejects_bad_input():
+    t = np.array([[1]], np.int32)
+    with pytest.raises(ValueError):
+        nat.Plan([t], [2])                         # depth > L
+    with pytest.raises(ValueError):
+        nat.Plan([t], [1], None, nat.FR_W_TOTAL)   # weighted without alphas
+    with pytest.raises(ValueError):
+        nat.Plan([t], [1], [np.ones(3, np.float32)], nat.FR_W_TOTAL)
+    with pytest.raises(ValueError):
+        nat.Plan([np.array([1], np.int32)], [1])   # not (L, Dw)
+    deep = nat.Plan([fr.words.SimpleWord("[1]" * 30 + "[2]").table(),
+                     fr.words.SimpleWord("[1]" * 30 + "[3]").table()], [31, 1])
+    assert deep.info(nat.FR_INFO_LEVELS) <= 12 and deep.rows == 32
+
+
+# ---------------------------------------------------------------- stages (no compute)
+def test_iss_bookkeeping():
+    words = fr.words.of_weight(2, dim=3)
+    ext = fr.ISS(words, mode=fr.ISSMode.EXTENDED)
+    assert ext.n_iterated_sums() == 18 and not ext.requires_fitting
+    assert fr.ISS(words).n_iterated_sums() == 15
+    case = [c for c in G.cases("iss") if c["name"] == "w23_ext_U"][0]
+    assert [ext.label(i) for i in range(18)] == case["labels"]
+    wl = fr.ISS(words, weighting=fr.iss.weighting.Indices())
+    assert wl.label(0) == "[11] : Indices"
+    cp = ext.copy()
+    assert cp is not ext and cp.words is ext.words and cp.mode == ext.mode
+    with pytest.raises(ValueError):
+        next(fr.ISS(words).batch_transform(np.zeros((1, 3, 4)), batch_size=16))
+    with pytest.raises(TypeError):
+        fr.ISS(words).fit_transform(np.zeros((1, 3, 4), dtype=np.float32))
+    with pytest.raises(NotImplementedError):
+        fr.ISS(words, semiring=fr.semiring.Arctic())._check_supported()
+    assert ext.word_batches(4, 8, 1) == [(i, i + 1) for i in range(15)]
+    assert ext.word_batches(4, 8) == [(0, 15)]
+
+
+def test_weighting_rows_match_oracle():
+    for kw in [{}, {"scale": 2.0}, {"relative": False, "scale": 3.0}]:
+        row = fr.iss.weighting.Indices(**kw)._row(37)
+        ref = orc.lookup_indices(1, 37, kw.get("relative", True), kw.get("scale", 50))[0]
+        np.testing.assert_array_equal(np.asarray(row, dtype=np.float64), ref)
+    with pytest.raises(ValueError):
+        fr.iss.weighting.Plateaus(1)
+    p = fr.iss.weighting.Plateaus(4, scale=1.0)._row(16)
+    assert p[0] == 0 and p[-1] == 1 and len(set(np.round(p, 12))) == 4
+
+
+def test_preparateurs_and_sieves_bookkeeping():
+    with pytest.raises(ValueError):
+        fr.preparation.INC(depth=0)
+    inc = fr.preparation.INC(2, 3, False)
+    assert str(inc) == "INC(2, 3, False)" and inc == inc.copy() and not inc.requires_fitting
+    assert inc._lag(100) == 2 and fr.preparation.INC(0.1)._lag(95) == 10
+    assert fr.preparation.INC(lambda T: T // 4)._lag(100) == 25
+    assert str(fr.preparation.NEW(fr.preparation.INC())) == "NEW(INC(1, 1, True))"
+    assert str(fr.preparation.STD()) == "STD(True, True)"
+    npi = fr.sieving.NPI(q=(0.5, 1.0), cut=[10, -1])
+    assert npi.requires_fitting and npi.nfeatures() == 2
+    assert npi.label(1) == "NPI[inc=1]!-1![0.5, 1.0]"
+    assert str(npi) == "NPI([10, -1], (0.5, 1.0), 1)"
+    assert not fr.sieving.NPI().requires_fitting and not fr.sieving.END().requires_fitting
+    assert fr.sieving.END().label(0) == "END!-1![-1.0, 1.0]"
+    np.testing.assert_array_equal(fr.sieving.NPI(cut=[-1, 3, 1])._int_cut_row(5), [0, 1, 3, 5])
+    cuts = fr.sieving.END(cut=[1, 4, -1])._get_transformed_cuts(np.zeros((2, 5)))
+    np.testing.assert_array_equal(cuts, orc.transformed_cuts(2, 5, [1, 4, -1]))
+    with pytest.raises(RuntimeError):
+        fr.sieving.NPI(q=(0.3, 1.0))._get_unfitted_quantiles()
+    s = fr.sieving.END(q=(-1.0, 0.25, 0.0, 1.0))   # SegmentSieve._fit: host np.quantile
+    s._fit(np.arange(8.0).reshape(2, 4))
+    np.testing.assert_array_equal(s._quantiles, orc.fit_quantiles((-1.0, 0.25, 0.0, 1.0),
+                                                                   np.arange(8.0)))
+
+
+def build_fruit(spec):
+    from test_hip_parity import build_fruit as bf
+    return bf(fr, spec)
+
+
+@pytest.mark.parametrize("case", G.cases("fruit"), ids=lambda c: c["name"])
+def test_fruit_structure_golden(case):
+    fruit = build_fruit(case["spec"])
+    assert fruit.nfeatures() == case["nfeatures"]
+    assert [fruit.label(i) for i in range(fruit.nfeatures())] == case["labels"]
+    assert [fruit.label(i, verbose=2) for i in range(len(case["labels_v2"]))] == case["labels_v2"]
+    assert fruit.summary() == case["summary"]
+    with pytest.raises(RuntimeError, match="Missing call of self.fit"):
+        fruit.transform(G[case["x"]])
+    dc = fruit.deepcopy()
+    assert dc.nfeatures() == fruit.nfeatures() and len(dc) == len(fruit)
+    assert dc.name.endswith("(Deepcopy)") and fruit.copy().name.endswith("(Copy)")
+
+
+def test_fruit_api_errors():
+    fruit = fr.Fruit("x")
+    with pytest.raises(TypeError):
+        fruit.add(3)
+    fruit.add(fr.preparation.INC)          # classes are instantiated
+    assert isinstance(fruit.get_slice().get_preparateurs()[0], fr.preparation.INC)
+    with pytest.raises(RuntimeError, match="No ISS given"):
+        fruit.fit(np.zeros((2, 1, 8)))
+    fruit.add(fr.ISS(fr.words.of_weight(4, dim=2)))
+    with pytest.raises(RuntimeError, match="No feature sieves given"):
+        fruit.fit(np.zeros((2, 2, 8)))
+    fruit.add(fr.sieving.NPI, fr.sieving.END)
+    assert fruit.nfeatures() == 164
+    with pytest.raises(TypeError):
+        fruit.fit(np.zeros((2, 2, 8), dtype=np.float32))
+    with pytest.raises(IndexError):
+        fruit.switch_slice(3)
+    fruit.cut()
+    assert len(fruit) == 2 and fruit[1] is fruit.get_slice()
+    assert [s for s in fruit] == [fruit[0], fruit[1]]
+    fruit[0].clear()
+    assert fruit[0].nfeatures() == 0 and fruit[0].fit_sample_size == 1
+    # reference tests/core/test_fruit.py:11-28 (counts only; PPV/MAX/MIN are out of scope)
+    f2 = fr.Fruit()
+    f2.add(fr.preparation.INC(zero_padding=False))
+    f2.add(fr.ISS(fr.words.of_weight(4, dim=2)))
+    assert len(f2.get_slice().get_iss()[0].words) == 82
