@@ -75,19 +75,25 @@ class ISS(Seed):
                     "only SimpleWord is supported by the MI355X implementation")
 
     def _plan(self, start: int, stop: int) -> nat.Plan:
+        return self._plan_indices(tuple(range(start, stop)))
+
+    def _plan_indices(self, indices) -> nat.Plan:
+        """Device program of an arbitrary subset of the words (in the given
+        order).  Output depths come from the cache plan of the FULL word list, so
+        shards of a word list (fruits_amd.parallel) emit exactly their share of
+        the rows."""
+        indices = tuple(indices)
         if self.weighting is None:
             wmode, alphas = nat.FR_W_NONE, None
         else:
             wmode = nat.FR_W_TOTAL if self.weighting.total else nat.FR_W_NONTOTAL
-            alphas = [np.asarray(self.words[i].alpha, dtype=np.float32)
-                      for i in range(start, stop)]
-        key = (start, stop, self.mode, wmode,
+            alphas = [np.asarray(self.words[i].alpha, dtype=np.float32) for i in indices]
+        key = (indices, self.mode, wmode,
                None if alphas is None else tuple(a.tobytes() for a in alphas))
         plan = self._plans.get(key)
         if plan is None:
-            plan = nat.Plan([self.words[i].table() for i in range(start, stop)],
-                            [self._depth(i) for i in range(start, stop)],
-                            alphas, wmode)
+            plan = nat.Plan([self.words[i].table() for i in indices],
+                            [self._depth(i) for i in indices], alphas, wmode)
             self._plans[key] = plan
         return plan
 
@@ -133,11 +139,12 @@ class ISS(Seed):
         return out
 
     def transform_device(self, Xd, start: int = 0, stop: Optional[int] = None,
-                         lookup_d="auto", out=None, groups: int = 0):
-        """Iterated sums of words [start, stop) as a (K, N, T) device tensor."""
+                         lookup_d="auto", out=None, groups: int = 0, indices=None):
+        """Iterated sums of words [start, stop) (or of ``indices``) as a
+        (K, N, T) device tensor."""
         self._check_supported()
         stop = len(self.words) if stop is None else stop
-        plan = self._plan(start, stop)
+        plan = self._plan(start, stop) if indices is None else self._plan_indices(indices)
         if plan.max_dim > Xd.shape[1]:
             raise IndexError(
                 f"a word references dimension {plan.max_dim} but the input has "

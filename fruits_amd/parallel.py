@@ -1,0 +1,192 @@
+"""Multi-GPU execution: one process per GPU, ``torch.distributed`` over RCCL/xGMI.
+
+The ISS path shards on two independent axes and needs no exchange inside the
+scan:
+
+* **series** (``shard_series``): every rank transforms its own rows and returns
+  its own feature rows - no collective at all.  This is what ``bench.py --gpus N``
+  measures (weak scaling).
+* **words** (``transform_sharded``): every rank holds the whole batch and owns a
+  balanced share of the word list's first-letter sub-tries, i.e. of the iterated
+  sums and therefore of the feature COLUMNS; one all-gather of the ``(N, F_r)``
+  feature blocks (padded to the widest block - RCCL has no all-gatherv) plus a
+  column permutation restores the reference's column order.  On a fully
+  connected 8-GPU xGMI node each block crosses each link once.
+
+The shard planning and the gather / permutation are plain host logic and are
+tested on CPU with the ``gloo`` backend; the compute callback is the HIP
+pipeline on GPU ranks.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+
+# ----------------------------------------------------------------------- series axis
+def shard_series(n_series: int, rank: int, world: int) -> slice:
+    """Contiguous, balanced block of series for ``rank`` (first ranks get the
+    remainder)."""
+    base, rem = divmod(n_series, world)
+    start = rank * base + min(rank, rem)
+    return slice(start, start + base + (1 if rank < rem else 0))
+
+
+# ----------------------------------------------------------------------- word axis
+def _letters(word_string: str) -> list[str]:
+    return [p + "]" for p in word_string.split("]")[:-1]]
+
+
+def shard_words(word_strings: Sequence[str], depths: Sequence[int], world: int):
+    """Assigns sub-tries of the word list to ranks.
+
+    Words that share a first letter start out together (their common prefixes
+    are then computed once, on one rank).  While the heaviest sub-trie is more
+    than its fair share it is split one letter deeper - the ranks that receive
+    the pieces recompute the short common prefix, which is cheap next to the
+    imbalance.  Sub-tries are placed heaviest-first on the lightest rank; weight
+    = scan passes + output rows.  Returns, per rank, the sorted word indices."""
+    letters = [_letters(s) for s in word_strings]
+    cost = [len(letters[i]) + depths[i] for i in range(len(word_strings))]
+    groups: dict[tuple, list[int]] = {}
+    for i, ls in enumerate(letters):
+        groups.setdefault(tuple(ls[:1]), []).append(i)
+    total = sum(cost)
+    fair = 1.25 * total / max(world, 1)
+    while True:
+        heavy = max(groups, key=lambda k: (sum(cost[i] for i in groups[k]), k), default=None)
+        if heavy is None or sum(cost[i] for i in groups[heavy]) <= fair:
+            break
+        depth = len(heavy) + 1
+        pieces: dict[tuple, list[int]] = {}
+        for i in groups[heavy]:
+            pieces.setdefault(tuple(letters[i][:depth]), []).append(i)
+        if len(pieces) <= 1:
+            break                      # a single chain cannot be split further
+        del groups[heavy]
+        for k, v in pieces.items():
+            groups.setdefault(k, []).extend(v)
+    weight = {k: sum(cost[i] for i in v) for k, v in groups.items()}
+    order = sorted(groups, key=lambda k: (-weight[k], groups[k][0]))
+    load = [0] * world
+    parts: list[list[int]] = [[] for _ in range(world)]
+    for k in order:
+        r = min(range(world), key=lambda j: (load[j], j))
+        load[r] += weight[k]
+        parts[r].extend(groups[k])
+    return [sorted(p) for p in parts]
+
+
+def row_ranges(depths: Sequence[int]):
+    """Global iterated-sum row range [begin, end) of every word (reference
+    order: words in order, shortest emitted prefix first)."""
+    out, k = [], 0
+    for d in depths:
+        out.append((k, k + d))
+        k += d
+    return out
+
+
+def column_map(parts, depths, features_per_sum: int):
+    """For every rank the global feature columns its local block maps to, in
+    local column order."""
+    rr = row_ranges(depths)
+    maps = []
+    for words in parts:
+        cols = []
+        for i in words:
+            for row in range(*rr[i]):
+                cols.extend(range(row * features_per_sum, (row + 1) * features_per_sum))
+        maps.append(np.asarray(cols, dtype=np.int64))
+    return maps
+
+
+def gather_features(local, maps, n_features: int, rank: int, world: int, group=None):
+    """All-gathers the per-rank ``(N, F_r)`` blocks and scatters their columns to
+    the reference positions.  ``local`` is a torch tensor (device tensor with the
+    nccl backend, CPU tensor with gloo)."""
+    import torch
+    import torch.distributed as dist
+
+    width = max(len(m) for m in maps)
+    n = local.shape[0]
+    padded = torch.zeros((n, width), dtype=local.dtype, device=local.device)
+    padded[:, :local.shape[1]] = local
+    if world > 1:
+        flat = torch.empty((world * n, width), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(flat, padded, group=group)
+        gathered = flat.view(world, n, width)
+    else:
+        gathered = padded.unsqueeze(0)
+    out = torch.zeros((n, n_features), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        idx = torch.as_tensor(maps[r], device=local.device)
+        if len(maps[r]):
+            out[:, idx] = gathered[r, :, :len(maps[r])]
+    return out
+
+
+# ----------------------------------------------------------------------- fruit slice
+def slice_transform_sharded(slc, X: np.ndarray, cache, rank: int, world: int, group=None,
+                            compute: Optional[Callable] = None):
+    """``FruitSlice.transform`` with the slice's word list sharded over ``world``
+    ranks.  ``compute(word_indices) -> (N, F_r)`` produces the local block; the
+    default runs the HIP pipeline.  Slices with chained ISS fall back to
+    replicated execution."""
+    if len(slc._iss) != 1:
+        return slc.transform(X, cache=cache)
+    iss = slc._iss[0]
+    strings = [str(w) for w in iss.words]
+    depths = [iss._depth(i) for i in range(len(strings))]
+    per_sum = sum(s.nfeatures() for s in slc._sieves)
+    parts = shard_words(strings, depths, world)
+    maps = column_map(parts, depths, per_sum)
+    mine = parts[rank]
+    if compute is None:
+        compute = lambda idx: _device_block(slc, iss, X, cache, idx, depths, per_sum)
+    local = compute(mine)
+    full = gather_features(local, maps, slc.nfeatures(), rank, world, group)
+    return full.cpu().numpy()
+
+
+def _device_block(slc, iss, X, cache, indices, depths, per_sum):
+    from . import _native as nat
+    t = nat.torch()
+    Xd = cache.input_device(X) if cache._input is X else nat.to_device(X)
+    Pd = slc._prepare_device(Xd, cache)
+    slc._attach(cache)
+    rr = row_ranges(depths)
+    n_rows = sum(depths[i] for i in indices)
+    feats = t.zeros((X.shape[0], n_rows * per_sum), dtype=t.float64, device=Pd.device)
+    if not indices:
+        return feats
+    block = iss.transform_device(Pd, indices=indices)
+    col = k = 0
+    for i in indices:
+        for row in range(*rr[i]):
+            sieves = slc._sieves_extended[row] if slc._sieves_extended else slc._sieves
+            for sieve in sieves:
+                sieve._cache = cache
+                sieve.transform_device(block[k], feats, col)
+                col += sieve.nfeatures()
+            k += 1
+    return feats
+
+
+def transform_sharded(fruit, X: np.ndarray, rank: Optional[int] = None,
+                      world: Optional[int] = None, group=None) -> np.ndarray:
+    """``Fruit.transform`` with every slice's words sharded over the ranks of the
+    (default) process group; every rank returns the full ``(N, nfeatures)``."""
+    import torch.distributed as dist
+    from .cache import SharedSeedCache
+
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if not fruit._fitted:
+        raise RuntimeError("Missing call of self.fit")
+    cache = SharedSeedCache(X)
+    blocks = [slice_transform_sharded(slc, X, cache, rank, world, group) for slc in fruit._slices]
+    return np.nan_to_num(np.concatenate(blocks, axis=1), copy=False, nan=0.0)

@@ -321,3 +321,33 @@ def test_c_abi_raw_device_entry(fr):
     np.testing.assert_allclose(out, ref, rtol=RTOL)
     L.fr_free(dX)
     L.fr_free(dO)
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_word_sharded_blocks_reassemble(fr, world):
+    """The word-sharded pipeline (fruits_amd.parallel) run rank after rank on one
+    GPU with a loop-back gather: bit-identical to the unsharded transform."""
+    from fruits_amd import parallel as par
+    from fruits_amd.cache import SharedSeedCache
+    case = [c for c in G.cases("fruit") if c["name"] == "cfg3_small"][0]
+    X = G[case["x"]]
+    fruit = build_fruit(fr, case["spec"])
+    np.random.seed(case["np_seed"])
+    fruit.fit(X)
+    ref = fruit.transform(X)
+    slc = fruit.get_slice(0)
+    iss = slc.get_iss()[0]
+    strings = [str(w) for w in iss.words]
+    depths = [iss._depth(i) for i in range(len(strings))]
+    per_sum = sum(s.nfeatures() for s in slc.get_sieves())
+    parts = par.shard_words(strings, depths, world)
+    maps = par.column_map(parts, depths, per_sum)
+    out = np.zeros_like(ref)
+    for r in range(world):
+        cache = SharedSeedCache(X)
+        block = par._device_block(slc, iss, X, cache, parts[r], depths, per_sum).cpu().numpy()
+        assert block.shape[1] == len(maps[r])
+        out[:, maps[r]] = block
+    np.testing.assert_array_equal(np.nan_to_num(out), ref)
+    if world == 1:
+        np.testing.assert_array_equal(par.transform_sharded(fruit, X, rank=0, world=1), ref)
