@@ -29,6 +29,8 @@ EXPORTS = [
     "fr_plan_destroy", "fr_plan_info", "fr_plan_dump", "fr_plan_workspace_bytes",
     "fr_iss_run", "fr_iterated_sum_fast_host", "fr_increments",
     "fr_pathlen_lookup", "fr_sieve", "fr_pre_transform", "fr_standardize",
+    "fr_pipeline_create", "fr_pipeline_destroy", "fr_pipeline_info",
+    "fr_pipeline_workspace_bytes", "fr_pipeline_run",
 ]
 
 _lib = None
@@ -69,6 +71,13 @@ def lib():
     L.fr_plan_dump.restype = C.c_int32
     L.fr_plan_workspace_bytes.restype = C.c_int64
     L.fr_plan_workspace_bytes.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+    L.fr_pipeline_create.restype = C.c_void_p
+    L.fr_pipeline_destroy.restype = None
+    L.fr_pipeline_destroy.argtypes = [C.c_void_p]
+    L.fr_pipeline_info.restype = C.c_int64
+    L.fr_pipeline_info.argtypes = [C.c_void_p, C.c_int32]
+    L.fr_pipeline_workspace_bytes.restype = C.c_int64
+    L.fr_pipeline_workspace_bytes.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
     _lib = L
     return L
 
@@ -247,6 +256,67 @@ class Plan:
             stream_ptr())
         check(rc, "fr_iss_run")
         return out
+
+
+class Pipeline:
+    """ISS + sieves fused into one launch (fr_pipeline_*): the (K, N, T) tensor is
+    never written.  ``sieves`` is a list of ``(kind, inc, cut_row, Q1)`` with
+    ``cut_row`` the transformed int64 cuts (sorted, leading 0) for length ``T``.
+    Raises ValueError when a sieve is outside the fused set."""
+
+    def __init__(self, plan: Plan, sieves, T: int):
+        L = lib()
+        self._h = None
+        self.plan = plan
+        self.T = int(T)
+        n = len(sieves)
+        kinds = np.array([s[0] for s in sieves], dtype=np.int32)
+        incs = np.array([s[1] for s in sieves], dtype=np.int32)
+        C1 = np.array([len(s[2]) for s in sieves], dtype=np.int32)
+        Q1 = np.array([s[3] for s in sieves], dtype=np.int32)
+        cuts = np.concatenate([np.asarray(s[2], dtype=np.int64) for s in sieves]).astype(np.int64)
+        ip = C.POINTER(C.c_int32)
+        h = L.fr_pipeline_create(plan._h, C.c_int32(n), kinds.ctypes.data_as(ip),
+                                 incs.ctypes.data_as(ip), C1.ctypes.data_as(ip),
+                                 Q1.ctypes.data_as(ip),
+                                 cuts.ctypes.data_as(C.POINTER(C.c_int64)), C.c_int64(self.T))
+        if not h:
+            raise ValueError(last_error())
+        self._h = C.c_void_p(h)
+        self.per_sum = int(L.fr_pipeline_info(self._h, 0))
+        self.q_stride = int(L.fr_pipeline_info(self._h, 1))
+        self.n_features = int(L.fr_pipeline_info(self._h, 2))
+
+    def __del__(self):
+        try:
+            if self._h is not None and _lib is not None:
+                _lib.fr_pipeline_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def run(self, Xd, lookup_d, quant_d, feats=None, groups: int = 0, work=None):
+        t = torch()
+        if Xd.dtype != t.float64 or Xd.dim() != 3 or not Xd.is_contiguous():
+            raise TypeError("X must be a contiguous float64 (N, D, T) device tensor")
+        N, D, T = Xd.shape
+        if feats is None:
+            feats = t.empty((N, self.n_features), dtype=t.float64, device=Xd.device)
+        rows = 0
+        if self.plan.weighting != FR_W_NONE:
+            if lookup_d is None:
+                raise ValueError("weighted plan needs a lookup")
+            rows = int(lookup_d.shape[0])
+        wb = int(lib().fr_pipeline_workspace_bytes(self._h, N, rows))
+        if wb > 0 and (work is None or work.numel() < wb):
+            work = t.empty(wb, dtype=t.uint8, device=Xd.device)
+        rc = lib().fr_pipeline_run(
+            self._h, dptr(Xd), C.c_int64(N), C.c_int64(D), C.c_int64(T),
+            dptr(lookup_d if self.plan.weighting != FR_W_NONE else None), C.c_int64(rows),
+            dptr(quant_d), dptr(feats), C.c_int64(feats.stride(0)), dptr(work),
+            C.c_int64(work.numel() if work is not None else 0), C.c_int32(groups), stream_ptr())
+        check(rc, "fr_pipeline_run")
+        return feats
 
 
 # ----------------------------------------------------------------------- kernels

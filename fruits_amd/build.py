@@ -1,10 +1,13 @@
 """Builds fruits_amd/libfruits_hip.so (gfx950) with hipcc, in-tree.
 
 ``python -m fruits_amd.build`` or ``__graft_entry__.build()``.  hipcc
-cross-compiles without a GPU; the built library travels with the tree.
+cross-compiles without a GPU; the built library travels with the tree.  The
+walk kernel's template variants are spread over several objects that compile in
+parallel.
 """
 from __future__ import annotations
 
+import concurrent.futures as cf
 import os
 import shutil
 import subprocess
@@ -12,9 +15,21 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libfruits_hip.so")
-SOURCES = ["iss_kernels.hip", "plan.cpp", "capi.cpp"]
-HEADERS = ["kernels.h", "plan.h", os.path.join("..", "..", "include", "fruits_hip.h")]
+HEADERS = ["kernels.h", "plan.h", "walk.h", "walk_scan.h",
+           os.path.join("..", "..", "include", "fruits_hip.h")]
+
+
+def units():
+    """(object name, source, extra flags)"""
+    out = [("kernels_misc", "kernels_misc.hip", []), ("plan", "plan.cpp", []),
+           ("capi", "capi.cpp", []), ("walk_team1", "walk_inst.hip", ["-DWALK_TEAM1"])]
+    for mode in (0, 1):
+        for lv in (2, 4, 8, 12):
+            out.append((f"walk_m{mode}_l{lv}", "walk_inst.hip",
+                        [f"-DWALK_MODE={mode}", f"-DWALK_LV={lv}"]))
+    return out
 
 
 def hipcc() -> str:
@@ -24,26 +39,53 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
+def _newest_header() -> float:
+    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    srcs = {os.path.join(CSRC, u[1]) for u in units()}
+    return any(os.path.getmtime(s) > t for s in srcs) or _newest_header() > t
 
 
-def build_native(force: bool = False, verbose: bool = False) -> str:
+def build_native(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + (["-DFRUITS_HIP_TIMING_BUILD"] if os.environ.get("FRUITS_HIP_TIMING_BUILD") else []) + [
-           "-Wall", "-Wno-unused-function", "-o", LIB + ".tmp"]
-    cmd += ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
+             "-Wno-unused-function"]
+    if os.environ.get("FRUITS_HIP_TIMING_BUILD"):
+        flags.append("-DFRUITS_HIP_TIMING_BUILD")
+    tag = "t" if os.environ.get("FRUITS_HIP_TIMING_BUILD") else "p"
+    hdr_t = _newest_header()
+
+    def compile_one(unit):
+        name, src, extra = unit
+        srcp = os.path.join(CSRC, src)
+        obj = os.path.join(OBJ, f"{name}.{tag}.o")
+        if (not force and os.path.exists(obj)
+                and os.path.getmtime(obj) > max(os.path.getmtime(srcp), hdr_t)):
+            return obj
+        cmd = [cc] + flags + extra + ["-x", "hip", "-c", srcp, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    jobs = jobs or min(8, os.cpu_count() or 1)
+    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(compile_one, units()))
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build_native(force="--force" in sys.argv, verbose=True))
+    print(build_native(force="--force" in sys.argv, verbose="-v" in sys.argv))

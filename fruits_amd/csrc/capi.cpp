@@ -230,35 +230,49 @@ int64_t fr_plan_workspace_bytes(const fr_plan_t *plan, int64_t N, int64_t T, int
   return (int64_t)work_layout(*plan->p, N, T, lookup_rows).total();
 }
 
-int fr_iss_run(fr_plan_t *plan, const double *d_X, int64_t N, int64_t D, int64_t T,
-               const double *d_lookup, int64_t lookup_rows, double *d_out, int64_t out_k_stride,
-               int64_t out_n_stride, void *d_work, int64_t work_bytes, int32_t groups,
-               void *stream) {
-  if (!plan || !plan->p) return fail(FR_E_ARG, "fr_iss_run: null plan");
-  fr::Plan &p = *plan->p;
-  if (N < 0 || D < 1 || T < 0) return fail(FR_E_ARG, "fr_iss_run: bad shape");
+}  // extern "C"
+
+namespace {
+
+struct FusedArgs {          // non-null feats selects the fused sieve kernels
+  const fr::SieveDesc *sieves = nullptr;
+  const int32_t *cuts = nullptr;
+  const double *quant = nullptr;
+  double *feats = nullptr, *cnt = nullptr;
+  int64_t feat_stride = 0;
+  int32_t n_sieves = 0, q_stride = 0, per_sum = 0;
+};
+
+// Shared body of fr_iss_run and fr_pipeline_run: validates, lays out the
+// workspace, fills the exp tables and launches the trie walk.
+int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t D, int64_t T,
+             const double *d_lookup, int64_t lookup_rows, double *d_out, int64_t out_k_stride,
+             int64_t out_n_stride, void *d_work, int64_t work_bytes, int32_t groups,
+             hipStream_t st, const FusedArgs *fu) {
+  const std::string w(who);
+  if (N < 0 || D < 1 || T < 0) return fail(FR_E_ARG, w + ": bad shape");
   if (p.max_dim > D)
-    return fail(FR_E_DIM, "fr_iss_run: a word references dimension " + std::to_string(p.max_dim) +
+    return fail(FR_E_DIM, w + ": a word references dimension " + std::to_string(p.max_dim) +
                               " but the input has only " + std::to_string(D));
   if (N == 0 || T == 0 || p.K == 0 || p.nodes.empty()) return FR_OK;
-  if (!d_X || !d_out) return fail(FR_E_ARG, "fr_iss_run: null device pointer");
+  if (!d_X || (!fu && !d_out)) return fail(FR_E_ARG, w + ": null device pointer");
   if (p.weighting != 0) {
-    if (!d_lookup) return fail(FR_E_ARG, "fr_iss_run: weighted plan needs a lookup");
+    if (!d_lookup) return fail(FR_E_ARG, w + ": weighted plan needs a lookup");
     if (lookup_rows != 1 && lookup_rows != N)
-      return fail(FR_E_ARG, "fr_iss_run: lookup_rows must be 1 or N");
+      return fail(FR_E_ARG, w + ": lookup_rows must be 1 or N");
   }
-  hipStream_t st = (hipStream_t)stream;
   const WorkLayout wl = work_layout(p, N, T, p.weighting ? lookup_rows : 0);
   if (wl.total() > 0 && (!d_work || (size_t)work_bytes < wl.total()))
-    return fail(FR_E_NOMEM, "fr_iss_run: workspace too small (need " +
-                                std::to_string(wl.total()) + " bytes)");
-  const bool vec_ok_pre = (T % 2 == 0) && aligned16(d_X) && aligned16(d_out) &&
-                          (out_k_stride % 2 == 0) && (out_n_stride % 2 == 0);
-  // one wave per row when the plan splits into 4 balanced groups (see WalkCfg::TEAM)
+    return fail(FR_E_NOMEM, w + ": workspace too small (need " + std::to_string(wl.total()) +
+                                " bytes)");
+  const bool vec_ok_pre = (T % 2 == 0) && aligned16(d_X) &&
+                          (fu || (aligned16(d_out) && (out_k_stride % 2 == 0) &&
+                                  (out_n_stride % 2 == 0)));
+  // one wave per row when the plan splits into 4 balanced groups (see WalkCfg::TEAM);
+  // opt-in: measured 71 us vs 67 us for the cooperative kernel on config 2 (a third
+  // of the scalar instructions, but only 2 waves/SIMD)
   const int team_env = env_int("FRUITS_HIP_TEAM", 0);
-  // (opt-in: measured 71 us vs 67 us for the cooperative kernel on config 2; it has
-  // a third of the scalar instructions but only 2 waves/SIMD)
-  const bool wave_rows = team_env == 1 && groups <= 0 && p.units() >= 4 &&
+  const bool wave_rows = !fu && team_env == 1 && groups <= 0 && p.units() >= 4 &&
                          fr::wave_rows_supported(T, p.levels, vec_ok_pre);
   const int G = wave_rows ? 4 : choose_groups(p, N, groups);
   fr::GroupedProgram &gp = fr::grouped(p, G);
@@ -292,8 +306,7 @@ int fr_iss_run(fr_plan_t *plan, const double *d_X, int64_t N, int64_t D, int64_t
     a.aux_n_stride = lookup_rows == 1 ? 0 : T;
   }
   if (wl.carry_bytes) a.carry = reinterpret_cast<double *>(work + wl.aux_bytes);
-  a.vec_ok = (T % 2 == 0) && aligned16(d_X) && aligned16(d_out) && (out_k_stride % 2 == 0) &&
-             (out_n_stride % 2 == 0) && (!a.aux || aligned16(a.aux));
+  a.vec_ok = vec_ok_pre && (!a.aux || aligned16(a.aux));
   a.xcd_map = (a.G > 1 && N % 8 == 0) ? 1 : 0;
   a.debug = env_int("FRUITS_HIP_DEBUG", 0);
   if (a.debug & 16) {
@@ -305,8 +318,196 @@ int fr_iss_run(fr_plan_t *plan, const double *d_X, int64_t N, int64_t D, int64_t
   }
   a.persistent = env_int("FRUITS_HIP_PERSIST", 1);
   a.wave_rows = wave_rows ? 1 : 0;
+  if (fu) {
+    a.sieves = fu->sieves;
+    a.cuts = fu->cuts;
+    a.quant = fu->quant;
+    a.feats = fu->feats;
+    a.cnt = fu->cnt;
+    a.feat_stride = fu->feat_stride;
+    a.n_sieves = fu->n_sieves;
+    a.q_stride = fu->q_stride;
+    a.per_sum = fu->per_sum;
+  }
   hipError_t e = fr::launch_iss_walk(a, p.levels, st);
   if (e != hipSuccess) return hip_fail(e, "iss_walk launch");
+  return FR_OK;
+}
+
+}  // namespace
+
+struct fr_pipeline {
+  fr_plan_t *plan = nullptr;
+  int64_t T = 0;
+  int32_t n_sieves = 0, per_sum = 0, q_stride = 0;
+  std::vector<int32_t> mpi_cols;
+  void *d_blob = nullptr;
+  const fr::SieveDesc *d_sieves = nullptr;
+  const int32_t *d_cuts = nullptr;
+  const int32_t *d_mpi_cols = nullptr;
+};
+
+extern "C" {
+
+int fr_iss_run(fr_plan_t *plan, const double *d_X, int64_t N, int64_t D, int64_t T,
+               const double *d_lookup, int64_t lookup_rows, double *d_out, int64_t out_k_stride,
+               int64_t out_n_stride, void *d_work, int64_t work_bytes, int32_t groups,
+               void *stream) {
+  if (!plan || !plan->p) return fail(FR_E_ARG, "fr_iss_run: null plan");
+  return run_walk("fr_iss_run", *plan->p, d_X, N, D, T, d_lookup, lookup_rows, d_out,
+                  out_k_stride, out_n_stride, d_work, work_bytes, groups, (hipStream_t)stream,
+                  nullptr);
+}
+
+fr_pipeline_t *fr_pipeline_create(fr_plan_t *plan, int32_t n_sieves, const int32_t *kinds,
+                                  const int32_t *incs, const int32_t *C1, const int32_t *Q1,
+                                  const int64_t *cuts, int64_t T) {
+  if (!plan || !plan->p || n_sieves < 1 || !kinds || !incs || !C1 || !Q1 || !cuts || T < 1) {
+    fail(FR_E_ARG, "fr_pipeline_create: bad argument");
+    return nullptr;
+  }
+  std::vector<fr::SieveDesc> descs(n_sieves);
+  std::vector<int32_t> cut32, mpi_cols;
+  int32_t col = 0, qoff = 0;
+  for (int i = 0; i < n_sieves; ++i) {
+    fr::SieveDesc &d = descs[i];
+    d = fr::SieveDesc{};
+    d.kind = kinds[i];
+    d.inc = incs[i];
+    d.C1 = C1[i];
+    d.Q1 = Q1[i];
+    if (d.kind < 0 || d.kind > 2 || d.C1 < 2) {
+      fail(FR_E_ARG, "fr_pipeline_create: bad sieve " + std::to_string(i));
+      return nullptr;
+    }
+    if (d.kind != FR_SIEVE_END) {
+      if (d.Q1 < 2) {
+        fail(FR_E_ARG, "fr_pipeline_create: a band sieve needs >= 2 thresholds");
+        return nullptr;
+      }
+      if (d.inc < 0 || d.inc > 1) {
+        fail(FR_E_LIMIT, "fr_pipeline_create: the fused epilogue supports inc 0 and 1 only");
+        return nullptr;
+      }
+      if (d.inc == 1 && plan->p->weighting == FR_W_TOTAL) {
+        fail(FR_E_LIMIT, "fr_pipeline_create: increments of totally weighted sums are not fused");
+        return nullptr;
+      }
+    }
+    d.col = col;
+    d.cut_off = (int32_t)cut32.size();
+    for (int j = 0; j < d.C1; ++j) {
+      int64_t c = *cuts++;
+      cut32.push_back((int32_t)(c < 0 ? 0 : (c > T ? T : c)));
+    }
+    const int nf = d.kind == FR_SIEVE_END ? d.C1 - 1 : (d.C1 - 1) * (d.Q1 - 1);
+    if (d.kind == FR_SIEVE_MPI)
+      for (int f = 0; f < nf; ++f) mpi_cols.push_back(col + f);
+    if (d.kind != FR_SIEVE_END) {
+      d.q_off = qoff;
+      qoff += d.Q1;
+    }
+    col += nf;
+  }
+  fr_pipeline_t *pl = new fr_pipeline_t;
+  pl->plan = plan;
+  pl->T = T;
+  pl->n_sieves = n_sieves;
+  pl->per_sum = col;
+  pl->q_stride = qoff > 0 ? qoff : 1;
+  pl->mpi_cols = mpi_cols;
+  const size_t o_s = 0, o_c = align_up(descs.size() * sizeof(fr::SieveDesc), 64);
+  const size_t o_m = o_c + align_up(cut32.size() * 4, 64);
+  const size_t total = o_m + align_up(mpi_cols.size() * 4 + 4, 64);
+  std::vector<char> host(total, 0);
+  std::memcpy(host.data() + o_s, descs.data(), descs.size() * sizeof(fr::SieveDesc));
+  std::memcpy(host.data() + o_c, cut32.data(), cut32.size() * 4);
+  if (!mpi_cols.empty()) std::memcpy(host.data() + o_m, mpi_cols.data(), mpi_cols.size() * 4);
+  void *d = nullptr;
+  hipError_t e = hipMalloc(&d, total);
+  if (e == hipSuccess) e = hipMemcpy(d, host.data(), total, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (d) (void)hipFree(d);
+    hip_fail(e, "fr_pipeline_create upload");
+    delete pl;
+    return nullptr;
+  }
+  char *b = static_cast<char *>(d);
+  pl->d_blob = d;
+  pl->d_sieves = reinterpret_cast<const fr::SieveDesc *>(b + o_s);
+  pl->d_cuts = reinterpret_cast<const int32_t *>(b + o_c);
+  pl->d_mpi_cols = reinterpret_cast<const int32_t *>(b + o_m);
+  return pl;
+}
+
+void fr_pipeline_destroy(fr_pipeline_t *pl) {
+  if (!pl) return;
+  if (pl->d_blob) (void)hipFree(pl->d_blob);
+  delete pl;
+}
+
+int64_t fr_pipeline_info(const fr_pipeline_t *pl, int32_t what) {
+  if (!pl) return fail(FR_E_ARG, "fr_pipeline_info: null pipeline");
+  switch (what) {
+    case 0: return pl->per_sum;
+    case 1: return pl->q_stride;
+    case 2: return (int64_t)pl->per_sum * pl->plan->p->K;
+    default: return fail(FR_E_ARG, "fr_pipeline_info: unknown selector");
+  }
+}
+
+int64_t fr_pipeline_workspace_bytes(const fr_pipeline_t *pl, int64_t N, int64_t lookup_rows) {
+  if (!pl || N < 0) return fail(FR_E_ARG, "fr_pipeline_workspace_bytes: bad argument");
+  const fr::Plan &p = *pl->plan->p;
+  size_t b = align_up(work_layout(p, N, pl->T, p.weighting ? lookup_rows : 0).total(), 256);
+  if (!pl->mpi_cols.empty()) b += align_up((size_t)N * pl->per_sum * p.K * 8, 256);
+  return (int64_t)b;
+}
+
+int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, int64_t T,
+                    const double *d_lookup, int64_t lookup_rows, const double *d_quant,
+                    double *d_feats, int64_t feat_stride, void *d_work, int64_t work_bytes,
+                    int32_t groups, void *stream) {
+  if (!pl || !pl->plan || !pl->plan->p) return fail(FR_E_ARG, "fr_pipeline_run: null pipeline");
+  fr::Plan &p = *pl->plan->p;
+  if (T != pl->T) return fail(FR_E_ARG, "fr_pipeline_run: pipeline was created for another T");
+  const int64_t F = (int64_t)pl->per_sum * p.K;
+  if (N == 0 || F == 0) return FR_OK;
+  if (!d_feats || !d_quant || feat_stride < F)
+    return fail(FR_E_ARG, "fr_pipeline_run: bad feature / quantile buffer");
+  const int64_t need = fr_pipeline_workspace_bytes(pl, N, lookup_rows);
+  if (need > 0 && (!d_work || work_bytes < need))
+    return fail(FR_E_NOMEM, "fr_pipeline_run: workspace too small (need " +
+                                std::to_string(need) + " bytes)");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t plan_ws = align_up(work_layout(p, N, T, p.weighting ? lookup_rows : 0).total(), 256);
+  FusedArgs fu;
+  fu.sieves = pl->d_sieves;
+  fu.cuts = pl->d_cuts;
+  fu.quant = d_quant;
+  fu.feats = d_feats;
+  fu.feat_stride = feat_stride;
+  fu.n_sieves = pl->n_sieves;
+  fu.q_stride = pl->q_stride;
+  fu.per_sum = pl->per_sum;
+  // features accumulate with atomics: clear them (memset nodes, graph-capturable)
+  HIP_TRY(hipMemset2DAsync(d_feats, (size_t)feat_stride * 8, 0, (size_t)F * 8, (size_t)N, st));
+  if (!pl->mpi_cols.empty()) {
+    // the population table shares the feature row stride
+    if (feat_stride != F) return fail(FR_E_ARG, "fr_pipeline_run: MPI needs feat_stride == F");
+    fu.cnt = reinterpret_cast<double *>(static_cast<char *>(d_work) + plan_ws);
+    HIP_TRY(hipMemsetAsync(fu.cnt, 0, (size_t)N * F * 8, st));
+  } else {
+    fu.cnt = d_feats;  // never touched without MPI sieves
+  }
+  int rc = run_walk("fr_pipeline_run", p, d_X, N, D, T, d_lookup, lookup_rows, nullptr, 0, 0,
+                    d_work, (int64_t)plan_ws, groups, st, &fu);
+  if (rc != FR_OK) return rc;
+  if (!pl->mpi_cols.empty()) {
+    hipError_t e = fr::launch_mpi_finalize(d_feats, fu.cnt, N, feat_stride, pl->d_mpi_cols,
+                                           (int)pl->mpi_cols.size(), pl->per_sum, p.K, st);
+    if (e != hipSuccess) return hip_fail(e, "mpi_finalize launch");
+  }
   return FR_OK;
 }
 

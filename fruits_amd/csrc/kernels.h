@@ -14,6 +14,14 @@ constexpr int FR_SIEVE_NPI_K = 0;
 constexpr int FR_SIEVE_MPI_K = 1;
 constexpr int FR_SIEVE_END_K = 2;
 
+struct SieveDesc {   // 32 bytes, read with scalar loads
+  int32_t kind, inc, C1, Q1;
+  int32_t col;        // first feature column inside the block of one iterated sum
+  int32_t cut_off;    // offset of this sieve's C1 cuts in the cut table
+  int32_t q_off;      // offset of its Q1 thresholds inside a row of the quantile table
+  int32_t pad;
+};
+
 struct IssArgs {
   const double *X;          // (N, D, T)
   const double *aux;        // exp tables [2A][aux rows][T] or nullptr
@@ -36,6 +44,14 @@ struct IssArgs {
   int32_t xcd_map;
   int32_t persistent;       // grid = one resident round of workgroups
   int32_t wave_rows;        // TEAM = 1 kernel: one wave per row, 4 groups per workgroup
+  // fused sieve epilogue (MODE 1 kernels): features instead of the (K,N,T) tensor
+  const SieveDesc *sieves;
+  const int32_t *cuts;      // concatenated cut tables (sorted, leading 0, clamped to [0, T])
+  const double *quant;      // (K, q_stride) band thresholds per output row
+  double *feats;            // (N, feat_stride) zero-initialised features
+  double *cnt;              // same shape: band population of MPI features
+  int64_t feat_stride;
+  int32_t n_sieves, q_stride, per_sum;
   unsigned long long *dbg;  // diagnostic stamps (timing build only)
   int32_t debug;            // timing experiments (FRUITS_HIP_DEBUG), 0 in production
 };
@@ -43,6 +59,9 @@ struct IssArgs {
 int walk_chunk_elems(int64_t T);
 bool wave_rows_supported(int64_t T, int levels, bool vec_ok);
 hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st);
+hipError_t launch_mpi_finalize(double *feats, const double *cnt, int64_t N, int64_t stride,
+                               const int32_t *cols, int n_cols, int per_sum, int K,
+                               hipStream_t st);
 hipError_t launch_exp_tables(const double *g, int64_t count, const float *alphas, int n_alpha,
                              double *aux, hipStream_t st);
 hipError_t launch_increments(const double *X, int64_t rows, int64_t T, int64_t shift, double *out,

@@ -1,0 +1,374 @@
+// Small HIP kernels around the trie walk (exp tables, INC, path-length lookups,
+// standalone sieves, STD) and the dispatcher over the walk-kernel instances.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "walk_scan.h"
+
+namespace fr {
+
+// ---------------------------------------------------------------- exp tables
+// aux[2a]   = exp( g * alpha_a)   (np.exp(weights * alpha[k]),  semiring.py:123,150)
+// aux[2a+1] = exp(-g * alpha_a)   (np.exp(-weights * alpha[k]), semiring.py:119,153,157)
+__global__ void exp_tables_kernel(const double *__restrict__ g, int64_t count,
+                                  const float *__restrict__ alphas, int n_alpha,
+                                  double *__restrict__ aux) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const double w = g[i];
+  for (int a = 0; a < n_alpha; ++a) {
+    const double al = (double)alphas[a];
+    aux[(int64_t)(2 * a) * count + i] = exp(w * al);
+    aux[(int64_t)(2 * a + 1) * count + i] = exp(-w * al);
+  }
+}
+
+// ---------------------------------------------------------------- increments
+__global__ void increments_kernel(const double *__restrict__ X, int64_t rows, int64_t T,
+                                  int64_t shift, double *__restrict__ out,
+                                  const double *__restrict__ head_src, int64_t head) {
+  const int64_t total = rows * T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i % T;
+    double v = (t >= shift) ? X[i] - X[i - shift] : 0.0;
+    if (head_src != nullptr && t < head) v = head_src[i];
+    out[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------- path-length lookup
+// One workgroup per series: r = cumsum_t |dx_0| (or dx_0^2), optional /(last+1e-5),
+// min-max normalise, * scale.  fruits/iss/weighting.py:148-160, cache.py:25-40,
+// preparation/transform.py:184-198.
+__device__ __forceinline__ double block_reduce_minmax(double v, bool is_max, double *sm) {
+  for (int o = 32; o > 0; o >>= 1) {
+    double w = __shfl_xor(v, o);
+    v = is_max ? fmax(v, w) : fmin(v, w);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  double r = sm[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = is_max ? fmax(r, sm[w]) : fmin(r, sm[w]);
+  return r;
+}
+
+__global__ __launch_bounds__(256) void pathlen_lookup_kernel(const double *__restrict__ X,
+                                                              int64_t D, int64_t T, int norm,
+                                                              int relative, double scale,
+                                                              double *__restrict__ out) {
+  __shared__ double sm_tot[2][4];
+  __shared__ double sm_red[4];
+  const int64_t n = blockIdx.x;
+  const double *x = X + n * D * T;  // dimension 0 only
+  double *o = out + n * T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double carry = 0.0;
+  int buf = 0;
+  for (int64_t t0 = 0; t0 < T; t0 += 512) {
+    double s[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int64_t t = t0 + tid * 2 + e;
+      double d = 0.0;
+      if (t < T && t >= 1) d = x[t] - x[t - 1];
+      s[e] = (norm == 1) ? fabs(d) : d * d;
+      if (t >= T) s[e] = 0.0;
+    }
+    const double l1 = s[0] + s[1];
+    const double incl = wave_inclusive_scan(l1);
+    const double excl = wave_shift_right1(incl);
+    if (lane == 63) sm_tot[buf][wave] = incl;
+    __syncthreads();
+    double run = carry, base = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w == wave) base = run;
+      run += sm_tot[buf][w];
+    }
+    carry = run;
+    buf ^= 1;
+    const double off = base + excl;
+    const int64_t t = t0 + tid * 2;
+    if (t < T) o[t] = off + s[0];
+    if (t + 1 < T) o[t + 1] = off + l1;
+  }
+  if (relative == 2) return;  // raw cumulative path length (SharedSeedCache entry)
+  __syncthreads();
+  // every thread re-reads only elements it wrote itself (same t -> same thread)
+  const double last = carry;
+  double mn = INFINITY, mx = -INFINITY;
+  for (int64_t t0 = 0; t0 < T; t0 += 512)
+    for (int e = 0; e < 2; ++e) {
+      const int64_t t = t0 + tid * 2 + e;
+      if (t < T) {
+        double v = o[t];
+        if (relative) v = v / (last + 1e-5);
+        mn = fmin(mn, v);
+        mx = fmax(mx, v);
+      }
+    }
+  mn = block_reduce_minmax(mn, false, sm_red);
+  mx = block_reduce_minmax(mx, true, sm_red);
+  for (int64_t t0 = 0; t0 < T; t0 += 512)
+    for (int e = 0; e < 2; ++e) {
+      const int64_t t = t0 + tid * 2 + e;
+      if (t < T) {
+        double v = o[t];
+        if (relative) v = v / (last + 1e-5);
+        o[t] = (mn != mx) ? ((v - mn) / (mx - mn)) * scale : 0.0 * scale;
+      }
+    }
+}
+
+// ---------------------------------------------------------------- sieves on (N,T)
+// value of the inc-times differenced series at t (IncrementSieve._pre_transform,
+// fruits/sieving/increment.py:63-71 with _increments of fruits/cache.py:8-13):
+// D_0 = A, D_k[t] = D_{k-1}[t] - D_{k-1}[t-1] for t >= 1, D_k[0] = 0.
+constexpr int kMaxInc = 8;
+__device__ __forceinline__ double diff_at(const double *__restrict__ row, int64_t t, int inc) {
+  double v[kMaxInc + 1];
+#pragma unroll
+  for (int j = 0; j <= kMaxInc; ++j) v[j] = (j <= inc && t - j >= 0) ? row[t - j] : 0.0;
+#pragma unroll
+  for (int lvl = 1; lvl <= kMaxInc; ++lvl) {
+    if (lvl <= inc) {
+#pragma unroll
+      for (int j = 0; j + lvl <= kMaxInc; ++j)
+        if (j <= inc - lvl) v[j] = (t - j >= 1) ? v[j] - v[j + 1] : 0.0;
+    }
+  }
+  return v[0];
+}
+
+__global__ __launch_bounds__(256) void sieve_kernel(int kind, const double *__restrict__ A,
+                                                     int64_t T, int64_t a_stride, int inc,
+                                                     const int64_t *__restrict__ cuts,
+                                                     int64_t cut_rows, int C1,
+                                                     const double *__restrict__ q, int Q1,
+                                                     double *__restrict__ out,
+                                                     int64_t out_stride) {
+  __shared__ double sm_sum[4];
+  __shared__ double sm_cnt[4];
+  const int64_t n = blockIdx.x;
+  const double *row = A + n * a_stride;
+  const int64_t *cut = cuts + (cut_rows == 1 ? 0 : n * C1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (kind == FR_SIEVE_END_K) {
+    // out[n, j] = A[n, cut_{j+1} - 1]; index -1 wraps like numpy (segment.py:213-218)
+    for (int j = tid; j < C1 - 1; j += blockDim.x) {
+      int64_t idx = cut[j + 1] - 1;
+      if (idx < 0) idx += T;
+      out[n * out_stride + j] = row[idx];
+    }
+    return;
+  }
+  const int Q = Q1 - 1;
+  for (int j = 0; j < C1 - 1; ++j) {
+    int64_t lo = cut[j], hi = cut[j + 1];
+    if (lo < 0) lo = 0;
+    if (hi > T) hi = T;
+    for (int k = 0; k < Q; ++k) {
+      const double qlo = q[k], qhi = q[k + 1];
+      double sum = 0.0, cnt = 0.0;
+      for (int64_t t = lo + tid; t < hi; t += blockDim.x) {
+        const double v = diff_at(row, t, inc);
+        if (qlo < v && v <= qhi) {
+          sum += v;
+          cnt += 1.0;
+        }
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        sum += __shfl_xor(sum, o);
+        cnt += __shfl_xor(cnt, o);
+      }
+      __syncthreads();
+      if (lane == 0) {
+        sm_sum[wave] = sum;
+        sm_cnt[wave] = cnt;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double s = 0.0, c = 0.0;
+        for (int w = 0; w < 4; ++w) {
+          s += sm_sum[w];
+          c += sm_cnt[w];
+        }
+        out[n * out_stride + j * Q + k] =
+            (kind == FR_SIEVE_NPI_K) ? c : (c > 0.0 ? s / c : 0.0);
+      }
+    }
+  }
+}
+
+// IncrementSieve._pre_transform (inc >= 0) materialised: out[n,t] = D_inc[n,t]
+__global__ void pre_transform_kernel(const double *__restrict__ A, int64_t N, int64_t T,
+                                     int64_t a_stride, int inc, double *__restrict__ out) {
+  const int64_t total = N * T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / T, t = i % T;
+    out[i] = diff_at(A + n * a_stride, t, inc);
+  }
+}
+
+// STD preparateur, separately=True (fruits/preparation/transform.py:141-147):
+// per (series, dimension) row: (x - mean) / (std + eps), std = population std
+// (np.std), or 1 when var=False.
+__device__ __forceinline__ double block_reduce_sum(double v, double *sm) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  double r = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += sm[w];
+  return r;
+}
+
+__global__ __launch_bounds__(256) void standardize_kernel(const double *__restrict__ X, int64_t T,
+                                                           int div_std, double eps,
+                                                           double *__restrict__ out) {
+  __shared__ double sm[4];
+  const double *x = X + (int64_t)blockIdx.x * T;
+  double *o = out + (int64_t)blockIdx.x * T;
+  double acc = 0.0;
+  for (int64_t t = threadIdx.x; t < T; t += blockDim.x) acc += x[t];
+  const double mean = block_reduce_sum(acc, sm) / (double)T;
+  double sd = 1.0;
+  if (div_std) {
+    double v = 0.0;
+    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
+      const double d = x[t] - mean;
+      v += d * d;
+    }
+    sd = sqrt(block_reduce_sum(v, sm) / (double)T);
+  }
+  const double den = sd + eps;
+  for (int64_t t = threadIdx.x; t < T; t += blockDim.x) o[t] = (x[t] - mean) / den;
+}
+
+// ---------------------------------------------------------------- launchers
+int walk_chunk_elems(int64_t T) { return T <= 512 ? 512 : 1024; }
+
+// wave-per-row variant (TEAM = 1): single chunk, aligned 16-byte accesses,
+// shallow tries (register frames of 2 * E * P VGPRs per level)
+bool wave_rows_supported(int64_t T, int levels, bool vec_ok) {
+  return vec_ok && T <= 1024 && levels <= 4;
+}
+
+#define DECL_INST(m, l) hipError_t walk_inst_m##m##_l##l(const IssArgs &, int, hipStream_t);
+DECL_INST(0, 2) DECL_INST(0, 4) DECL_INST(0, 8) DECL_INST(0, 12)
+DECL_INST(1, 2) DECL_INST(1, 4) DECL_INST(1, 8) DECL_INST(1, 12)
+hipError_t walk_inst_team1(const IssArgs &, int, int, hipStream_t);
+
+hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st) {
+  const int chunk = walk_chunk_elems(a.T);
+  a.nchunks = (int32_t)((a.T + chunk - 1) / chunk);
+  if (a.N * a.G <= 0) return hipSuccess;
+  if (a.nchunks > 1 && a.carry == nullptr) return hipErrorInvalidValue;
+  if (a.wave_rows) {
+    if (a.G != 4 || a.feats || !wave_rows_supported(a.T, levels, a.vec_ok != 0))
+      return hipErrorInvalidValue;
+    return walk_inst_team1(a, levels, chunk, st);
+  }
+  if (a.feats) {
+    if (levels <= 2) return walk_inst_m1_l2(a, chunk, st);
+    if (levels <= 4) return walk_inst_m1_l4(a, chunk, st);
+    if (levels <= 8) return walk_inst_m1_l8(a, chunk, st);
+    return walk_inst_m1_l12(a, chunk, st);
+  }
+  if (levels <= 2) return walk_inst_m0_l2(a, chunk, st);
+  if (levels <= 4) return walk_inst_m0_l4(a, chunk, st);
+  if (levels <= 8) return walk_inst_m0_l8(a, chunk, st);
+  return walk_inst_m0_l12(a, chunk, st);
+}
+
+// MPI features: mean = sum / population (0 for an empty band, increment.py:158-161)
+__global__ void mpi_finalize_kernel(double *__restrict__ feats, const double *__restrict__ cnt,
+                                    int64_t N, int64_t stride, const int32_t *__restrict__ cols,
+                                    int n_cols, int per_sum, int K) {
+  const int64_t total = N * (int64_t)K * n_cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / ((int64_t)K * n_cols);
+    const int64_t r = i % ((int64_t)K * n_cols);
+    const int64_t f = (r / n_cols) * per_sum + cols[r % n_cols];
+    const double c = cnt[n * stride + f];
+    feats[n * stride + f] = c > 0.0 ? feats[n * stride + f] / c : 0.0;
+  }
+}
+
+hipError_t launch_mpi_finalize(double *feats, const double *cnt, int64_t N, int64_t stride,
+                               const int32_t *cols, int n_cols, int per_sum, int K,
+                               hipStream_t st) {
+  const int64_t total = N * (int64_t)K * n_cols;
+  if (total <= 0) return hipSuccess;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(mpi_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, st, feats, cnt, N,
+                     stride, cols, n_cols, per_sum, K);
+  return hipGetLastError();
+}
+
+hipError_t launch_exp_tables(const double *g, int64_t count, const float *alphas, int n_alpha,
+                             double *aux, hipStream_t st) {
+  if (count <= 0 || n_alpha <= 0) return hipSuccess;
+  const int bs = 256;
+  hipLaunchKernelGGL(exp_tables_kernel, dim3((unsigned)((count + bs - 1) / bs)), dim3(bs), 0, st,
+                     g, count, alphas, n_alpha, aux);
+  return hipGetLastError();
+}
+
+hipError_t launch_increments(const double *X, int64_t rows, int64_t T, int64_t shift, double *out,
+                             const double *head_src, int64_t head, hipStream_t st) {
+  const int64_t total = rows * T;
+  if (total <= 0) return hipSuccess;
+  const int bs = 256;
+  int64_t blocks = (total + bs - 1) / bs;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(increments_kernel, dim3((unsigned)blocks), dim3(bs), 0, st, X, rows, T,
+                     shift, out, head_src, head);
+  return hipGetLastError();
+}
+
+hipError_t launch_pathlen_lookup(const double *X, int64_t N, int64_t D, int64_t T, int norm,
+                                 int relative, double scale, double *out, hipStream_t st) {
+  if (N <= 0 || T <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pathlen_lookup_kernel, dim3((unsigned)N), dim3(256), 0, st, X, D, T, norm,
+                     relative, scale, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_sieve(int kind, const double *A, int64_t N, int64_t T, int64_t a_stride, int inc,
+                        const int64_t *cuts, int64_t cut_rows, int C1, const double *q, int Q1,
+                        double *out, int64_t out_stride, hipStream_t st) {
+  if (N <= 0) return hipSuccess;
+  hipLaunchKernelGGL(sieve_kernel, dim3((unsigned)N), dim3(256), 0, st, kind, A, T, a_stride, inc,
+                     cuts, cut_rows, C1, q, Q1, out, out_stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_pre_transform(const double *A, int64_t N, int64_t T, int64_t a_stride, int inc,
+                                double *out, hipStream_t st) {
+  const int64_t total = N * T;
+  if (total <= 0) return hipSuccess;
+  const int bs = 256;
+  int64_t blocks = (total + bs - 1) / bs;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(pre_transform_kernel, dim3((unsigned)blocks), dim3(bs), 0, st, A, N, T,
+                     a_stride, inc, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_standardize(const double *X, int64_t rows, int64_t T, int div_std, double eps,
+                              double *out, hipStream_t st) {
+  if (rows <= 0 || T <= 0) return hipSuccess;
+  hipLaunchKernelGGL(standardize_kernel, dim3((unsigned)rows), dim3(256), 0, st, X, T, div_std,
+                     eps, out);
+  return hipGetLastError();
+}
+
+}  // namespace fr

@@ -12,96 +12,26 @@
 //     stores into the reference's (K,N,T) layout (fruits/iss/iss.py:46).
 // The kernel is HBM-bound (one write per output element, X read once per
 // group); there is no contraction anywhere, so no MFMA.
+#pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_runtime_api.h>
 
 #include "kernels.h"
+#include "walk_scan.h"
 
 namespace fr {
-
-typedef double vd2 __attribute__((ext_vector_type(2)));
-
-// The program tables are read-only for the whole launch.  Reading them through
-// the constant address space makes every (wave-uniform) access a scalar load
-// (s_load, counted by lgkmcnt).  As plain global loads they would be VECTOR loads
-// counted by vmcnt, and waiting for one of those also waits for every output
-// store issued before it - serialising the store stream node by node.
-template <class T>
-using cptr = const T __attribute__((address_space(4))) *;
-template <class T>
-__device__ __forceinline__ cptr<T> as_const(const T *p) {
-  return (cptr<T>)(p);
-}
-
-// ---------------------------------------------------------------- wave scan
-// DPP fetch of a double: the value of the source lane, 0.0 where the lane has no
-// source.  FULL = all rows enabled: bound_ctrl supplies the zeros and no "old"
-// value has to be materialised; otherwise disabled rows keep old = 0.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_fetch(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  if constexpr (ROW_MASK == 0xf) {
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-  } else {
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
-  }
-  return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double wave_inclusive_scan(double v) {
-  v += dpp_fetch<0x111, 0xf>(v);  // row_shr:1
-  v += dpp_fetch<0x112, 0xf>(v);  // row_shr:2
-  v += dpp_fetch<0x114, 0xf>(v);  // row_shr:4
-  v += dpp_fetch<0x118, 0xf>(v);  // row_shr:8
-  v += dpp_fetch<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
-  v += dpp_fetch<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
-  return v;
-}
-
-// P independent scans, advanced step by step so their DPP latencies overlap
-template <int P>
-__device__ __forceinline__ void wave_inclusive_scan_multi(double (&v)[P]) {
-#pragma unroll
-  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x111, 0xf>(v[h]);
-#pragma unroll
-  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x112, 0xf>(v[h]);
-#pragma unroll
-  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x114, 0xf>(v[h]);
-#pragma unroll
-  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x118, 0xf>(v[h]);
-#pragma unroll
-  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x142, 0xa>(v[h]);
-#pragma unroll
-  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x143, 0xc>(v[h]);
-}
-
-__device__ __forceinline__ double wave_shift_right1(double v) {
-  return dpp_fetch<0x138, 0xf>(v);  // wave_shr:1, lane 0 gets 0.0
-}
-
-__device__ __forceinline__ double wave_last_lane(double v) {
-  // lane 63's value as a wave-uniform (scalar) double
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-  return __hiloint2double(hi, lo);
-}
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for
-// vmcnt(0), i.e. for the acknowledgement of every global store the wave has in
-// flight - that would serialise each node's output stores with the next node's
-// scan.  Waiting for lgkmcnt(0) alone keeps the stores streaming.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 // ---------------------------------------------------------------- walk kernel
 // Time layout of one chunk: wave w owns the contiguous span [w*SPAN, (w+1)*SPAN);
 // the span is P pieces of 64*E elements; lane l holds E consecutive elements of
 // every piece.  So every 16-byte global access of a wave is lane-contiguous
 // (E = 2: 1 KiB per instruction) and only NW wave totals cross waves.
-template <int E_, int P_, int MAXLV_, bool MULTI_, bool VEC_, bool WEIGHTED_, int TEAM_ = 4>
+template <int E_, int P_, int MAXLV_, bool MULTI_, bool VEC_, bool WEIGHTED_, int TEAM_ = 4,
+          int MODE_ = 0>
 struct WalkCfg {
+  // MODE 0: write the (K,N,T) tensor.  MODE 1: fused sieve epilogue - the values of
+  // a node go straight into NPI / MPI / END features, no tensor is written.
+  static constexpr int MODE = MODE_;
   // TEAM waves scan one row together.  TEAM = 4: the whole workgroup works on one
   // (series, group) unit and waves exchange totals through LDS once per node.
   // TEAM = 1: every wave scans whole rows alone (no barrier, no LDS exchange) and
@@ -141,6 +71,8 @@ struct WalkCtx {
   const double *rows;   // LDS: staged rows [R][CHUNK]
   double *tot;          // LDS: wave totals [2][NW]
   double *out_base;     // out + n*out_n_stride + t0
+  double *feat_row;     // MODE 1: feats + n*feat_stride
+  double *cnt_row;      // MODE 1: band population of MPI features
   double *carry;        // carry slots of this series (multi-chunk) or nullptr
   int64_t t0;           // first time index of the chunk
   int tid, lane, wave, team;   // wave = index inside the team
@@ -360,6 +292,95 @@ __device__ __forceinline__ void emit_all(const WalkCtx &cx, const Rec &nd,
   }
 }
 
+// ---------------------------------------------------------------- fused sieves
+// Features of ONE output row k from the node's inclusive values c and their
+// exclusive shifts x (x[t] = c[t-1]): what IncrementSieve._pre_transform +
+// NPI/MPI._backend (fruits/sieving/increment.py:63-71,107-163) and END._transform
+// (fruits/sieving/segment.py:210-219) compute on the materialised row.
+template <class C>
+__device__ __forceinline__ void fused_row(const WalkCtx &cx, int64_t k, const double (&c)[C::EP],
+                                          const double (&x)[C::EP]) {
+  constexpr int E = C::E, P = C::P, EP = C::EP;
+  const IssArgs &a = *cx.a;
+  cptr<double> qrow = as_const(a.quant) + k * a.q_stride;
+  double *frow = cx.feat_row + k * a.per_sum;
+  double *crow = cx.cnt_row + k * a.per_sum;
+  const int T = (int)a.T;
+  const int t_first = (int)cx.t0 + cx.wave * C::SPAN + cx.lane * E;  // element (h=0, e=0)
+  for (int si = 0; si < a.n_sieves; ++si) {
+    cptr<int32_t> sd = as_const(reinterpret_cast<const int32_t *>(a.sieves + si));
+    const int kind = sd[0], inc = sd[1], C1 = sd[2], Q1 = sd[3], col = sd[4];
+    cptr<int32_t> cut = as_const(a.cuts) + sd[5];
+    const int q_off = sd[6];
+    if (kind == FR_SIEVE_END_K) {
+      for (int j = 0; j + 1 < C1; ++j) {
+        int idx = cut[j + 1] - 1;
+        if (idx < 0) idx += T;  // numpy's wrap of index -1 (cut = 0)
+        const int rel = idx - (int)cx.t0;
+        if (rel >= 0 && rel < C::CHUNK) {
+          const int wv = rel / C::SPAN, in = rel % C::SPAN;
+          const int sel = (in / C::PIECE) * E + (in % E), ln = (in % C::PIECE) / E;
+          double val = c[0];
+#pragma unroll
+          for (int i = 1; i < EP; ++i) val = (sel == i) ? c[i] : val;
+          if (cx.wave == wv && cx.lane == ln) frow[col + j] = val;
+        }
+      }
+      continue;
+    }
+    double d[EP];
+    if (inc == 0) {
+#pragma unroll
+      for (int i = 0; i < EP; ++i) d[i] = c[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < EP; ++i) d[i] = c[i] - x[i];
+      if (t_first == 0) d[0] = 0.0;  // increments are zero-padded at t = 0 (cache.py:8-13)
+    }
+    for (int j = 0; j + 1 < C1; ++j) {
+      const int lo = cut[j], hi = cut[j + 1];
+      for (int q = 0; q + 1 < Q1; ++q) {
+        const double qlo = qrow[q_off + q], qhi = qrow[q_off + q + 1];
+        int cnt = 0;
+        double sum = 0.0;
+#pragma unroll
+        for (int h = 0; h < P; ++h)
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const int t = t_first + h * C::PIECE + e;
+            const double v = d[h * E + e];
+            const bool in = t >= lo && t < hi && qlo < v && v <= qhi;
+            cnt += __popcll(__ballot(in));
+            if (kind == FR_SIEVE_MPI_K) sum += in ? v : 0.0;
+          }
+        if (cnt == 0) continue;
+        const int f = col + j * (Q1 - 1) + q;
+        if (kind == FR_SIEVE_MPI_K) {
+          for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+          if (cx.lane == 0) {
+            unsafeAtomicAdd(&frow[f], sum);
+            unsafeAtomicAdd(&crow[f], (double)cnt);
+          }
+        } else if (cx.lane == 0) {
+          unsafeAtomicAdd(&frow[f], (double)cnt);
+        }
+      }
+    }
+  }
+}
+
+template <class C>
+__device__ __forceinline__ void fused_all(const WalkCtx &cx, const Rec &nd,
+                                          const double (&c)[C::EP], const double (&x)[C::EP]) {
+  const int ne = nd.emit_count();
+  if (ne > 0) fused_row<C>(cx, nd.w[7], c, x);
+  if (ne > 1) {
+    fused_row<C>(cx, nd.w[8], c, x);
+    for (int j = kRecInlineEmits; j < ne; ++j)
+      fused_row<C>(cx, as_const(cx.a->emit_rows)[nd.emit_begin() + j], c, x);
+  }
+}
+
 template <class C>
 __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd,
                                              const double (&pin)[C::EP],
@@ -398,7 +419,10 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd,
     block_scan<C>(cx, s, c, x, 2 * nd.node_id());
     if (nd.emit_count() > 0) {
       if (C::WEIGHTED && emit_mul >= 0) mul_row<C>(cx, emit_mul, c);
-      emit_all<C>(cx, nd, c);
+      if constexpr (C::MODE == 1)
+        fused_all<C>(cx, nd, c, x);
+      else
+        emit_all<C>(cx, nd, c);
       STAMP(cx, 5);  // stores
     }
     if (has_children && !need2) {
@@ -500,6 +524,10 @@ __global__ __launch_bounds__(kWalkThreads) void iss_walk_kernel(const IssArgs a)
       cx.first_chunk = chunk == 0;
       cx.full_chunk = t0 + C::CHUNK <= a.T;
       cx.out_base = a.out + n * a.out_n_stride + t0;
+      if constexpr (C::MODE == 1) {
+        cx.feat_row = a.feats + n * a.feat_stride;
+        cx.cnt_row = a.cnt + n * a.feat_stride;
+      }
       if (!first_unit || chunk > 0) lds_barrier();  // all reads of the old rows are done
       // stage the referenced rows of this chunk: coalesced 16-byte units, the
       // loads of up to 4 rows in flight before the first LDS write
@@ -521,7 +549,7 @@ __global__ __launch_bounds__(kWalkThreads) void iss_walk_kernel(const IssArgs a)
               const int i = 2 * (k * kWalkThreads + tid);
               const int64_t t = t0 + i;
               v[rr][k] = vd2{0.0, 0.0};
-              if constexpr (C::VEC) {
+              if (a.vec_ok) {
                 if (cx.full_chunk || t < a.T) v[rr][k] = *reinterpret_cast<const vd2 *>(gp + t);
               } else {
                 if (t < a.T) v[rr][k].x = gp[t];
@@ -562,250 +590,7 @@ __global__ __launch_bounds__(kWalkThreads) void iss_walk_kernel(const IssArgs a)
 #endif
 }
 
-// ---------------------------------------------------------------- exp tables
-// aux[2a]   = exp( g * alpha_a)   (np.exp(weights * alpha[k]),  semiring.py:123,150)
-// aux[2a+1] = exp(-g * alpha_a)   (np.exp(-weights * alpha[k]), semiring.py:119,153,157)
-__global__ void exp_tables_kernel(const double *__restrict__ g, int64_t count,
-                                  const float *__restrict__ alphas, int n_alpha,
-                                  double *__restrict__ aux) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  const double w = g[i];
-  for (int a = 0; a < n_alpha; ++a) {
-    const double al = (double)alphas[a];
-    aux[(int64_t)(2 * a) * count + i] = exp(w * al);
-    aux[(int64_t)(2 * a + 1) * count + i] = exp(-w * al);
-  }
-}
-
-// ---------------------------------------------------------------- increments
-__global__ void increments_kernel(const double *__restrict__ X, int64_t rows, int64_t T,
-                                  int64_t shift, double *__restrict__ out,
-                                  const double *__restrict__ head_src, int64_t head) {
-  const int64_t total = rows * T;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t t = i % T;
-    double v = (t >= shift) ? X[i] - X[i - shift] : 0.0;
-    if (head_src != nullptr && t < head) v = head_src[i];
-    out[i] = v;
-  }
-}
-
-// ---------------------------------------------------------------- path-length lookup
-// One workgroup per series: r = cumsum_t |dx_0| (or dx_0^2), optional /(last+1e-5),
-// min-max normalise, * scale.  fruits/iss/weighting.py:148-160, cache.py:25-40,
-// preparation/transform.py:184-198.
-__device__ __forceinline__ double block_reduce_minmax(double v, bool is_max, double *sm) {
-  for (int o = 32; o > 0; o >>= 1) {
-    double w = __shfl_xor(v, o);
-    v = is_max ? fmax(v, w) : fmin(v, w);
-  }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  __syncthreads();
-  if (lane == 0) sm[wave] = v;
-  __syncthreads();
-  double r = sm[0];
-  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = is_max ? fmax(r, sm[w]) : fmin(r, sm[w]);
-  return r;
-}
-
-__global__ __launch_bounds__(256) void pathlen_lookup_kernel(const double *__restrict__ X,
-                                                              int64_t D, int64_t T, int norm,
-                                                              int relative, double scale,
-                                                              double *__restrict__ out) {
-  __shared__ double sm_tot[2][4];
-  __shared__ double sm_red[4];
-  const int64_t n = blockIdx.x;
-  const double *x = X + n * D * T;  // dimension 0 only
-  double *o = out + n * T;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double carry = 0.0;
-  int buf = 0;
-  for (int64_t t0 = 0; t0 < T; t0 += 512) {
-    double s[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int64_t t = t0 + tid * 2 + e;
-      double d = 0.0;
-      if (t < T && t >= 1) d = x[t] - x[t - 1];
-      s[e] = (norm == 1) ? fabs(d) : d * d;
-      if (t >= T) s[e] = 0.0;
-    }
-    const double l1 = s[0] + s[1];
-    const double incl = wave_inclusive_scan(l1);
-    const double excl = wave_shift_right1(incl);
-    if (lane == 63) sm_tot[buf][wave] = incl;
-    __syncthreads();
-    double run = carry, base = 0.0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      if (w == wave) base = run;
-      run += sm_tot[buf][w];
-    }
-    carry = run;
-    buf ^= 1;
-    const double off = base + excl;
-    const int64_t t = t0 + tid * 2;
-    if (t < T) o[t] = off + s[0];
-    if (t + 1 < T) o[t + 1] = off + l1;
-  }
-  if (relative == 2) return;  // raw cumulative path length (SharedSeedCache entry)
-  __syncthreads();
-  // every thread re-reads only elements it wrote itself (same t -> same thread)
-  const double last = carry;
-  double mn = INFINITY, mx = -INFINITY;
-  for (int64_t t0 = 0; t0 < T; t0 += 512)
-    for (int e = 0; e < 2; ++e) {
-      const int64_t t = t0 + tid * 2 + e;
-      if (t < T) {
-        double v = o[t];
-        if (relative) v = v / (last + 1e-5);
-        mn = fmin(mn, v);
-        mx = fmax(mx, v);
-      }
-    }
-  mn = block_reduce_minmax(mn, false, sm_red);
-  mx = block_reduce_minmax(mx, true, sm_red);
-  for (int64_t t0 = 0; t0 < T; t0 += 512)
-    for (int e = 0; e < 2; ++e) {
-      const int64_t t = t0 + tid * 2 + e;
-      if (t < T) {
-        double v = o[t];
-        if (relative) v = v / (last + 1e-5);
-        o[t] = (mn != mx) ? ((v - mn) / (mx - mn)) * scale : 0.0 * scale;
-      }
-    }
-}
-
-// ---------------------------------------------------------------- sieves on (N,T)
-// value of the inc-times differenced series at t (IncrementSieve._pre_transform,
-// fruits/sieving/increment.py:63-71 with _increments of fruits/cache.py:8-13):
-// D_0 = A, D_k[t] = D_{k-1}[t] - D_{k-1}[t-1] for t >= 1, D_k[0] = 0.
-constexpr int kMaxInc = 8;
-__device__ __forceinline__ double diff_at(const double *__restrict__ row, int64_t t, int inc) {
-  double v[kMaxInc + 1];
-#pragma unroll
-  for (int j = 0; j <= kMaxInc; ++j) v[j] = (j <= inc && t - j >= 0) ? row[t - j] : 0.0;
-#pragma unroll
-  for (int lvl = 1; lvl <= kMaxInc; ++lvl) {
-    if (lvl <= inc) {
-#pragma unroll
-      for (int j = 0; j + lvl <= kMaxInc; ++j)
-        if (j <= inc - lvl) v[j] = (t - j >= 1) ? v[j] - v[j + 1] : 0.0;
-    }
-  }
-  return v[0];
-}
-
-__global__ __launch_bounds__(256) void sieve_kernel(int kind, const double *__restrict__ A,
-                                                     int64_t T, int64_t a_stride, int inc,
-                                                     const int64_t *__restrict__ cuts,
-                                                     int64_t cut_rows, int C1,
-                                                     const double *__restrict__ q, int Q1,
-                                                     double *__restrict__ out,
-                                                     int64_t out_stride) {
-  __shared__ double sm_sum[4];
-  __shared__ double sm_cnt[4];
-  const int64_t n = blockIdx.x;
-  const double *row = A + n * a_stride;
-  const int64_t *cut = cuts + (cut_rows == 1 ? 0 : n * C1);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (kind == FR_SIEVE_END_K) {
-    // out[n, j] = A[n, cut_{j+1} - 1]; index -1 wraps like numpy (segment.py:213-218)
-    for (int j = tid; j < C1 - 1; j += blockDim.x) {
-      int64_t idx = cut[j + 1] - 1;
-      if (idx < 0) idx += T;
-      out[n * out_stride + j] = row[idx];
-    }
-    return;
-  }
-  const int Q = Q1 - 1;
-  for (int j = 0; j < C1 - 1; ++j) {
-    int64_t lo = cut[j], hi = cut[j + 1];
-    if (lo < 0) lo = 0;
-    if (hi > T) hi = T;
-    for (int k = 0; k < Q; ++k) {
-      const double qlo = q[k], qhi = q[k + 1];
-      double sum = 0.0, cnt = 0.0;
-      for (int64_t t = lo + tid; t < hi; t += blockDim.x) {
-        const double v = diff_at(row, t, inc);
-        if (qlo < v && v <= qhi) {
-          sum += v;
-          cnt += 1.0;
-        }
-      }
-      for (int o = 32; o > 0; o >>= 1) {
-        sum += __shfl_xor(sum, o);
-        cnt += __shfl_xor(cnt, o);
-      }
-      __syncthreads();
-      if (lane == 0) {
-        sm_sum[wave] = sum;
-        sm_cnt[wave] = cnt;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        double s = 0.0, c = 0.0;
-        for (int w = 0; w < 4; ++w) {
-          s += sm_sum[w];
-          c += sm_cnt[w];
-        }
-        out[n * out_stride + j * Q + k] =
-            (kind == FR_SIEVE_NPI_K) ? c : (c > 0.0 ? s / c : 0.0);
-      }
-    }
-  }
-}
-
-// IncrementSieve._pre_transform (inc >= 0) materialised: out[n,t] = D_inc[n,t]
-__global__ void pre_transform_kernel(const double *__restrict__ A, int64_t N, int64_t T,
-                                     int64_t a_stride, int inc, double *__restrict__ out) {
-  const int64_t total = N * T;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t n = i / T, t = i % T;
-    out[i] = diff_at(A + n * a_stride, t, inc);
-  }
-}
-
-// STD preparateur, separately=True (fruits/preparation/transform.py:141-147):
-// per (series, dimension) row: (x - mean) / (std + eps), std = population std
-// (np.std), or 1 when var=False.
-__device__ __forceinline__ double block_reduce_sum(double v, double *sm) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  __syncthreads();
-  if (lane == 0) sm[wave] = v;
-  __syncthreads();
-  double r = 0.0;
-  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += sm[w];
-  return r;
-}
-
-__global__ __launch_bounds__(256) void standardize_kernel(const double *__restrict__ X, int64_t T,
-                                                           int div_std, double eps,
-                                                           double *__restrict__ out) {
-  __shared__ double sm[4];
-  const double *x = X + (int64_t)blockIdx.x * T;
-  double *o = out + (int64_t)blockIdx.x * T;
-  double acc = 0.0;
-  for (int64_t t = threadIdx.x; t < T; t += blockDim.x) acc += x[t];
-  const double mean = block_reduce_sum(acc, sm) / (double)T;
-  double sd = 1.0;
-  if (div_std) {
-    double v = 0.0;
-    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
-      const double d = x[t] - mean;
-      v += d * d;
-    }
-    sd = sqrt(block_reduce_sum(v, sm) / (double)T);
-  }
-  const double den = sd + eps;
-  for (int64_t t = threadIdx.x; t < T; t += blockDim.x) o[t] = (x[t] - mean) / den;
-}
-
-// ---------------------------------------------------------------- launchers
+// ---------------------------------------------------------------- launch
 static int device_cu_count() {
   static int cus = 0;
   if (cus == 0) {
@@ -818,9 +603,9 @@ static int device_cu_count() {
   return cus;
 }
 
-template <int E, int P, int LV, bool MULTI, bool VEC, bool W, int TEAM = 4>
+template <int E, int P, int LV, bool MULTI, bool VEC, bool W, int TEAM = 4, int MODE = 0>
 static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
-  using C = WalkCfg<E, P, LV, MULTI, VEC, W, TEAM>;
+  using C = WalkCfg<E, P, LV, MULTI, VEC, W, TEAM, MODE>;
   const size_t lds = ((size_t)a.R * C::CHUNK + 2 * C::NW) * sizeof(double);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static size_t lds_attr = 0;  // per instantiation
@@ -851,118 +636,6 @@ static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
   }
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(iss_walk_kernel<C>, dim3((unsigned)blocks), dim3(kWalkThreads), lds, st, a);
-  return hipGetLastError();
-}
-
-template <int E, int P, int LV, bool MULTI, bool VEC>
-static hipError_t launch_walk_w(const IssArgs &a, hipStream_t st) {
-  return a.aux ? launch_walk_cfg<E, P, LV, MULTI, VEC, true>(a, st)
-               : launch_walk_cfg<E, P, LV, MULTI, VEC, false>(a, st);
-}
-
-template <int E, int P, bool MULTI, bool VEC>
-static hipError_t launch_walk_lv(const IssArgs &a, int levels, hipStream_t st) {
-  if (levels <= 2) return launch_walk_w<E, P, 2, MULTI, VEC>(a, st);
-  if (levels <= 4) return launch_walk_w<E, P, 4, MULTI, VEC>(a, st);
-  if (levels <= 8) return launch_walk_w<E, P, 8, MULTI, VEC>(a, st);
-  return launch_walk_w<E, P, kMaxLevels, MULTI, VEC>(a, st);
-}
-
-template <int E, int P>
-static hipError_t launch_walk_ep(const IssArgs &a, int levels, hipStream_t st) {
-  const bool multi = a.nchunks > 1;
-  if (multi && a.carry == nullptr) return hipErrorInvalidValue;
-  if (multi)
-    return a.vec_ok ? launch_walk_lv<E, P, true, true>(a, levels, st)
-                    : launch_walk_lv<E, P, true, false>(a, levels, st);
-  return a.vec_ok ? launch_walk_lv<E, P, false, true>(a, levels, st)
-                  : launch_walk_lv<E, P, false, false>(a, levels, st);
-}
-
-int walk_chunk_elems(int64_t T) { return T <= 512 ? 512 : 1024; }
-
-// wave-per-row variant (TEAM = 1): single chunk, aligned 16-byte accesses,
-// shallow tries (register frames of 2 * E * P VGPRs per level)
-bool wave_rows_supported(int64_t T, int levels, bool vec_ok) {
-  return vec_ok && T <= 1024 && levels <= 4;
-}
-
-template <int P>
-static hipError_t launch_wave_rows(const IssArgs &a, int levels, hipStream_t st) {
-  if (levels <= 2)
-    return a.aux ? launch_walk_cfg<2, P, 2, false, true, true, 1>(a, st)
-                 : launch_walk_cfg<2, P, 2, false, true, false, 1>(a, st);
-  return a.aux ? launch_walk_cfg<2, P, 4, false, true, true, 1>(a, st)
-               : launch_walk_cfg<2, P, 4, false, true, false, 1>(a, st);
-}
-
-hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st) {
-  const int chunk = walk_chunk_elems(a.T);
-  a.nchunks = (int32_t)((a.T + chunk - 1) / chunk);
-  if (a.N * a.G <= 0) return hipSuccess;
-  if (a.wave_rows) {
-    if (a.G != 4 || !wave_rows_supported(a.T, levels, a.vec_ok != 0)) return hipErrorInvalidValue;
-    return chunk == 512 ? launch_wave_rows<4>(a, levels, st) : launch_wave_rows<8>(a, levels, st);
-  }
-  if (chunk == 512) return launch_walk_ep<2, 1>(a, levels, st);
-  return launch_walk_ep<2, 2>(a, levels, st);
-}
-
-hipError_t launch_exp_tables(const double *g, int64_t count, const float *alphas, int n_alpha,
-                             double *aux, hipStream_t st) {
-  if (count <= 0 || n_alpha <= 0) return hipSuccess;
-  const int bs = 256;
-  hipLaunchKernelGGL(exp_tables_kernel, dim3((unsigned)((count + bs - 1) / bs)), dim3(bs), 0, st,
-                     g, count, alphas, n_alpha, aux);
-  return hipGetLastError();
-}
-
-hipError_t launch_increments(const double *X, int64_t rows, int64_t T, int64_t shift, double *out,
-                             const double *head_src, int64_t head, hipStream_t st) {
-  const int64_t total = rows * T;
-  if (total <= 0) return hipSuccess;
-  const int bs = 256;
-  int64_t blocks = (total + bs - 1) / bs;
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(increments_kernel, dim3((unsigned)blocks), dim3(bs), 0, st, X, rows, T,
-                     shift, out, head_src, head);
-  return hipGetLastError();
-}
-
-hipError_t launch_pathlen_lookup(const double *X, int64_t N, int64_t D, int64_t T, int norm,
-                                 int relative, double scale, double *out, hipStream_t st) {
-  if (N <= 0 || T <= 0) return hipSuccess;
-  hipLaunchKernelGGL(pathlen_lookup_kernel, dim3((unsigned)N), dim3(256), 0, st, X, D, T, norm,
-                     relative, scale, out);
-  return hipGetLastError();
-}
-
-hipError_t launch_sieve(int kind, const double *A, int64_t N, int64_t T, int64_t a_stride, int inc,
-                        const int64_t *cuts, int64_t cut_rows, int C1, const double *q, int Q1,
-                        double *out, int64_t out_stride, hipStream_t st) {
-  if (N <= 0) return hipSuccess;
-  hipLaunchKernelGGL(sieve_kernel, dim3((unsigned)N), dim3(256), 0, st, kind, A, T, a_stride, inc,
-                     cuts, cut_rows, C1, q, Q1, out, out_stride);
-  return hipGetLastError();
-}
-
-hipError_t launch_pre_transform(const double *A, int64_t N, int64_t T, int64_t a_stride, int inc,
-                                double *out, hipStream_t st) {
-  const int64_t total = N * T;
-  if (total <= 0) return hipSuccess;
-  const int bs = 256;
-  int64_t blocks = (total + bs - 1) / bs;
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(pre_transform_kernel, dim3((unsigned)blocks), dim3(bs), 0, st, A, N, T,
-                     a_stride, inc, out);
-  return hipGetLastError();
-}
-
-hipError_t launch_standardize(const double *X, int64_t rows, int64_t T, int div_std, double eps,
-                              double *out, hipStream_t st) {
-  if (rows <= 0 || T <= 0) return hipSuccess;
-  hipLaunchKernelGGL(standardize_kernel, dim3((unsigned)rows), dim3(256), 0, st, X, T, div_std,
-                     eps, out);
   return hipGetLastError();
 }
 

@@ -1,0 +1,46 @@
+// One translation unit per (WALK_MODE, WALK_LV) [or WALK_TEAM1]: the walk kernel has
+// many template variants; compiling them in separate objects lets the build run in
+// parallel (fruits_amd/build.py).
+#include "walk.h"
+
+namespace fr {
+
+#ifdef WALK_TEAM1
+// wave-per-row variant: single chunk, aligned accesses, shallow tries
+template <int P>
+static hipError_t team1_p(const IssArgs &a, int levels, hipStream_t st) {
+  if (levels <= 2)
+    return a.aux ? launch_walk_cfg<2, P, 2, false, true, true, 1>(a, st)
+                 : launch_walk_cfg<2, P, 2, false, true, false, 1>(a, st);
+  return a.aux ? launch_walk_cfg<2, P, 4, false, true, true, 1>(a, st)
+               : launch_walk_cfg<2, P, 4, false, true, false, 1>(a, st);
+}
+hipError_t walk_inst_team1(const IssArgs &a, int levels, int chunk, hipStream_t st) {
+  return chunk == 512 ? team1_p<4>(a, levels, st) : team1_p<8>(a, levels, st);
+}
+#else
+template <int P, bool MULTI, bool VEC>
+static hipError_t inst_w(const IssArgs &a, hipStream_t st) {
+  return a.aux ? launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, true, 4, WALK_MODE>(a, st)
+               : launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, false, 4, WALK_MODE>(a, st);
+}
+template <int P>
+static hipError_t inst_p(const IssArgs &a, hipStream_t st) {
+  const bool multi = a.nchunks > 1;
+#if WALK_MODE == 1
+  // no tensor stores in fused mode: the VEC template parameter is irrelevant
+  return multi ? inst_w<P, true, true>(a, st) : inst_w<P, false, true>(a, st);
+#else
+  if (multi) return a.vec_ok ? inst_w<P, true, true>(a, st) : inst_w<P, true, false>(a, st);
+  return a.vec_ok ? inst_w<P, false, true>(a, st) : inst_w<P, false, false>(a, st);
+#endif
+}
+#define WALK_CAT2(a, b, c, d) a##b##c##d
+#define WALK_CAT(a, b, c, d) WALK_CAT2(a, b, c, d)
+hipError_t WALK_CAT(walk_inst_m, WALK_MODE, _l, WALK_LV)(const IssArgs &a, int chunk,
+                                                          hipStream_t st) {
+  return chunk == 512 ? inst_p<1>(a, st) : inst_p<2>(a, st);
+}
+#endif
+
+}  // namespace fr

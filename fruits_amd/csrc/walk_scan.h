@@ -1,0 +1,84 @@
+// Wave64 DPP scan primitives and small device helpers shared by the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace fr {
+
+typedef double vd2 __attribute__((ext_vector_type(2)));
+
+// The program tables are read-only for the whole launch.  Reading them through
+// the constant address space makes every (wave-uniform) access a scalar load
+// (s_load, counted by lgkmcnt).  As plain global loads they would be VECTOR loads
+// counted by vmcnt, and waiting for one of those also waits for every output
+// store issued before it - serialising the store stream node by node.
+template <class T>
+using cptr = const T __attribute__((address_space(4))) *;
+template <class T>
+__device__ __forceinline__ cptr<T> as_const(const T *p) {
+  return (cptr<T>)(p);
+}
+
+// ---------------------------------------------------------------- wave scan
+// DPP fetch of a double: the value of the source lane, 0.0 where the lane has no
+// source.  FULL = all rows enabled: bound_ctrl supplies the zeros and no "old"
+// value has to be materialised; otherwise disabled rows keep old = 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_fetch(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  if constexpr (ROW_MASK == 0xf) {
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  } else {
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  }
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_inclusive_scan(double v) {
+  v += dpp_fetch<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_fetch<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_fetch<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_fetch<0x118, 0xf>(v);  // row_shr:8
+  v += dpp_fetch<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+  v += dpp_fetch<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
+  return v;
+}
+
+// P independent scans, advanced step by step so their DPP latencies overlap
+template <int P>
+__device__ __forceinline__ void wave_inclusive_scan_multi(double (&v)[P]) {
+#pragma unroll
+  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x111, 0xf>(v[h]);
+#pragma unroll
+  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x112, 0xf>(v[h]);
+#pragma unroll
+  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x114, 0xf>(v[h]);
+#pragma unroll
+  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x118, 0xf>(v[h]);
+#pragma unroll
+  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x142, 0xa>(v[h]);
+#pragma unroll
+  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x143, 0xc>(v[h]);
+}
+
+__device__ __forceinline__ double wave_shift_right1(double v) {
+  return dpp_fetch<0x138, 0xf>(v);  // wave_shr:1, lane 0 gets 0.0
+}
+
+__device__ __forceinline__ double wave_last_lane(double v) {
+  // lane 63's value as a wave-uniform (scalar) double
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for
+// vmcnt(0), i.e. for the acknowledgement of every global store the wave has in
+// flight - that would serialise each node's output stores with the next node's
+// scan.  Waiting for lgkmcnt(0) alone keeps the stores streaming.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+}  // namespace fr

@@ -11,6 +11,7 @@ straight into the ``(N, F)`` feature tensor, and only that tensor travels back.
 from __future__ import annotations
 
 import inspect
+import os
 from typing import Callable, Generator, Literal, Optional, Union
 
 import numpy as np
@@ -311,6 +312,55 @@ class FruitSlice:
                 else:
                     yield from self._iterate_iss_device(block[k].unsqueeze(1), iss_index + 1)
 
+    # ---- fused ISS + sieves (one launch, no (K, N, T) tensor) --------------------
+    def _fusable(self) -> bool:
+        from .sieving.increment import MPI, NPI
+        from .sieving.segment import END
+        if os.environ.get("FRUITS_AMD_FUSED", "1") == "0" or len(self._iss) != 1:
+            return False
+        for sv in self._sieves:
+            if type(sv) not in (NPI, MPI, END) or sv._has_float_cuts():
+                return False
+            if type(sv) is not END and sv._inc not in (0, 1):
+                return False
+        return True
+
+    def _fused(self, T: int):
+        """(pipeline, quantile table) for series length T, or None when a sieve or
+        the weighting is outside the fused set; cached until the next fit."""
+        if not hasattr(self, "_fused_cache"):
+            self._fused_cache = {}
+        if T in self._fused_cache:
+            return self._fused_cache[T]
+        entry = None
+        if self._fusable():
+            from .sieving.segment import END
+            iss = self._iss[0]
+            iss._check_supported()
+            plan = iss._plan(0, len(iss.words))
+            specs = [(sv._kind, 0 if type(sv) is END else sv._inc, sv._int_cut_row(T),
+                      len(sv._q)) for sv in self._sieves]
+            try:
+                pipe = nat.Pipeline(plan, specs, T)
+            except ValueError:
+                pipe = None
+            if pipe is not None:
+                K = plan.rows
+                quant = np.zeros((K, pipe.q_stride))
+                for k in range(K):
+                    sieves = self._sieves_extended[k] if self._sieves_extended else self._sieves
+                    off = 0
+                    for sv in sieves:
+                        if type(sv) is END:
+                            continue
+                        if not sv.requires_fitting:
+                            sv._get_unfitted_quantiles()
+                        quant[k, off:off + len(sv._q)] = sv._quantiles
+                        off += len(sv._q)
+                entry = (pipe, nat.to_device(quant))
+        self._fused_cache[T] = entry
+        return entry
+
     def _attach(self, cache) -> None:
         for iss in self._iss:
             iss._cache = cache
@@ -319,6 +369,7 @@ class FruitSlice:
     # ---- fit / transform ----------------------------------------------------
     def fit(self, X: np.ndarray, cache: Optional[SharedSeedCache] = None) -> None:
         self._compile()
+        self._fused_cache = {}
         X = _check_batch(X)
         if cache is None:
             cache = SharedSeedCache(X)
@@ -358,8 +409,13 @@ class FruitSlice:
         Pd = self._prepare_device(Xd, cache, callbacks)
         for cb in callbacks:
             cb.on_preparation_end(nat.to_host(Pd))
-        feats = t.zeros((X.shape[0], self.nfeatures()), dtype=t.float64, device=Pd.device)
         self._attach(cache)
+        fused = None if callbacks else self._fused(int(Pd.shape[2]))
+        if fused is not None:
+            pipe, quant_d = fused
+            feats = pipe.run(Pd, self._iss[0].lookup_device(Pd), quant_d)
+            return nat.to_host(feats)
+        feats = t.zeros((X.shape[0], self.nfeatures()), dtype=t.float64, device=Pd.device)
         col = 0
         for i, itsum in enumerate(self._iterate_iss_device(Pd)):
             for cb in callbacks:

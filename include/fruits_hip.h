@@ -61,6 +61,7 @@ extern "C" {
 #define FR_SIEVE_END 2 /* fruits/sieving/segment.py:203-225   */
 
 typedef struct fr_plan fr_plan_t;
+typedef struct fr_pipeline fr_pipeline_t;
 
 /* ------------------------------------------------------------------ misc */
 const char *fr_last_error(void);
@@ -175,6 +176,37 @@ int fr_sieve(int32_t kind, const double *d_A, int64_t N, int64_t T, int64_t a_st
              int32_t inc, const int64_t *d_cuts, int64_t cut_rows, int32_t C1,
              const double *d_q, int32_t Q1, double *d_out, int64_t out_stride,
              void *stream);
+
+/* ------------------------------------------------------------------ fused pipeline
+ * ISS + sieves in ONE launch: replaces the loop of FruitSlice.transform
+ * (fruits/fruit.py:538-550) - for every iterated sum, for every sieve,
+ * sieve.transform(itsum) - without ever materialising the (K, N, T) tensor.
+ * Sieves: NPI / MPI with inc in {0, 1} and END, integer cuts (the same for all
+ * series).  Feature (n, k*per_sum + col_s + j*(Q1_s-1) + q) is the reference's
+ * column order (iterated sum, then sieve, then segment, then band).
+ *
+ *   kinds/incs/C1/Q1   per sieve; Q1 is ignored for END
+ *   cuts               concatenated transformed cut rows (C1[s] values each: sorted,
+ *                      leading 0, negative cuts already resolved for length T -
+ *                      fruits/sieving/segment.py:51-64)
+ *   d_quant            (K, q_stride) thresholds of every iterated sum (the fitted
+ *                      sieve copies of fruit.py:484-496), q_stride =
+ *                      fr_pipeline_info(p, 1) = sum of Q1 over the NPI/MPI sieves
+ *   d_feats            (N, feat_stride >= F) output, F = fr_pipeline_info(p, 2)
+ * Returns FR_E_LIMIT from create when a sieve is outside the fused set (the caller
+ * then uses fr_iss_run + fr_sieve).  fr_pipeline_info: 0 features per iterated sum,
+ * 1 q_stride, 2 total features. */
+fr_pipeline_t *fr_pipeline_create(fr_plan_t *plan, int32_t n_sieves, const int32_t *kinds,
+                                  const int32_t *incs, const int32_t *C1, const int32_t *Q1,
+                                  const int64_t *cuts, int64_t T);
+void fr_pipeline_destroy(fr_pipeline_t *pipeline);
+int64_t fr_pipeline_info(const fr_pipeline_t *pipeline, int32_t what);
+int64_t fr_pipeline_workspace_bytes(const fr_pipeline_t *pipeline, int64_t N,
+                                    int64_t lookup_rows);
+int fr_pipeline_run(fr_pipeline_t *pipeline, const double *d_X, int64_t N, int64_t D, int64_t T,
+                    const double *d_lookup, int64_t lookup_rows, const double *d_quant,
+                    double *d_feats, int64_t feat_stride, void *d_work, int64_t work_bytes,
+                    int32_t groups, void *stream);
 
 /* IncrementSieve._pre_transform alone (fruits/sieving/increment.py:63-71, inc >= 0),
  * materialised: d_out (N, T) contiguous.  Used by fit, which needs the values for

@@ -262,10 +262,13 @@ def build_fruit(fr, spec):
     return fruit
 
 
-def compare_features(got, ref, labels, rtol=RTOL):
+def compare_features(got, ref, labels, rtol=RTOL, count_frac=0.01):
     """Value features to rtol; counting features (NPI) may differ by one count
     on a rare series because a re-associated scan can move an increment across a
-    quantile threshold: <= 1 count on <= 1 % of entries."""
+    quantile threshold: <= 1 count on <= 1 % of entries.
+    (A fitted quantile of an odd-sized sample IS one of the data points, so that
+    point sits exactly on the threshold in the reference: one flip per iterated
+    sum is then legitimate - callers with such samples pass a larger fraction.)"""
     assert got.shape == ref.shape
     is_count = np.array(["NPI" in lb for lb in labels])
     val = ~is_count
@@ -276,7 +279,7 @@ def compare_features(got, ref, labels, rtol=RTOL):
     if is_count.any():
         d = np.abs(got[:, is_count] - ref[:, is_count])
         assert d.max() <= 1
-        assert (d > 0).mean() <= 0.01
+        assert (d > 0).mean() <= count_frac
 
 
 @pytest.mark.parametrize("case", G.cases("fruit"), ids=lambda c: c["name"])
@@ -351,3 +354,46 @@ def test_word_sharded_blocks_reassemble(fr, world):
     np.testing.assert_array_equal(np.nan_to_num(out), ref)
     if world == 1:
         np.testing.assert_array_equal(par.transform_sharded(fruit, X, rank=0, world=1), ref)
+
+
+@pytest.mark.parametrize("name", ["readme", "cfg3_small", "cfg3_small_unweighted", "twi_small",
+                                  "twi_small_hot", "x1_two_slices_end"])
+def test_fused_matches_materialised(fr, name, monkeypatch):
+    """The fused ISS+sieve launch against the materialising path (fr_iss_run +
+    fr_sieve per iterated sum): END and inc=0 features are bit-identical, inc=1
+    counts may differ by one where a lane boundary rounds differently."""
+    case = [c for c in G.cases("fruit") if c["name"] == name][0]
+    X = G[case["x"]]
+    fruit = build_fruit(fr, case["spec"])
+    np.random.seed(case["np_seed"])
+    fruit.fit(X)
+    assert any(s._fused(X.shape[2]) is not None for s in fruit._slices)
+    fused = fruit.transform(X)
+    monkeypatch.setenv("FRUITS_AMD_FUSED", "0")
+    for s in fruit._slices:
+        s._fused_cache = {}
+    plain = fruit.transform(X)
+    labels = case["labels"]
+    end = np.array(["END" in lb for lb in labels])
+    np.testing.assert_array_equal(fused[:, end], plain[:, end])
+    compare_features(fused, plain, labels)
+
+
+@pytest.mark.parametrize("T", [7, 64, 511, 1024, 1500, 3000])
+def test_fused_ragged_and_multichunk(fr, T):
+    rng = np.random.default_rng(T)
+    X = rng.standard_normal((5, 2, T))
+    spec = {"slices": [{"preps": [{"kind": "INC"}],
+                        "iss": [{"words": G.manifest["words"]["3,2"]["words"], "mode": "EXTENDED"}],
+                        "sieves": [{"kind": "NPI", "q": [0.5, 1.0]}, {"kind": "NPI", "inc": 0},
+                                   {"kind": "MPI", "cut": [T // 2, -1]}, {"kind": "END", "cut": [1, -1]}],
+                        "fit_sample_size": 1.0}]}
+    fruit = build_fruit(fr, spec)
+    np.random.seed(3)
+    fruit.fit(X)
+    assert fruit._slices[0]._fused(T) is not None
+    got = fruit.transform(X)
+    np.random.seed(3)
+    ref = orc.fruit_transform(spec, orc.fruit_fit(spec, X), X)
+    labels = [fruit.label(i) for i in range(fruit.nfeatures())]
+    compare_features(got, ref, labels, count_frac=0.05)
