@@ -30,7 +30,7 @@ EXPORTS = [
     "fr_iss_run", "fr_iterated_sum_fast_host", "fr_increments",
     "fr_pathlen_lookup", "fr_sieve", "fr_pre_transform", "fr_standardize",
     "fr_pipeline_create", "fr_pipeline_destroy", "fr_pipeline_info",
-    "fr_pipeline_workspace_bytes", "fr_pipeline_run",
+    "fr_pipeline_workspace_bytes", "fr_pipeline_run", "fr_pipeline_set_quantiles",
 ]
 
 _lib = None
@@ -295,7 +295,16 @@ class Pipeline:
         except Exception:
             pass
 
-    def run(self, Xd, lookup_d, quant_d, feats=None, groups: int = 0, work=None):
+    def set_quantiles(self, quant: np.ndarray) -> None:
+        """``quant`` (K, q_stride) host array: the sorted thresholds of every
+        iterated sum's band sieves, in sieve order."""
+        q = np.ascontiguousarray(quant, dtype=np.float64)
+        if q.shape != (self.plan.rows, self.q_stride):
+            raise ValueError("quantile table must be (K, q_stride)")
+        check(lib().fr_pipeline_set_quantiles(self._h, q.ctypes.data_as(C.POINTER(C.c_double))),
+              "fr_pipeline_set_quantiles")
+
+    def run(self, Xd, lookup_d, feats=None, groups: int = 0, work=None):
         t = torch()
         if Xd.dtype != t.float64 or Xd.dim() != 3 or not Xd.is_contiguous():
             raise TypeError("X must be a contiguous float64 (N, D, T) device tensor")
@@ -313,7 +322,7 @@ class Pipeline:
         rc = lib().fr_pipeline_run(
             self._h, dptr(Xd), C.c_int64(N), C.c_int64(D), C.c_int64(T),
             dptr(lookup_d if self.plan.weighting != FR_W_NONE else None), C.c_int64(rows),
-            dptr(quant_d), dptr(feats), C.c_int64(feats.stride(0)), dptr(work),
+            dptr(feats), C.c_int64(feats.stride(0)), dptr(work),
             C.c_int64(work.numel() if work is not None else 0), C.c_int32(groups), stream_ptr())
         check(rc, "fr_pipeline_run")
         return feats

@@ -235,12 +235,10 @@ int64_t fr_plan_workspace_bytes(const fr_plan_t *plan, int64_t N, int64_t T, int
 namespace {
 
 struct FusedArgs {          // non-null feats selects the fused sieve kernels
-  const fr::SieveDesc *sieves = nullptr;
-  const int32_t *cuts = nullptr;
-  const double *quant = nullptr;
+  const fr::FeatOp *ops = nullptr;
   double *feats = nullptr, *cnt = nullptr;
   int64_t feat_stride = 0;
-  int32_t n_sieves = 0, q_stride = 0, per_sum = 0;
+  int32_t n_ops = 0, n_ops_padded = 0;
 };
 
 // Shared body of fr_iss_run and fr_pipeline_run: validates, lays out the
@@ -319,15 +317,12 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   a.persistent = env_int("FRUITS_HIP_PERSIST", 1);
   a.wave_rows = wave_rows ? 1 : 0;
   if (fu) {
-    a.sieves = fu->sieves;
-    a.cuts = fu->cuts;
-    a.quant = fu->quant;
+    a.ops = fu->ops;
     a.feats = fu->feats;
     a.cnt = fu->cnt;
     a.feat_stride = fu->feat_stride;
-    a.n_sieves = fu->n_sieves;
-    a.q_stride = fu->q_stride;
-    a.per_sum = fu->per_sum;
+    a.n_ops = fu->n_ops;
+    a.n_ops_padded = fu->n_ops_padded;
   }
   hipError_t e = fr::launch_iss_walk(a, p.levels, st);
   if (e != hipSuccess) return hip_fail(e, "iss_walk launch");
@@ -336,15 +331,20 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
 
 }  // namespace
 
+struct PipeSieve {
+  int32_t kind, inc, Q1, col, q_off;
+  std::vector<int32_t> cuts;   // transformed, clamped to [0, T]
+};
+
 struct fr_pipeline {
   fr_plan_t *plan = nullptr;
   int64_t T = 0;
-  int32_t n_sieves = 0, per_sum = 0, q_stride = 0;
-  std::vector<int32_t> mpi_cols;
-  void *d_blob = nullptr;
-  const fr::SieveDesc *d_sieves = nullptr;
-  const int32_t *d_cuts = nullptr;
-  const int32_t *d_mpi_cols = nullptr;
+  int32_t per_sum = 0, q_stride = 0, n_ops = 0, n_ops_padded = 0;
+  std::vector<PipeSieve> sieves;
+  std::vector<int32_t> mpi_cols;   // columns inside one iterated sum's block
+  void *d_ops = nullptr;           // (K, n_ops_padded) FeatOp
+  void *d_mpi_cols = nullptr;
+  bool have_quantiles = false;
 };
 
 extern "C" {
@@ -366,83 +366,59 @@ fr_pipeline_t *fr_pipeline_create(fr_plan_t *plan, int32_t n_sieves, const int32
     fail(FR_E_ARG, "fr_pipeline_create: bad argument");
     return nullptr;
   }
-  std::vector<fr::SieveDesc> descs(n_sieves);
-  std::vector<int32_t> cut32, mpi_cols;
-  int32_t col = 0, qoff = 0;
-  for (int i = 0; i < n_sieves; ++i) {
-    fr::SieveDesc &d = descs[i];
-    d = fr::SieveDesc{};
-    d.kind = kinds[i];
-    d.inc = incs[i];
-    d.C1 = C1[i];
-    d.Q1 = Q1[i];
-    if (d.kind < 0 || d.kind > 2 || d.C1 < 2) {
-      fail(FR_E_ARG, "fr_pipeline_create: bad sieve " + std::to_string(i));
-      return nullptr;
-    }
-    if (d.kind != FR_SIEVE_END) {
-      if (d.Q1 < 2) {
-        fail(FR_E_ARG, "fr_pipeline_create: a band sieve needs >= 2 thresholds");
-        return nullptr;
-      }
-      if (d.inc < 0 || d.inc > 1) {
-        fail(FR_E_LIMIT, "fr_pipeline_create: the fused epilogue supports inc 0 and 1 only");
-        return nullptr;
-      }
-      if (d.inc == 1 && plan->p->weighting == FR_W_TOTAL) {
-        fail(FR_E_LIMIT, "fr_pipeline_create: increments of totally weighted sums are not fused");
-        return nullptr;
-      }
-    }
-    d.col = col;
-    d.cut_off = (int32_t)cut32.size();
-    for (int j = 0; j < d.C1; ++j) {
-      int64_t c = *cuts++;
-      cut32.push_back((int32_t)(c < 0 ? 0 : (c > T ? T : c)));
-    }
-    const int nf = d.kind == FR_SIEVE_END ? d.C1 - 1 : (d.C1 - 1) * (d.Q1 - 1);
-    if (d.kind == FR_SIEVE_MPI)
-      for (int f = 0; f < nf; ++f) mpi_cols.push_back(col + f);
-    if (d.kind != FR_SIEVE_END) {
-      d.q_off = qoff;
-      qoff += d.Q1;
-    }
-    col += nf;
-  }
   fr_pipeline_t *pl = new fr_pipeline_t;
   pl->plan = plan;
   pl->T = T;
-  pl->n_sieves = n_sieves;
+  int32_t col = 0, qoff = 0, n_ops = 0;
+  for (int i = 0; i < n_sieves; ++i) {
+    PipeSieve sv;
+    sv.kind = kinds[i];
+    sv.inc = incs[i];
+    sv.Q1 = Q1[i];
+    const int c1 = C1[i];
+    std::string bad;
+    if (sv.kind < 0 || sv.kind > 2 || c1 < 2) bad = "bad sieve " + std::to_string(i);
+    int code = FR_E_ARG;
+    if (bad.empty() && sv.kind != FR_SIEVE_END) {
+      if (sv.Q1 < 2) bad = "a band sieve needs >= 2 thresholds";
+      else if (sv.inc < 0 || sv.inc > 1) {
+        bad = "the fused epilogue supports inc 0 and 1 only";
+        code = FR_E_LIMIT;
+      } else if (sv.inc == 1 && plan->p->weighting == FR_W_TOTAL) {
+        bad = "increments of totally weighted sums are not fused";
+        code = FR_E_LIMIT;
+      }
+    }
+    if (!bad.empty()) {
+      fail(code, "fr_pipeline_create: " + bad);
+      delete pl;
+      return nullptr;
+    }
+    for (int j = 0; j < c1; ++j) {
+      const int64_t c = *cuts++;
+      sv.cuts.push_back((int32_t)(c < 0 ? 0 : (c > T ? T : c)));
+    }
+    const int nf = sv.kind == FR_SIEVE_END ? c1 - 1 : (c1 - 1) * (sv.Q1 - 1);
+    sv.col = col;
+    sv.q_off = qoff;
+    if (sv.kind == FR_SIEVE_MPI)
+      for (int f = 0; f < nf; ++f) pl->mpi_cols.push_back(col + f);
+    if (sv.kind != FR_SIEVE_END) qoff += sv.Q1;
+    col += nf;
+    n_ops += nf;
+    pl->sieves.push_back(sv);
+  }
   pl->per_sum = col;
   pl->q_stride = qoff > 0 ? qoff : 1;
-  pl->mpi_cols = mpi_cols;
-  const size_t o_s = 0, o_c = align_up(descs.size() * sizeof(fr::SieveDesc), 64);
-  const size_t o_m = o_c + align_up(cut32.size() * 4, 64);
-  const size_t total = o_m + align_up(mpi_cols.size() * 4 + 4, 64);
-  std::vector<char> host(total, 0);
-  std::memcpy(host.data() + o_s, descs.data(), descs.size() * sizeof(fr::SieveDesc));
-  std::memcpy(host.data() + o_c, cut32.data(), cut32.size() * 4);
-  if (!mpi_cols.empty()) std::memcpy(host.data() + o_m, mpi_cols.data(), mpi_cols.size() * 4);
-  void *d = nullptr;
-  hipError_t e = hipMalloc(&d, total);
-  if (e == hipSuccess) e = hipMemcpy(d, host.data(), total, hipMemcpyHostToDevice);
-  if (e != hipSuccess) {
-    if (d) (void)hipFree(d);
-    hip_fail(e, "fr_pipeline_create upload");
-    delete pl;
-    return nullptr;
-  }
-  char *b = static_cast<char *>(d);
-  pl->d_blob = d;
-  pl->d_sieves = reinterpret_cast<const fr::SieveDesc *>(b + o_s);
-  pl->d_cuts = reinterpret_cast<const int32_t *>(b + o_c);
-  pl->d_mpi_cols = reinterpret_cast<const int32_t *>(b + o_m);
+  pl->n_ops = n_ops;
+  pl->n_ops_padded = (n_ops + 1) / 2 * 2;
   return pl;
 }
 
 void fr_pipeline_destroy(fr_pipeline_t *pl) {
   if (!pl) return;
-  if (pl->d_blob) (void)hipFree(pl->d_blob);
+  if (pl->d_ops) (void)hipFree(pl->d_ops);
+  if (pl->d_mpi_cols) (void)hipFree(pl->d_mpi_cols);
   delete pl;
 }
 
@@ -456,6 +432,46 @@ int64_t fr_pipeline_info(const fr_pipeline_t *pl, int32_t what) {
   }
 }
 
+int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
+  if (!pl || !h_quant) return fail(FR_E_ARG, "fr_pipeline_set_quantiles: bad argument");
+  const fr::Plan &p = *pl->plan->p;
+  const int K = p.K;
+  std::vector<fr::FeatOp> ops((size_t)K * pl->n_ops_padded);
+  for (int k = 0; k < K; ++k) {
+    fr::FeatOp *o = ops.data() + (size_t)k * pl->n_ops_padded;
+    int i = 0;
+    for (const PipeSieve &sv : pl->sieves) {
+      const int C = (int)sv.cuts.size() - 1;
+      if (sv.kind == FR_SIEVE_END) {
+        for (int j = 0; j < C; ++j, ++i) {
+          int idx = sv.cuts[j + 1] - 1;
+          if (idx < 0) idx += (int)pl->T;  // numpy's wrap of index -1 (segment.py:213-218)
+          o[i] = fr::FeatOp{FR_SIEVE_END, k * pl->per_sum + sv.col + j, idx, 0, 0.0, 0.0};
+        }
+        continue;
+      }
+      const double *q = h_quant + (size_t)k * pl->q_stride + sv.q_off;
+      for (int j = 0; j < C; ++j)
+        for (int b = 0; b + 1 < sv.Q1; ++b, ++i)
+          o[i] = fr::FeatOp{sv.kind | (sv.inc << 8),
+                            k * pl->per_sum + sv.col + j * (sv.Q1 - 1) + b, sv.cuts[j],
+                            sv.cuts[j + 1], q[b], q[b + 1]};
+    }
+    for (; i < pl->n_ops_padded; ++i)  // padding op: an END that never matches a chunk
+      o[i] = fr::FeatOp{FR_SIEVE_END, 0, -(1 << 30), 0, 0.0, 0.0};
+  }
+  const size_t bytes = ops.size() * sizeof(fr::FeatOp);
+  if (!pl->d_ops && bytes) HIP_TRY(hipMalloc(&pl->d_ops, bytes));
+  if (bytes) HIP_TRY(hipMemcpy(pl->d_ops, ops.data(), bytes, hipMemcpyHostToDevice));
+  if (!pl->mpi_cols.empty() && !pl->d_mpi_cols) {
+    HIP_TRY(hipMalloc(&pl->d_mpi_cols, pl->mpi_cols.size() * 4));
+    HIP_TRY(hipMemcpy(pl->d_mpi_cols, pl->mpi_cols.data(), pl->mpi_cols.size() * 4,
+                      hipMemcpyHostToDevice));
+  }
+  pl->have_quantiles = true;
+  return FR_OK;
+}
+
 int64_t fr_pipeline_workspace_bytes(const fr_pipeline_t *pl, int64_t N, int64_t lookup_rows) {
   if (!pl || N < 0) return fail(FR_E_ARG, "fr_pipeline_workspace_bytes: bad argument");
   const fr::Plan &p = *pl->plan->p;
@@ -465,16 +481,17 @@ int64_t fr_pipeline_workspace_bytes(const fr_pipeline_t *pl, int64_t N, int64_t 
 }
 
 int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, int64_t T,
-                    const double *d_lookup, int64_t lookup_rows, const double *d_quant,
-                    double *d_feats, int64_t feat_stride, void *d_work, int64_t work_bytes,
-                    int32_t groups, void *stream) {
+                    const double *d_lookup, int64_t lookup_rows, double *d_feats,
+                    int64_t feat_stride, void *d_work, int64_t work_bytes, int32_t groups,
+                    void *stream) {
   if (!pl || !pl->plan || !pl->plan->p) return fail(FR_E_ARG, "fr_pipeline_run: null pipeline");
   fr::Plan &p = *pl->plan->p;
   if (T != pl->T) return fail(FR_E_ARG, "fr_pipeline_run: pipeline was created for another T");
+  if (!pl->have_quantiles)
+    return fail(FR_E_ARG, "fr_pipeline_run: call fr_pipeline_set_quantiles first");
   const int64_t F = (int64_t)pl->per_sum * p.K;
   if (N == 0 || F == 0) return FR_OK;
-  if (!d_feats || !d_quant || feat_stride < F)
-    return fail(FR_E_ARG, "fr_pipeline_run: bad feature / quantile buffer");
+  if (!d_feats || feat_stride < F) return fail(FR_E_ARG, "fr_pipeline_run: bad feature buffer");
   const int64_t need = fr_pipeline_workspace_bytes(pl, N, lookup_rows);
   if (need > 0 && (!d_work || work_bytes < need))
     return fail(FR_E_NOMEM, "fr_pipeline_run: workspace too small (need " +
@@ -482,14 +499,11 @@ int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, 
   hipStream_t st = (hipStream_t)stream;
   const size_t plan_ws = align_up(work_layout(p, N, T, p.weighting ? lookup_rows : 0).total(), 256);
   FusedArgs fu;
-  fu.sieves = pl->d_sieves;
-  fu.cuts = pl->d_cuts;
-  fu.quant = d_quant;
+  fu.ops = static_cast<const fr::FeatOp *>(pl->d_ops);
   fu.feats = d_feats;
   fu.feat_stride = feat_stride;
-  fu.n_sieves = pl->n_sieves;
-  fu.q_stride = pl->q_stride;
-  fu.per_sum = pl->per_sum;
+  fu.n_ops = pl->n_ops;
+  fu.n_ops_padded = pl->n_ops_padded;
   // features accumulate with atomics: clear them (memset nodes, graph-capturable)
   HIP_TRY(hipMemset2DAsync(d_feats, (size_t)feat_stride * 8, 0, (size_t)F * 8, (size_t)N, st));
   if (!pl->mpi_cols.empty()) {
@@ -504,7 +518,8 @@ int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, 
                     d_work, (int64_t)plan_ws, groups, st, &fu);
   if (rc != FR_OK) return rc;
   if (!pl->mpi_cols.empty()) {
-    hipError_t e = fr::launch_mpi_finalize(d_feats, fu.cnt, N, feat_stride, pl->d_mpi_cols,
+    hipError_t e = fr::launch_mpi_finalize(d_feats, fu.cnt, N, feat_stride,
+                                           static_cast<const int32_t *>(pl->d_mpi_cols),
                                            (int)pl->mpi_cols.size(), pl->per_sum, p.K, st);
     if (e != hipSuccess) return hip_fail(e, "mpi_finalize launch");
   }

@@ -14,12 +14,14 @@ constexpr int FR_SIEVE_NPI_K = 0;
 constexpr int FR_SIEVE_MPI_K = 1;
 constexpr int FR_SIEVE_END_K = 2;
 
-struct SieveDesc {   // 32 bytes, read with scalar loads
-  int32_t kind, inc, C1, Q1;
-  int32_t col;        // first feature column inside the block of one iterated sum
-  int32_t cut_off;    // offset of this sieve's C1 cuts in the cut table
-  int32_t q_off;      // offset of its Q1 thresholds inside a row of the quantile table
-  int32_t pad;
+// One feature of one iterated sum, everything resolved on the host (32 bytes, read
+// with one scalar load): END picks the value at index `lo`; NPI / MPI look at
+// t in [lo, hi) and values in (qlo, qhi] of the inc-times differenced row.
+struct FeatOp {
+  int32_t kind_inc;   // kind | inc << 8
+  int32_t col;        // absolute feature column
+  int32_t lo, hi;
+  double qlo, qhi;
 };
 
 struct IssArgs {
@@ -45,13 +47,11 @@ struct IssArgs {
   int32_t persistent;       // grid = one resident round of workgroups
   int32_t wave_rows;        // TEAM = 1 kernel: one wave per row, 4 groups per workgroup
   // fused sieve epilogue (MODE 1 kernels): features instead of the (K,N,T) tensor
-  const SieveDesc *sieves;
-  const int32_t *cuts;      // concatenated cut tables (sorted, leading 0, clamped to [0, T])
-  const double *quant;      // (K, q_stride) band thresholds per output row
+  const FeatOp *ops;        // (K, n_ops_padded) feature ops per output row, 64-byte aligned rows
   double *feats;            // (N, feat_stride) zero-initialised features
   double *cnt;              // same shape: band population of MPI features
   int64_t feat_stride;
-  int32_t n_sieves, q_stride, per_sum;
+  int32_t n_ops, n_ops_padded;
   unsigned long long *dbg;  // diagnostic stamps (timing build only)
   int32_t debug;            // timing experiments (FRUITS_HIP_DEBUG), 0 in production
 };

@@ -183,16 +183,21 @@ __device__ __forceinline__ void block_scan(WalkCtx &cx, const double (&s)[C::EP]
       if (cx.lane == 0) cx.carry[carry_slot] = carry_in + (p3 + t3);
     }
   }
+  // The last value of a lane is formed as base + (inclusive wave scan), the first
+  // exclusive value of the NEXT lane as base + (that same scan value, shifted): the
+  // two are bit-identical, so the stored row and the exclusive prefixes handed to
+  // children / sieves are consistent across lanes and pieces (an increment that the
+  // running sum absorbs is exactly 0, as in a sequential cumsum).
 #pragma unroll
   for (int h = 0; h < P; ++h) {
     const double off = base + excl[h];
     x[h * E] = off;
-    c[h * E] = off + l[h * E];
 #pragma unroll
-    for (int e = 1; e < E; ++e) {
-      x[h * E + e] = c[h * E + e - 1];
+    for (int e = 0; e + 1 < E; ++e) {
       c[h * E + e] = off + l[h * E + e];
+      x[h * E + e + 1] = c[h * E + e];
     }
+    c[h * E + E - 1] = base + incl[h];
     base += ptot[h];
   }
   STAMP(cx, 4);  // cross-wave prefix + final adds
@@ -296,88 +301,96 @@ __device__ __forceinline__ void emit_all(const WalkCtx &cx, const Rec &nd,
 // Features of ONE output row k from the node's inclusive values c and their
 // exclusive shifts x (x[t] = c[t-1]): what IncrementSieve._pre_transform +
 // NPI/MPI._backend (fruits/sieving/increment.py:63-71,107-163) and END._transform
-// (fruits/sieving/segment.py:210-219) compute on the materialised row.
+// (fruits/sieving/segment.py:210-219) compute on the materialised row.  The host
+// flattens the sieves of row k into n_ops fixed-size "feature ops" (FeatOp) whose
+// cuts and fitted thresholds are already resolved, so one scalar load per op
+// brings everything and there are no dependent table look-ups.
+struct Ops2 {
+  int32_t w[16];  // two FeatOps
+};
+
+__device__ __forceinline__ Ops2 load_ops2(const IssArgs &a, int64_t k, int first) {
+  cptr<int32_t> q = as_const(reinterpret_cast<const int32_t *>(
+      __builtin_assume_aligned(a.ops + (k * a.n_ops_padded + first), 64)));
+  Ops2 o;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) o.w[i] = q[i];
+  return o;
+}
+
+__device__ __forceinline__ double bits_to_double(int lo, int hi) {
+  return __hiloint2double(hi, lo);
+}
+
 template <class C>
-__device__ __forceinline__ void fused_row(const WalkCtx &cx, int64_t k, const double (&c)[C::EP],
-                                          const double (&x)[C::EP]) {
+__device__ __forceinline__ void fused_op(const WalkCtx &cx, const int32_t *w,
+                                         const double (&c)[C::EP], const double (&x)[C::EP]) {
   constexpr int E = C::E, P = C::P, EP = C::EP;
-  const IssArgs &a = *cx.a;
-  cptr<double> qrow = as_const(a.quant) + k * a.q_stride;
-  double *frow = cx.feat_row + k * a.per_sum;
-  double *crow = cx.cnt_row + k * a.per_sum;
-  const int T = (int)a.T;
+  const int kind = w[0] & 0xff, inc = w[0] >> 8, col = w[1];
+  if (kind == FR_SIEVE_END_K) {
+    const int rel = w[2] - (int)cx.t0;  // w[2] = index of the value to pick
+    if (rel >= 0 && rel < C::CHUNK) {
+      const int wv = rel / C::SPAN, in = rel % C::SPAN;
+      const int sel = (in / C::PIECE) * E + (in % E), ln = (in % C::PIECE) / E;
+      double val = c[0];
+#pragma unroll
+      for (int i = 1; i < EP; ++i) val = (sel == i) ? c[i] : val;
+      if (cx.wave == wv && cx.lane == ln) cx.feat_row[col] = val;
+    }
+    return;
+  }
+  const int lo = w[2], hi = w[3];
+  const double qlo = bits_to_double(w[4], w[5]), qhi = bits_to_double(w[6], w[7]);
   const int t_first = (int)cx.t0 + cx.wave * C::SPAN + cx.lane * E;  // element (h=0, e=0)
-  for (int si = 0; si < a.n_sieves; ++si) {
-    cptr<int32_t> sd = as_const(reinterpret_cast<const int32_t *>(a.sieves + si));
-    const int kind = sd[0], inc = sd[1], C1 = sd[2], Q1 = sd[3], col = sd[4];
-    cptr<int32_t> cut = as_const(a.cuts) + sd[5];
-    const int q_off = sd[6];
-    if (kind == FR_SIEVE_END_K) {
-      for (int j = 0; j + 1 < C1; ++j) {
-        int idx = cut[j + 1] - 1;
-        if (idx < 0) idx += T;  // numpy's wrap of index -1 (cut = 0)
-        const int rel = idx - (int)cx.t0;
-        if (rel >= 0 && rel < C::CHUNK) {
-          const int wv = rel / C::SPAN, in = rel % C::SPAN;
-          const int sel = (in / C::PIECE) * E + (in % E), ln = (in % C::PIECE) / E;
-          double val = c[0];
+  int cnt = 0;
+  double sum = 0.0;
 #pragma unroll
-          for (int i = 1; i < EP; ++i) val = (sel == i) ? c[i] : val;
-          if (cx.wave == wv && cx.lane == ln) frow[col + j] = val;
-        }
-      }
-      continue;
+  for (int h = 0; h < P; ++h)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int t = t_first + h * C::PIECE + e;
+      // increments are zero-padded at t = 0 (fruits/cache.py:8-13)
+      const double v = inc == 0 ? c[h * E + e] : (t == 0 ? 0.0 : c[h * E + e] - x[h * E + e]);
+      const bool in = t >= lo && t < hi && qlo < v && v <= qhi;
+      cnt += __popcll(__ballot(in));
+      if (kind == FR_SIEVE_MPI_K) sum += in ? v : 0.0;
     }
-    double d[EP];
-    if (inc == 0) {
-#pragma unroll
-      for (int i = 0; i < EP; ++i) d[i] = c[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < EP; ++i) d[i] = c[i] - x[i];
-      if (t_first == 0) d[0] = 0.0;  // increments are zero-padded at t = 0 (cache.py:8-13)
+  if (cnt == 0) return;
+  if (kind == FR_SIEVE_MPI_K) {
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (cx.lane == 0) {
+      unsafeAtomicAdd(&cx.feat_row[col], sum);
+      unsafeAtomicAdd(&cx.cnt_row[col], (double)cnt);
     }
-    for (int j = 0; j + 1 < C1; ++j) {
-      const int lo = cut[j], hi = cut[j + 1];
-      for (int q = 0; q + 1 < Q1; ++q) {
-        const double qlo = qrow[q_off + q], qhi = qrow[q_off + q + 1];
-        int cnt = 0;
-        double sum = 0.0;
-#pragma unroll
-        for (int h = 0; h < P; ++h)
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            const int t = t_first + h * C::PIECE + e;
-            const double v = d[h * E + e];
-            const bool in = t >= lo && t < hi && qlo < v && v <= qhi;
-            cnt += __popcll(__ballot(in));
-            if (kind == FR_SIEVE_MPI_K) sum += in ? v : 0.0;
-          }
-        if (cnt == 0) continue;
-        const int f = col + j * (Q1 - 1) + q;
-        if (kind == FR_SIEVE_MPI_K) {
-          for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-          if (cx.lane == 0) {
-            unsafeAtomicAdd(&frow[f], sum);
-            unsafeAtomicAdd(&crow[f], (double)cnt);
-          }
-        } else if (cx.lane == 0) {
-          unsafeAtomicAdd(&frow[f], (double)cnt);
-        }
-      }
-    }
+  } else if (cx.lane == 0) {
+    unsafeAtomicAdd(&cx.feat_row[col], (double)cnt);
   }
 }
 
 template <class C>
-__device__ __forceinline__ void fused_all(const WalkCtx &cx, const Rec &nd,
+__device__ __forceinline__ void fused_row(const WalkCtx &cx, int64_t k, const Ops2 &first,
+                                          const double (&c)[C::EP], const double (&x)[C::EP]) {
+  const int n = cx.a->n_ops;
+  fused_op<C>(cx, first.w, c, x);
+  if (n > 1) fused_op<C>(cx, first.w + 8, c, x);
+  for (int i = 2; i < n; i += 2) {
+    const Ops2 o = load_ops2(*cx.a, k, i);
+    fused_op<C>(cx, o.w, c, x);
+    if (i + 1 < n) fused_op<C>(cx, o.w + 8, c, x);
+  }
+}
+
+template <class C>
+__device__ __forceinline__ void fused_all(const WalkCtx &cx, const Rec &nd, const Ops2 &pre,
                                           const double (&c)[C::EP], const double (&x)[C::EP]) {
   const int ne = nd.emit_count();
-  if (ne > 0) fused_row<C>(cx, nd.w[7], c, x);
+  if (ne > 0) fused_row<C>(cx, nd.w[7], pre, c, x);
   if (ne > 1) {
-    fused_row<C>(cx, nd.w[8], c, x);
-    for (int j = kRecInlineEmits; j < ne; ++j)
-      fused_row<C>(cx, as_const(cx.a->emit_rows)[nd.emit_begin() + j], c, x);
+    fused_row<C>(cx, nd.w[8], load_ops2(*cx.a, nd.w[8], 0), c, x);
+    for (int j = kRecInlineEmits; j < ne; ++j) {
+      const int64_t k = as_const(cx.a->emit_rows)[nd.emit_begin() + j];
+      fused_row<C>(cx, k, load_ops2(*cx.a, k, 0), c, x);
+    }
   }
 }
 
@@ -389,6 +402,10 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd,
   double s[EP];
 #pragma unroll
   for (int i = 0; i < EP; ++i) s[i] = pin[i];
+  Ops2 pre;  // MODE 1: the first two feature ops of the first output row, requested early
+  if constexpr (C::MODE == 1) {
+    if (nd.emit_count() > 0) pre = load_ops2(*cx.a, nd.w[7], 0);
+  }
   const int nf = nd.fac_count();
   if (nd.flags() & F_SLOW) {
     slow_factors<C>(cx, nd.fac_begin(), nf, s);
@@ -420,7 +437,7 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd,
     if (nd.emit_count() > 0) {
       if (C::WEIGHTED && emit_mul >= 0) mul_row<C>(cx, emit_mul, c);
       if constexpr (C::MODE == 1)
-        fused_all<C>(cx, nd, c, x);
+        fused_all<C>(cx, nd, pre, c, x);
       else
         emit_all<C>(cx, nd, c);
       STAMP(cx, 5);  // stores

@@ -326,8 +326,9 @@ class FruitSlice:
         return True
 
     def _fused(self, T: int):
-        """(pipeline, quantile table) for series length T, or None when a sieve or
-        the weighting is outside the fused set; cached until the next fit."""
+        """The fused pipeline for series length T (thresholds of the fitted sieve
+        copies already resolved), or None when a sieve or the weighting is outside
+        the fused set; cached until the next fit."""
         if not hasattr(self, "_fused_cache"):
             self._fused_cache = {}
         if T in self._fused_cache:
@@ -357,7 +358,8 @@ class FruitSlice:
                             sv._get_unfitted_quantiles()
                         quant[k, off:off + len(sv._q)] = sv._quantiles
                         off += len(sv._q)
-                entry = (pipe, nat.to_device(quant))
+                pipe.set_quantiles(quant)
+                entry = pipe
         self._fused_cache[T] = entry
         return entry
 
@@ -412,8 +414,7 @@ class FruitSlice:
         self._attach(cache)
         fused = None if callbacks else self._fused(int(Pd.shape[2]))
         if fused is not None:
-            pipe, quant_d = fused
-            feats = pipe.run(Pd, self._iss[0].lookup_device(Pd), quant_d)
+            feats = fused.run(Pd, self._iss[0].lookup_device(Pd))
             return nat.to_host(feats)
         feats = t.zeros((X.shape[0], self.nfeatures()), dtype=t.float64, device=Pd.device)
         col = 0

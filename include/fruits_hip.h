@@ -189,9 +189,12 @@ int fr_sieve(int32_t kind, const double *d_A, int64_t N, int64_t T, int64_t a_st
  *   cuts               concatenated transformed cut rows (C1[s] values each: sorted,
  *                      leading 0, negative cuts already resolved for length T -
  *                      fruits/sieving/segment.py:51-64)
- *   d_quant            (K, q_stride) thresholds of every iterated sum (the fitted
+ *   h_quant            HOST (K, q_stride) thresholds of every iterated sum (the fitted
  *                      sieve copies of fruit.py:484-496), q_stride =
- *                      fr_pipeline_info(p, 1) = sum of Q1 over the NPI/MPI sieves
+ *                      fr_pipeline_info(p, 1) = sum of Q1 over the NPI/MPI sieves;
+ *                      fr_pipeline_set_quantiles resolves them with the cuts into a
+ *                      device table of per-row feature ops (call once after fit; it
+ *                      allocates and synchronises)
  *   d_feats            (N, feat_stride >= F) output, F = fr_pipeline_info(p, 2)
  * Returns FR_E_LIMIT from create when a sieve is outside the fused set (the caller
  * then uses fr_iss_run + fr_sieve).  fr_pipeline_info: 0 features per iterated sum,
@@ -203,10 +206,11 @@ void fr_pipeline_destroy(fr_pipeline_t *pipeline);
 int64_t fr_pipeline_info(const fr_pipeline_t *pipeline, int32_t what);
 int64_t fr_pipeline_workspace_bytes(const fr_pipeline_t *pipeline, int64_t N,
                                     int64_t lookup_rows);
+int fr_pipeline_set_quantiles(fr_pipeline_t *pipeline, const double *h_quant);
 int fr_pipeline_run(fr_pipeline_t *pipeline, const double *d_X, int64_t N, int64_t D, int64_t T,
-                    const double *d_lookup, int64_t lookup_rows, const double *d_quant,
-                    double *d_feats, int64_t feat_stride, void *d_work, int64_t work_bytes,
-                    int32_t groups, void *stream);
+                    const double *d_lookup, int64_t lookup_rows, double *d_feats,
+                    int64_t feat_stride, void *d_work, int64_t work_bytes, int32_t groups,
+                    void *stream);
 
 /* IncrementSieve._pre_transform alone (fruits/sieving/increment.py:63-71, inc >= 0),
  * materialised: d_out (N, T) contiguous.  Used by fit, which needs the values for

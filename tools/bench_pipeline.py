@@ -1,0 +1,77 @@
+"""Config 3 / 5 style pipelines: fused launch vs materialising path, device-resident timing."""
+import os, sys, time, json
+import numpy as np
+sys.path.insert(0, '.')
+import torch
+import fruits_amd as fr
+from fruits_amd import _native as nat
+
+def graph_time(fn, reps=10, rounds=5):
+    fn(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph(); s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(reps): fn()
+    ts = []
+    for _ in range(rounds):
+        g.replay(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); g.replay(); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) / reps * 1e3)
+    return float(np.median(ts))
+
+def run(name, N, D, T, words, weighting, sieves):
+    X = np.random.default_rng(0).standard_normal((N, D, T))
+    fruit = fr.Fruit(name)
+    fruit.add(fr.preparation.INC)
+    iss = fr.ISS(words, mode=fr.ISSMode.EXTENDED, weighting=weighting)
+    fruit.add(iss)
+    for s in sieves: fruit.add(s)
+    for slc in fruit: slc.fit_sample_size = 1.0
+    t0 = time.perf_counter(); np.random.seed(0); fruit.fit(X[:256]); t_fit = time.perf_counter() - t0
+    t0 = time.perf_counter(); f1 = fruit.transform(X); t_e2e_first = time.perf_counter() - t0
+    t0 = time.perf_counter(); f1 = fruit.transform(X); t_e2e = time.perf_counter() - t0
+    slc = fruit.get_slice(0)
+    cache = fr.cache.SharedSeedCache(X)
+    Xd = cache.input_device(X)
+    Pd = slc._prepare_device(Xd, cache)
+    slc._attach(cache)
+    pipe = slc._fused(T)
+    lk = iss.lookup_device(Pd)
+    feats = torch.empty((N, pipe.n_features), dtype=torch.float64, device=Pd.device)
+    wb = int(nat.lib().fr_pipeline_workspace_bytes(pipe._h, N, 0 if lk is None else lk.shape[0]))
+    work = torch.empty(max(wb, 1), dtype=torch.uint8, device=Pd.device)
+    t_fused = graph_time(lambda: pipe.run(Pd, lk, feats=feats, work=work))
+    plan = iss._plan(0, len(words)); K = plan.rows
+    out = torch.empty((K, N, T), dtype=torch.float64, device=Pd.device)
+    wb2 = plan.workspace_bytes(N, T, 0 if lk is None else lk.shape[0])
+    work2 = torch.empty(max(wb2, 1), dtype=torch.uint8, device=Pd.device)
+    t_mat = graph_time(lambda: plan.run(Pd, lk, out=out, work=work2))
+    os.environ["FRUITS_AMD_FUSED"] = "0"; slc._fused_cache = {}
+    t0 = time.perf_counter(); f0 = fruit.transform(X); t_e2e_plain = time.perf_counter() - t0
+    os.environ["FRUITS_AMD_FUSED"] = "1"; slc._fused_cache = {}
+    diff = np.abs(f0 - f1)
+    eq_bytes = 8.0 * N * T * (plan.dims_used + K)
+    res = {"name": name, "N": N, "D": D, "T": T, "W": len(words), "K": K, "F": int(pipe.n_features),
+           "fit_s(256 series)": round(t_fit, 3),
+           "fused_launch_us": round(t_fused, 1), "materialise_launch_us": round(t_mat, 1),
+           "fused_elements_per_s": N * K * T / (t_fused * 1e-6),
+           "fused_equiv_materialised_GBs": eq_bytes / (t_fused * 1e-6) / 1e9,
+           "materialise_GBs": eq_bytes / (t_mat * 1e-6) / 1e9,
+           "transform_e2e_fused_ms": round(t_e2e * 1e3, 2), "transform_e2e_first_ms": round(t_e2e_first * 1e3, 2),
+           "transform_e2e_unfused_ms": round(t_e2e_plain * 1e3, 2),
+           "max_feature_diff_fused_vs_unfused": float(diff.max()), "frac_diff": float((diff > 0).mean())}
+    print(json.dumps(res))
+
+which = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+if which in ("cfg3", "all"):
+    run("cfg3_indices", 2048, 3, 1024, fr.words.of_weight(4, dim=2), fr.iss.weighting.Indices(),
+        [fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END()])
+    run("cfg3_unweighted", 2048, 3, 1024, fr.words.of_weight(4, dim=2), None,
+        [fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END()])
+if which in ("cfg2", "all"):
+    run("cfg2_pipeline", 2048, 3, 1024, fr.words.of_weight(2, dim=3), None,
+        [fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END()])
+if which in ("cfg5", "all"):
+    run("cfg5_l1", 1024, 6, 4096, fr.words.of_weight(9, dim=1), fr.iss.weighting.L1(),
+        [fr.sieving.NPI(), fr.sieving.END()])
