@@ -260,8 +260,8 @@ bool wave_rows_supported(int64_t T, int levels, bool vec_ok) {
 }
 
 #define DECL_INST(m, l) hipError_t walk_inst_m##m##_l##l(const IssArgs &, int, hipStream_t);
-DECL_INST(0, 2) DECL_INST(0, 4) DECL_INST(0, 8) DECL_INST(0, 12)
-DECL_INST(1, 2) DECL_INST(1, 4) DECL_INST(1, 8) DECL_INST(1, 12)
+DECL_INST(0, 2) DECL_INST(0, 4) DECL_INST(0, 8)
+DECL_INST(1, 2) DECL_INST(1, 4) DECL_INST(1, 8)
 hipError_t walk_inst_team1(const IssArgs &, int, int, hipStream_t);
 
 hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st) {
@@ -277,13 +277,11 @@ hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st) {
   if (a.feats) {
     if (levels <= 2) return walk_inst_m1_l2(a, chunk, st);
     if (levels <= 4) return walk_inst_m1_l4(a, chunk, st);
-    if (levels <= 8) return walk_inst_m1_l8(a, chunk, st);
-    return walk_inst_m1_l12(a, chunk, st);
+    return walk_inst_m1_l8(a, chunk, st);
   }
   if (levels <= 2) return walk_inst_m0_l2(a, chunk, st);
   if (levels <= 4) return walk_inst_m0_l4(a, chunk, st);
-  if (levels <= 8) return walk_inst_m0_l8(a, chunk, st);
-  return walk_inst_m0_l12(a, chunk, st);
+  return walk_inst_m0_l8(a, chunk, st);
 }
 
 // MPI features: mean = sum / population (0 for an empty band, increment.py:158-161)

@@ -21,7 +21,7 @@ constexpr int32_t F_CHILDREN = 2;  // the exclusive prefix of this node is consu
 constexpr int32_t FAC_DIV = 0x80;
 constexpr int32_t FAC_ROW_MASK = 0x7f;
 
-constexpr int kMaxLevels = 12;  // deepest register-frame stack a kernel variant supports
+constexpr int kMaxLevels = 8;   // deepest register-frame stack a kernel variant supports
 
 struct NodeDesc {  // 32 bytes, read by the kernel with scalar loads
   int32_t level;       // register frame this node writes (reads level-1; level 0 reads ones)

@@ -66,6 +66,8 @@ __device__ __forceinline__ int lds_pos(int i) {
   }
 }
 
+constexpr int kStageRows = 3;  // rows staged per batch (registers: 4 * U VGPRs per row)
+
 struct WalkCtx {
   const IssArgs *a;
   const double *rows;   // LDS: staged rows [R][CHUNK]
@@ -335,7 +337,9 @@ __device__ __forceinline__ void fused_op(const WalkCtx &cx, const int32_t *w,
       double val = c[0];
 #pragma unroll
       for (int i = 1; i < EP; ++i) val = (sel == i) ? c[i] : val;
-      if (cx.wave == wv && cx.lane == ln) cx.feat_row[col] = val;
+      // (an add onto the zero-initialised feature, so that this buffer only ever sees
+      // atomics: a plain store here would make the compiler drain vmcnt first)
+      if (cx.wave == wv && cx.lane == ln) unsafeAtomicAdd(&cx.feat_row[col], val);
     }
     return;
   }
@@ -368,29 +372,23 @@ __device__ __forceinline__ void fused_op(const WalkCtx &cx, const int32_t *w,
 }
 
 template <class C>
-__device__ __forceinline__ void fused_row(const WalkCtx &cx, int64_t k, const Ops2 &first,
-                                          const double (&c)[C::EP], const double (&x)[C::EP]) {
-  const int n = cx.a->n_ops;
-  fused_op<C>(cx, first.w, c, x);
-  if (n > 1) fused_op<C>(cx, first.w + 8, c, x);
-  for (int i = 2; i < n; i += 2) {
-    const Ops2 o = load_ops2(*cx.a, k, i);
-    fused_op<C>(cx, o.w, c, x);
-    if (i + 1 < n) fused_op<C>(cx, o.w + 8, c, x);
-  }
-}
-
-template <class C>
 __device__ __forceinline__ void fused_all(const WalkCtx &cx, const Rec &nd, const Ops2 &pre,
                                           const double (&c)[C::EP], const double (&x)[C::EP]) {
-  const int ne = nd.emit_count();
-  if (ne > 0) fused_row<C>(cx, nd.w[7], pre, c, x);
-  if (ne > 1) {
-    fused_row<C>(cx, nd.w[8], load_ops2(*cx.a, nd.w[8], 0), c, x);
-    for (int j = kRecInlineEmits; j < ne; ++j) {
-      const int64_t k = as_const(cx.a->emit_rows)[nd.emit_begin() + j];
-      fused_row<C>(cx, k, load_ops2(*cx.a, k, 0), c, x);
+  const IssArgs &a = *cx.a;
+  const int ne = nd.emit_count(), n = a.n_ops;
+  int64_t k = nd.w[7];
+  Ops2 o = pre;  // ops 0-1 of the first row were requested at the start of the node
+  for (int j = 0;;) {
+    for (int i = 0;;) {
+      fused_op<C>(cx, o.w, c, x);
+      if (i + 1 < n) fused_op<C>(cx, o.w + 8, c, x);
+      i += 2;
+      if (i >= n) break;
+      o = load_ops2(a, k, i);
     }
+    if (++j >= ne) break;
+    k = j == 1 ? (int64_t)nd.w[8] : (int64_t)as_const(a.emit_rows)[nd.emit_begin() + j];
+    o = load_ops2(a, k, 0);
   }
 }
 
@@ -468,22 +466,50 @@ template <class C, int LV>
 __device__ __forceinline__ void walk(WalkCtx &cx, Rec &cur, int &pc,
                                      const double (&pin)[C::EP]) {
   const IssArgs &a = *cx.a;
-  while (cur.level() == LV) {
-    const Rec nd = cur;
-    ++pc;
-    cur = load_rec(a.recs, pc);
-    double pout[C::EP];
-    STAMP(cx, 0);  // interpreter: record decode / prefetch issue
-    process_node<C>(cx, nd, pin, pout);
-    // only children continue in place in this frame
-    while (cur.level() == LV && (cur.flags() & F_CHAIN)) {
-      const Rec nc = cur;
+  if constexpr (C::MODE == 0 && C::MAXLV <= 4) {
+    // two code sites per level (head of a chain / in-place continuation): no
+    // register copies; affordable for the small materialising kernels
+    while (cur.level() == LV) {
+      const Rec nd = cur;
       ++pc;
       cur = load_rec(a.recs, pc);
-      process_node<C>(cx, nc, pout, pout);
+      double pout[C::EP];
+      STAMP(cx, 0);  // interpreter: record decode / prefetch issue
+      process_node<C>(cx, nd, pin, pout);
+      while (cur.level() == LV && (cur.flags() & F_CHAIN)) {
+        const Rec nc = cur;
+        ++pc;
+        cur = load_rec(a.recs, pc);
+        process_node<C>(cx, nc, pout, pout);
+      }
+      if constexpr (LV + 1 < C::MAXLV) {
+        if (cur.level() == LV + 1) walk<C, LV + 1>(cx, cur, pc, pout);
+      }
     }
-    if constexpr (LV + 1 < C::MAXLV) {
-      if (cur.level() == LV + 1) walk<C, LV + 1>(cx, cur, pc, pout);
+  } else {
+    // one code site per level (code size matters for deep / fused kernels): an only
+    // child continues in place in this frame (reads its parent's prefix from pout);
+    // every other node of the level reads the frame below (pin)
+    double pout[C::EP];
+#pragma unroll
+    for (int i = 0; i < C::EP; ++i) pout[i] = 0.0;
+    while (cur.level() == LV) {
+      const Rec nd = cur;
+      ++pc;
+      cur = load_rec(a.recs, pc);
+      double src[C::EP];
+      if (nd.flags() & F_CHAIN) {
+#pragma unroll
+        for (int i = 0; i < C::EP; ++i) src[i] = pout[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < C::EP; ++i) src[i] = pin[i];
+      }
+      STAMP(cx, 0);  // interpreter: record decode / prefetch issue
+      process_node<C>(cx, nd, src, pout);
+      if constexpr (LV + 1 < C::MAXLV) {
+        if (cur.level() == LV + 1) walk<C, LV + 1>(cx, cur, pc, pout);
+      }
     }
   }
 }
@@ -547,15 +573,15 @@ __global__ __launch_bounds__(kWalkThreads) void iss_walk_kernel(const IssArgs a)
       }
       if (!first_unit || chunk > 0) lds_barrier();  // all reads of the old rows are done
       // stage the referenced rows of this chunk: coalesced 16-byte units, the
-      // loads of up to 4 rows in flight before the first LDS write
+      // loads of kStageRows rows in flight before the first LDS write
 #ifdef FRUITS_HIP_TIMING_BUILD
       if (!(a.debug & 8))
 #endif
-      for (int r0 = 0; r0 < a.R; r0 += 4) {
+      for (int r0 = 0; r0 < a.R; r0 += kStageRows) {
         constexpr int U = C::CHUNK / 2 / kWalkThreads;
-        vd2 v[4][U];
+        vd2 v[kStageRows][U];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
+        for (int rr = 0; rr < kStageRows; ++rr) {
           if (r0 + rr < a.R) {
             const int src = as_const(a.row_src)[r0 + rr];
             const double *gp =
@@ -576,7 +602,7 @@ __global__ __launch_bounds__(kWalkThreads) void iss_walk_kernel(const IssArgs a)
           }
         }
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
+        for (int rr = 0; rr < kStageRows; ++rr) {
           if (r0 + rr < a.R) {
 #pragma unroll
             for (int k = 0; k < U; ++k) {

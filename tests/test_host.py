@@ -192,7 +192,7 @@ def test_plan_rejects_bad_input():
         nat.Plan([np.array([1], np.int32)], [1])   # not (L, Dw)
     deep = nat.Plan([fr.words.SimpleWord("[1]" * 30 + "[2]").table(),
                      fr.words.SimpleWord("[1]" * 30 + "[3]").table()], [31, 1])
-    assert deep.info(nat.FR_INFO_LEVELS) <= 12 and deep.rows == 32
+    assert deep.info(nat.FR_INFO_LEVELS) <= 8 and deep.rows == 32
 
 
 # ---------------------------------------------------------------- stages (no compute)
