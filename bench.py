@@ -63,12 +63,78 @@ def cpu_baseline(words, seconds_budget: float = 15.0):
     }
 
 
+def _event_time_us(torch, fn, reps=20):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+
+
+def extras(torch, fr, nat, dev):
+    """Secondary measurements on the same GPU (not the headline value): the metric's
+    "48 words" reading, and the fused INC->ISS->NPI,END pipeline of BASELINE configs[2]."""
+    out = {}
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((N_SERIES, N_DIMS, N_STEPS_T))
+    Xd = nat.to_device(X)
+    # (a) words[i % 15] tiled to 48, SINGLE mode: K = 48 rows, 855.6 MB algorithmic
+    w15 = fr.words.of_weight(2, dim=N_DIMS)
+    w48 = [w15[i % 15] for i in range(48)]
+    plan = fr.ISS(w48)._plan(0, 48)
+    buf = torch.empty((48, N_SERIES, N_STEPS_T), dtype=torch.float64, device=dev)
+    t = _event_time_us(torch, lambda: plan.run(Xd, None, out=buf))
+    b_alg = 8.0 * N_SERIES * N_STEPS_T * (3 + 48)
+    out["words48_single"] = {"kernel_us": t, "elements_per_s": N_SERIES * 48 * N_STEPS_T / (t * 1e-6),
+                             "GBs": b_alg / (t * 1e-6) / 1e9, "frac": b_alg / (t * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    del buf
+    # (b) config 3 shape: INC -> ISS(of_weight(4,2) EXTENDED, Indices) -> NPI(q=(.5,1)), END, fused
+    fruit = fr.Fruit("cfg3")
+    fruit.add(fr.preparation.INC)
+    iss = fr.ISS(fr.words.of_weight(4, dim=2), mode=fr.ISSMode.EXTENDED,
+                 weighting=fr.iss.weighting.Indices())
+    fruit.add(iss)
+    fruit.add(fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END)
+    fruit.get_slice().fit_sample_size = 1.0
+    np.random.seed(0)
+    fruit.fit(X[:128])
+    slc = fruit.get_slice()
+    cache = fr.cache.SharedSeedCache(X)
+    cache.adopt_device_input(Xd)
+    Pd = slc._prepare_device(Xd, cache)
+    slc._attach(cache)
+    pipe = slc._fused(N_STEPS_T)
+    lk = iss.lookup_device(Pd)
+    feats = torch.empty((N_SERIES, pipe.n_features), dtype=torch.float64, device=dev)
+    t = _event_time_us(torch, lambda: pipe.run(Pd, lk, feats=feats))
+    K = pipe.plan.rows
+    fruit.transform(X)   # first call builds plans / uploads tables
+    t0 = time.perf_counter()
+    fruit.transform(X)
+    e2e = time.perf_counter() - t0
+    out["config3_fused_pipeline"] = {
+        "launch_us": t, "K": K, "features": pipe.n_features,
+        "elements_per_s": N_SERIES * K * N_STEPS_T / (t * 1e-6),
+        "algorithmic_bytes": 8.0 * N_SERIES * N_STEPS_T * 2 + 8.0 * N_SERIES * pipe.n_features,
+        "equivalent_materialised_GBs": 8.0 * N_SERIES * N_STEPS_T * (2 + K) / (t * 1e-6) / 1e9,
+        "fruit_transform_end_to_end_ms": e2e * 1e3,
+        "note": "no (K,N,T) tensor is written; the GB/s figure is what a materialising run "
+                "of the same work would have needed, not achieved bandwidth",
+    }
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--groups", type=int, default=0)
     args = ap.parse_args()
 
@@ -171,6 +237,8 @@ def main() -> None:
             "kernel_avg_us": kernel_avg_s * 1e6, "kernel_median_us": kernel_med_s * 1e6,
         },
     }
+    if rank == 0 and world == 1 and not args.no_extras:
+        res["extras"] = extras(torch, fr, nat, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(words)
     if distributed:
