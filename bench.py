@@ -145,7 +145,7 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or bool(os.environ.get("FRUITS_BENCH_FORCE_DIST"))
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
