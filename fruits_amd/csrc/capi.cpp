@@ -2,6 +2,7 @@
 // reference interfaces each entry point replaces).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -316,6 +317,18 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   }
   a.persistent = env_int("FRUITS_HIP_PERSIST", 1);
   a.wave_rows = wave_rows ? 1 : 0;
+  {
+    int max_nodes = 0;
+    for (size_t g = 0; g + 1 < gp.group_begin.size(); ++g)
+      max_nodes = std::max(max_nodes, gp.group_begin[g + 1] - gp.group_begin[g]);
+    a.carry_slots = 2 * max_nodes;
+    // rows + carries must leave room for >= 4 workgroups per CU (160 KiB LDS)
+    const size_t rows_bytes = (size_t)a.R * fr::walk_chunk_elems(T) * 8;
+    a.carry_in_lds = (env_int("FRUITS_HIP_LDS_CARRY", 1) != 0 &&
+                      rows_bytes + (size_t)a.carry_slots * 8 <= 40 * 1024)
+                         ? 1
+                         : 0;
+  }
   if (fu) {
     a.ops = fu->ops;
     a.feats = fu->feats;

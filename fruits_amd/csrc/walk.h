@@ -26,7 +26,7 @@ namespace fr {
 // the span is P pieces of 64*E elements; lane l holds E consecutive elements of
 // every piece.  So every 16-byte global access of a wave is lane-contiguous
 // (E = 2: 1 KiB per instruction) and only NW wave totals cross waves.
-template <int E_, int P_, int MAXLV_, bool MULTI_, bool VEC_, bool WEIGHTED_, int TEAM_ = 4,
+template <int E_, int P_, int MAXLV_, int MULTI_, bool VEC_, bool WEIGHTED_, int TEAM_ = 4,
           int MODE_ = 0>
 struct WalkCfg {
   // MODE 0: write the (K,N,T) tensor.  MODE 1: fused sieve epilogue - the values of
@@ -45,7 +45,10 @@ struct WalkCfg {
   static constexpr int P = P_;          // pieces per wave
   static constexpr int EP = E_ * P_;
   static constexpr int MAXLV = MAXLV_;
-  static constexpr bool MULTI = MULTI_;  // more than one time chunk (carries in memory)
+  // more than one time chunk: 0 no, 1 per-node carries in LDS, 2 carries in global memory
+  // (a global carry load is a vector load: waiting for it also waits for every output
+  // store in flight, so LDS is preferred whenever the group's carries fit)
+  static constexpr int MULTI = MULTI_;
   static constexpr int NW = TEAM_;
   static constexpr int PIECE = 64 * E_;          // elements per wave piece
   static constexpr int SPAN = PIECE * P_;        // elements per wave
@@ -75,9 +78,10 @@ struct WalkCtx {
   double *out_base;     // out + n*out_n_stride + t0
   double *feat_row;     // MODE 1: feats + n*feat_stride
   double *cnt_row;      // MODE 1: band population of MPI features
-  double *carry;        // carry slots of this series (multi-chunk) or nullptr
+  double *carry;        // carry slots of this series (multi-chunk; LDS or global) or nullptr
   int64_t t0;           // first time index of the chunk
   int tid, lane, wave, team;   // wave = index inside the team
+  int pc_begin;                // first record of the group being walked
   int buf;
   bool first_chunk;
   bool full_chunk;      // every element of the chunk is < T (no per-lane bounds checks)
@@ -151,13 +155,13 @@ __device__ __forceinline__ void block_scan(WalkCtx &cx, const double (&s)[C::EP]
     ptot[h] = wave_last_lane(incl[h]);
   }
   double carry_in = 0.0;
-  if constexpr (C::MULTI) {
+  if constexpr (C::MULTI != 0) {
     if (!cx.first_chunk) carry_in = cx.carry[carry_slot];
   }
   double base = 0.0;
   if constexpr (NW == 1) {
     STAMP(cx, 2);  // local sums + wave scans
-    if constexpr (C::MULTI) {
+    if constexpr (C::MULTI != 0) {
       double total = ptot[0];
 #pragma unroll
       for (int h = 1; h < P; ++h) total += ptot[h];
@@ -179,7 +183,11 @@ __device__ __forceinline__ void block_scan(WalkCtx &cx, const double (&s)[C::EP]
     const double p2 = t0 + t1, p3 = p2 + t2;
     base = cx.wave == 0 ? 0.0 : (cx.wave == 1 ? t0 : (cx.wave == 2 ? p2 : p3));
     cx.buf ^= 1;
-    if constexpr (C::MULTI) {
+    if constexpr (C::MULTI == 1) {
+      // LDS carry: every wave read it before the barrier above; one lane updates it
+      base += carry_in;
+      if (cx.wave == 0 && cx.lane == 0) cx.carry[carry_slot] = carry_in + (p3 + t3);
+    } else if constexpr (C::MULTI == 2) {
       base += carry_in;
       // every wave stores the same value; a wave only ever re-reads its own store
       if (cx.lane == 0) cx.carry[carry_slot] = carry_in + (p3 + t3);
@@ -393,7 +401,7 @@ __device__ __forceinline__ void fused_all(const WalkCtx &cx, const Rec &nd, cons
 }
 
 template <class C>
-__device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd,
+__device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd, int slot,
                                              const double (&pin)[C::EP],
                                              double (&pout)[C::EP]) {
   constexpr int EP = C::EP;
@@ -431,7 +439,7 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd,
 #endif
   if (need1) {
     double c[EP], x[EP];
-    block_scan<C>(cx, s, c, x, 2 * nd.node_id());
+    block_scan<C>(cx, s, c, x, slot);
     if (nd.emit_count() > 0) {
       if (C::WEIGHTED && emit_mul >= 0) mul_row<C>(cx, emit_mul, c);
       if constexpr (C::MODE == 1)
@@ -451,11 +459,19 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd,
 #pragma unroll
       for (int i = 0; i < EP; ++i) s2[i] = s[i];
       mul_row<C>(cx, z_mul, s2);
-      block_scan<C>(cx, s2, c, x, 2 * nd.node_id() + 1);
+      block_scan<C>(cx, s2, c, x, slot + 1);
 #pragma unroll
       for (int i = 0; i < EP; ++i) pout[i] = x[i];
     }
   }
+}
+
+// carry slot of a node: LDS carries are indexed by the node's position inside its
+// group, global ones by its plan-wide id
+template <class C>
+__device__ __forceinline__ int carry_slot_of(const WalkCtx &cx, const Rec &nd, int pc) {
+  if constexpr (C::MULTI == 1) return 2 * (pc - cx.pc_begin);
+  return 2 * nd.node_id();
 }
 
 // Walks the records of one group.  cx.cur always holds the record at cx.pc; the
@@ -471,16 +487,18 @@ __device__ __forceinline__ void walk(WalkCtx &cx, Rec &cur, int &pc,
     // register copies; affordable for the small materialising kernels
     while (cur.level() == LV) {
       const Rec nd = cur;
+      const int slot = carry_slot_of<C>(cx, nd, pc);
       ++pc;
       cur = load_rec(a.recs, pc);
       double pout[C::EP];
       STAMP(cx, 0);  // interpreter: record decode / prefetch issue
-      process_node<C>(cx, nd, pin, pout);
+      process_node<C>(cx, nd, slot, pin, pout);
       while (cur.level() == LV && (cur.flags() & F_CHAIN)) {
         const Rec nc = cur;
+        const int slot2 = carry_slot_of<C>(cx, nc, pc);
         ++pc;
         cur = load_rec(a.recs, pc);
-        process_node<C>(cx, nc, pout, pout);
+        process_node<C>(cx, nc, slot2, pout, pout);
       }
       if constexpr (LV + 1 < C::MAXLV) {
         if (cur.level() == LV + 1) walk<C, LV + 1>(cx, cur, pc, pout);
@@ -495,6 +513,7 @@ __device__ __forceinline__ void walk(WalkCtx &cx, Rec &cur, int &pc,
     for (int i = 0; i < C::EP; ++i) pout[i] = 0.0;
     while (cur.level() == LV) {
       const Rec nd = cur;
+      const int slot = carry_slot_of<C>(cx, nd, pc);
       ++pc;
       cur = load_rec(a.recs, pc);
       double src[C::EP];
@@ -506,7 +525,7 @@ __device__ __forceinline__ void walk(WalkCtx &cx, Rec &cur, int &pc,
         for (int i = 0; i < C::EP; ++i) src[i] = pin[i];
       }
       STAMP(cx, 0);  // interpreter: record decode / prefetch issue
-      process_node<C>(cx, nd, src, pout);
+      process_node<C>(cx, nd, slot, src, pout);
       if constexpr (LV + 1 < C::MAXLV) {
         if (cur.level() == LV + 1) walk<C, LV + 1>(cx, cur, pc, pout);
       }
@@ -559,8 +578,12 @@ __global__ __launch_bounds__(kWalkThreads) void iss_walk_kernel(const IssArgs a)
       n = u / a.G;
       g = (int)(u % a.G);
     }
-    cx.carry = a.carry ? a.carry + n * (2 * (int64_t)a.total_nodes) : nullptr;
+    if constexpr (C::MULTI == 1)
+      cx.carry = lds + (int64_t)a.R * C::CHUNK + 2 * C::NW;
+    else
+      cx.carry = a.carry ? a.carry + n * (2 * (int64_t)a.total_nodes) : nullptr;
     const int node_begin = as_const(a.group_begin)[g];
+    cx.pc_begin = node_begin;
     for (int64_t chunk = 0; chunk < a.nchunks; ++chunk) {
       const int64_t t0 = chunk * C::CHUNK;
       cx.t0 = t0;
@@ -646,10 +669,11 @@ static int device_cu_count() {
   return cus;
 }
 
-template <int E, int P, int LV, bool MULTI, bool VEC, bool W, int TEAM = 4, int MODE = 0>
+template <int E, int P, int LV, int MULTI, bool VEC, bool W, int TEAM = 4, int MODE = 0>
 static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
   using C = WalkCfg<E, P, LV, MULTI, VEC, W, TEAM, MODE>;
-  const size_t lds = ((size_t)a.R * C::CHUNK + 2 * C::NW) * sizeof(double);
+  const size_t lds = ((size_t)a.R * C::CHUNK + 2 * C::NW + (MULTI == 1 ? a.carry_slots : 0)) *
+                     sizeof(double);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static size_t lds_attr = 0;  // per instantiation
   if (lds > 64 * 1024 && lds > lds_attr) {

@@ -10,29 +10,32 @@ namespace fr {
 template <int P>
 static hipError_t team1_p(const IssArgs &a, int levels, hipStream_t st) {
   if (levels <= 2)
-    return a.aux ? launch_walk_cfg<2, P, 2, false, true, true, 1>(a, st)
-                 : launch_walk_cfg<2, P, 2, false, true, false, 1>(a, st);
-  return a.aux ? launch_walk_cfg<2, P, 4, false, true, true, 1>(a, st)
-               : launch_walk_cfg<2, P, 4, false, true, false, 1>(a, st);
+    return a.aux ? launch_walk_cfg<2, P, 2, 0, true, true, 1>(a, st)
+                 : launch_walk_cfg<2, P, 2, 0, true, false, 1>(a, st);
+  return a.aux ? launch_walk_cfg<2, P, 4, 0, true, true, 1>(a, st)
+               : launch_walk_cfg<2, P, 4, 0, true, false, 1>(a, st);
 }
 hipError_t walk_inst_team1(const IssArgs &a, int levels, int chunk, hipStream_t st) {
   return chunk == 512 ? team1_p<4>(a, levels, st) : team1_p<8>(a, levels, st);
 }
 #else
-template <int P, bool MULTI, bool VEC>
+template <int P, int MULTI, bool VEC>
 static hipError_t inst_w(const IssArgs &a, hipStream_t st) {
   return a.aux ? launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, true, 4, WALK_MODE>(a, st)
                : launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, false, 4, WALK_MODE>(a, st);
 }
 template <int P>
 static hipError_t inst_p(const IssArgs &a, hipStream_t st) {
-  const bool multi = a.nchunks > 1;
+  // carries of a multi-chunk walk live in LDS when the group's slots fit (see WalkCfg)
+  const int multi = a.nchunks > 1 ? (a.carry_in_lds ? 1 : 2) : 0;
 #if WALK_MODE == 1
   // no tensor stores in fused mode: the VEC template parameter is irrelevant
-  return multi ? inst_w<P, true, true>(a, st) : inst_w<P, false, true>(a, st);
+  if (multi == 1) return inst_w<P, 1, true>(a, st);
+  return multi == 2 ? inst_w<P, 2, true>(a, st) : inst_w<P, 0, true>(a, st);
 #else
-  if (multi) return a.vec_ok ? inst_w<P, true, true>(a, st) : inst_w<P, true, false>(a, st);
-  return a.vec_ok ? inst_w<P, false, true>(a, st) : inst_w<P, false, false>(a, st);
+  if (multi == 1) return a.vec_ok ? inst_w<P, 1, true>(a, st) : inst_w<P, 1, false>(a, st);
+  if (multi == 2) return a.vec_ok ? inst_w<P, 2, true>(a, st) : inst_w<P, 2, false>(a, st);
+  return a.vec_ok ? inst_w<P, 0, true>(a, st) : inst_w<P, 0, false>(a, st);
 #endif
 }
 #define WALK_CAT2(a, b, c, d) a##b##c##d
