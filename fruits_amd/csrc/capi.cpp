@@ -105,7 +105,7 @@ struct WorkLayout {
 WorkLayout work_layout(const fr::Plan &p, int64_t N, int64_t T, int64_t lookup_rows) {
   WorkLayout w;
   if (p.weighting != 0)
-    w.aux_bytes = align_up((size_t)(2 * p.alphas.size()) * (size_t)lookup_rows * (size_t)T * 8, 256);
+    w.aux_bytes = align_up((size_t)p.aux_tables() * (size_t)lookup_rows * (size_t)T * 8, 256);
   if (T > fr::walk_chunk_elems(T))
     w.carry_bytes = align_up((size_t)N * 2 * p.nodes.size() * 8, 256);
   return w;
@@ -272,6 +272,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   // of the scalar instructions, but only 2 waves/SIMD)
   const int team_env = env_int("FRUITS_HIP_TEAM", 0);
   const bool wave_rows = !fu && team_env == 1 && groups <= 0 && p.units() >= 4 &&
+                         p.semiring == fr::kSemiReals &&
                          fr::wave_rows_supported(T, p.levels, vec_ok_pre);
   const int G = wave_rows ? 4 : choose_groups(p, N, groups);
   fr::GroupedProgram &gp = fr::grouped(p, G);
@@ -298,7 +299,8 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   if (p.weighting != 0) {
     double *aux = reinterpret_cast<double *>(work);
     const int64_t count = lookup_rows * T;
-    hipError_t e = fr::launch_exp_tables(d_lookup, count, gp.d_alphas, (int)p.alphas.size(), aux, st);
+    hipError_t e = fr::launch_exp_tables(d_lookup, count, gp.d_alphas, (int)p.alphas.size(), aux,
+                                         p.semiring == fr::kSemiArctic, st);
     if (e != hipSuccess) return hip_fail(e, "exp_tables launch");
     a.aux = aux;
     a.aux_tab_stride = count;
@@ -317,6 +319,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   }
   a.persistent = env_int("FRUITS_HIP_PERSIST", 1);
   a.wave_rows = wave_rows ? 1 : 0;
+  a.semiring = p.semiring;
   {
     int max_nodes = 0;
     for (size_t g = 0; g + 1 < gp.group_begin.size(); ++g)
@@ -547,11 +550,12 @@ int fr_iterated_sum_fast_host(const double *h_Z, int64_t N, int64_t D, int64_t T
     return fail(FR_E_ARG, "fr_iterated_sum_fast_host: bad argument");
   if (extended < 1 || extended > L)
     return fail(FR_E_ARG, "fr_iterated_sum_fast_host: extended must be in [1, L]");
-  const int weighting = h_lookup ? (total_weighting ? FR_W_TOTAL : FR_W_NONTOTAL) : FR_W_NONE;
+  const int weighting = h_lookup ? ((total_weighting & 1) ? FR_W_TOTAL : FR_W_NONTOTAL) : FR_W_NONE;
+  const int plan_flags = (total_weighting & 2) ? FR_PLAN_ARCTIC : 0;
   if (weighting != FR_W_NONE && !alpha)
     return fail(FR_E_ARG, "fr_iterated_sum_fast_host: weighted call needs alpha");
   const int32_t depth = (int32_t)extended;
-  fr_plan_t *plan = fr_plan_create(1, word, &L, &Dw, alpha, &depth, weighting, 0);
+  fr_plan_t *plan = fr_plan_create(1, word, &L, &Dw, alpha, &depth, weighting, plan_flags);
   if (!plan) return FR_E_ARG;
   int rc = FR_OK;
   void *dZ = nullptr, *dL = nullptr, *dO = nullptr, *dW = nullptr;

@@ -47,6 +47,7 @@ struct IssArgs {
   int32_t persistent;       // grid = one resident round of workgroups
   int32_t carry_slots;      // 2 * (largest group's node count): LDS carry slots
   int32_t carry_in_lds;     // multi-chunk carries fit in LDS
+  int32_t semiring;         // kSemiReals / kSemiArctic
   int32_t wave_rows;        // TEAM = 1 kernel: one wave per row, 4 groups per workgroup
   // fused sieve epilogue (MODE 1 kernels): features instead of the (K,N,T) tensor
   const FeatOp *ops;        // (K, n_ops_padded) feature ops per output row, 64-byte aligned rows
@@ -65,7 +66,7 @@ hipError_t launch_mpi_finalize(double *feats, const double *cnt, int64_t N, int6
                                const int32_t *cols, int n_cols, int per_sum, int K,
                                hipStream_t st);
 hipError_t launch_exp_tables(const double *g, int64_t count, const float *alphas, int n_alpha,
-                             double *aux, hipStream_t st);
+                             double *aux, bool linear, hipStream_t st);
 hipError_t launch_increments(const double *X, int64_t rows, int64_t T, int64_t shift, double *out,
                              const double *head_src, int64_t head, hipStream_t st);
 hipError_t launch_pathlen_lookup(const double *X, int64_t N, int64_t D, int64_t T, int norm,

@@ -10,12 +10,17 @@ namespace fr {
 // ---------------------------------------------------------------- exp tables
 // aux[2a]   = exp( g * alpha_a)   (np.exp(weights * alpha[k]),  semiring.py:123,150)
 // aux[2a+1] = exp(-g * alpha_a)   (np.exp(-weights * alpha[k]), semiring.py:119,153,157)
+// Arctic (linear = 1): aux[a] = g * alpha_a   (weights * alpha[k], semiring.py:297,306,330)
 __global__ void exp_tables_kernel(const double *__restrict__ g, int64_t count,
                                   const float *__restrict__ alphas, int n_alpha,
-                                  double *__restrict__ aux) {
+                                  double *__restrict__ aux, int linear) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const double w = g[i];
+  if (linear) {
+    for (int a = 0; a < n_alpha; ++a) aux[(int64_t)a * count + i] = w * (double)alphas[a];
+    return;
+  }
   for (int a = 0; a < n_alpha; ++a) {
     const double al = (double)alphas[a];
     aux[(int64_t)(2 * a) * count + i] = exp(w * al);
@@ -312,11 +317,11 @@ hipError_t launch_mpi_finalize(double *feats, const double *cnt, int64_t N, int6
 }
 
 hipError_t launch_exp_tables(const double *g, int64_t count, const float *alphas, int n_alpha,
-                             double *aux, hipStream_t st) {
+                             double *aux, bool linear, hipStream_t st) {
   if (count <= 0 || n_alpha <= 0) return hipSuccess;
   const int bs = 256;
   hipLaunchKernelGGL(exp_tables_kernel, dim3((unsigned)((count + bs - 1) / bs)), dim3(bs), 0, st,
-                     g, count, alphas, n_alpha, aux);
+                     g, count, alphas, n_alpha, aux, linear ? 1 : 0);
   return hipGetLastError();
 }
 

@@ -51,6 +51,7 @@ struct Builder {
   }
   int row_plus(uint32_t bits) { return p->dims_used + 2 * alpha_id(bits); }
   int row_minus(uint32_t bits) { return p->dims_used + 2 * alpha_id(bits) + 1; }
+  int row_lin(uint32_t bits) { return p->dims_used + alpha_id(bits); }  // Arctic: g*alpha
 
   void emit_node(int t, int level, int chain, int unit) {
     const TrieNode &tn = trie[t];
@@ -62,6 +63,23 @@ struct Builder {
     nd.z_mul = -1;
     const bool weighted = p->weighting != 0;
     const bool has_parent = tn.depth > 1;
+    if (p->semiring == kSemiArctic) {
+      // (max, +), fruits/iss/semiring.py:282-338: tmp += el * Z[dim] per dimension;
+      // non-total: then tmp -= g*alpha_{k-1}, emit cummax(tmp), children scan tmp + g*alpha_k;
+      // total: tmp -= g*alpha_{k-1} (end of the previous letter), letters, tmp += g*alpha_k,
+      //        cummax, emit tmp - g*alpha_k
+      if (weighted && p->weighting == 2 && has_parent)
+        p->factors.push_back(fac_arctic(row_lin(trie[tn.parent].alpha_bits), -1));
+      for (size_t d = 0; d < tn.exps.size(); ++d)
+        if (tn.exps[d] != 0) p->factors.push_back(fac_arctic(dim_row[(int)d], tn.exps[d]));
+      if (weighted && p->weighting == 1) {
+        if (has_parent) p->factors.push_back(fac_arctic(row_lin(trie[tn.parent].alpha_bits), -1));
+        if (!tn.children.empty()) nd.z_mul = row_lin(tn.alpha_bits);
+      } else if (weighted) {
+        p->factors.push_back(fac_arctic(row_lin(tn.alpha_bits), 1));
+        nd.emit_mul = row_lin(tn.alpha_bits);
+      }
+    } else {
     // total weighting: the factor exp(-g*alpha_{k-1}) is applied right after the
     // shift, before the letters (fruits/iss/semiring.py:154-157, then :143-149)
     if (weighted && p->weighting == 2 && has_parent)
@@ -81,6 +99,7 @@ struct Builder {
       // (semiring.py:150-153)
       p->factors.push_back(row_plus(tn.alpha_bits));
       nd.emit_mul = row_minus(tn.alpha_bits);
+    }
     }
     nd.fac_count = (int32_t)p->factors.size() - nd.fac_begin;
     nd.emit_begin = (int32_t)p->emit_rows.size();
@@ -134,6 +153,7 @@ Plan *build_plan(int W, const int32_t *exps, const int32_t *L, const int32_t *Dw
     Plan *p = new Plan();
     p->W = W;
     p->weighting = weighting;
+    p->semiring = (flags & 2) ? kSemiArctic : kSemiReals;
     p->shared = share;
     Builder b;
     b.p = p;
@@ -203,10 +223,7 @@ Plan *build_plan(int W, const int32_t *exps, const int32_t *L, const int32_t *Dw
     // register all alphas up front so LDS row numbers are final before emission
     if (weighting)
       for (size_t t = 1; t < b.trie.size(); ++t) b.alpha_id(b.trie[t].alpha_bits);
-    for (size_t j = 0; j < p->alphas.size(); ++j) {
-      p->row_src.push_back(-(int32_t)(1 + 2 * j));
-      p->row_src.push_back(-(int32_t)(2 + 2 * j));
-    }
+    for (int j = 0; j < p->aux_tables(); ++j) p->row_src.push_back(-(int32_t)(1 + j));
 
     // DFS program, one unit per root child
     p->unit_begin.push_back(0);
@@ -263,11 +280,12 @@ GroupedProgram &grouped(Plan &p, int G) {
         NodeRec r{};
         bool slow = nd.fac_count > kRecInlineFactors;
         for (int j = 0; j < nd.fac_count; ++j)
-          if (p.factors[nd.fac_begin + j] & FAC_DIV) slow = true;
+          if (p.semiring == kSemiReals && (p.factors[nd.fac_begin + j] & FAC_DIV)) slow = true;
         r.w[0] = (nd.level & 0xff) | (((nd.flags | (slow ? F_SLOW : 0)) & 0xff) << 8);
         r.w[1] = nd.fac_count;
         for (int j = 0; j < kRecInlineFactors && j < nd.fac_count; ++j)
-          r.w[2 + j] = p.factors[nd.fac_begin + j] & FAC_ROW_MASK;
+          r.w[2 + j] = p.semiring == kSemiReals ? (p.factors[nd.fac_begin + j] & FAC_ROW_MASK)
+                                                : p.factors[nd.fac_begin + j];
         r.w[6] = nd.emit_count;
         for (int j = 0; j < kRecInlineEmits && j < nd.emit_count; ++j)
           r.w[7 + j] = p.emit_rows[nd.emit_begin + j];

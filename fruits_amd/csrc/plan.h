@@ -17,9 +17,13 @@ namespace fr {
 // node flags
 constexpr int32_t F_CHAIN = 1;     // only child: processed in place in its parent's frame
 constexpr int32_t F_CHILDREN = 2;  // the exclusive prefix of this node is consumed by children
-// factor code: LDS row in the low 7 bits, bit 7 = divide instead of multiply
+// factor code: LDS row in the low 7 bits.  Reals: bit 7 = divide instead of multiply
+// (one code per occurrence of a letter).  Arctic: bits 8-15 = signed multiplier el of
+// the ADDED term el * row (one code per dimension of the extended letter).
 constexpr int32_t FAC_DIV = 0x80;
 constexpr int32_t FAC_ROW_MASK = 0x7f;
+constexpr int kSemiReals = 0, kSemiArctic = 1;
+constexpr int32_t fac_arctic(int row, int el) { return row | ((el & 0xff) << 8); }
 
 constexpr int kMaxLevels = 8;   // deepest register-frame stack a kernel variant supports
 
@@ -69,6 +73,7 @@ struct GroupedProgram {       // node order for one choice of G (groups per seri
 struct Plan {
   int W = 0;
   int weighting = 0;
+  int semiring = kSemiReals;
   bool shared = true;
   int K = 0;                 // output rows
   int levels = 0;            // register frames needed
@@ -80,7 +85,10 @@ struct Plan {
   std::vector<int32_t> factors;
   std::vector<int32_t> emit_rows;
   std::vector<int32_t> row_src;      // LDS row -> source: d (>=0) = X dimension d, -(1+j) = aux table j
-  std::vector<float> alphas;         // distinct alphas; aux table 2a = exp(+g*alpha_a), 2a+1 = exp(-g*alpha_a)
+  // distinct alphas.  Reals: aux table 2a = exp(+g*alpha_a), 2a+1 = exp(-g*alpha_a);
+  // Arctic: aux table a = g*alpha_a
+  std::vector<float> alphas;
+  int aux_tables() const { return (int)alphas.size() * (semiring == kSemiArctic ? 1 : 2); }
   int dims_used = 0;
   std::map<int, GroupedProgram> programs;  // per G
   int device = -1;

@@ -27,8 +27,11 @@ namespace fr {
 // every piece.  So every 16-byte global access of a wave is lane-contiguous
 // (E = 2: 1 KiB per instruction) and only NW wave totals cross waves.
 template <int E_, int P_, int MAXLV_, int MULTI_, bool VEC_, bool WEIGHTED_, int TEAM_ = 4,
-          int MODE_ = 0>
+          int MODE_ = 0, int SEMI_ = 0>
 struct WalkCfg {
+  // SEMI 0: Reals (+, x) with an exclusive shift between letters; SEMI 1: Arctic
+  // (max, +), letters add el * x and children continue from the INCLUSIVE maximum
+  static constexpr int SEMI = SEMI_;
   // MODE 0: write the (K,N,T) tensor.  MODE 1: fused sieve epilogue - the values of
   // a node go straight into NPI / MPI / END features, no tensor is written.
   static constexpr int MODE = MODE_;
@@ -144,34 +147,34 @@ __device__ __forceinline__ void block_scan(WalkCtx &cx, const double (&s)[C::EP]
   for (int h = 0; h < P; ++h) {
     l[h * E] = s[h * E];
 #pragma unroll
-    for (int e = 1; e < E; ++e) l[h * E + e] = l[h * E + e - 1] + s[h * E + e];
+    for (int e = 1; e < E; ++e) l[h * E + e] = semi_add<C::SEMI>(l[h * E + e - 1], s[h * E + e]);
   }
 #pragma unroll
   for (int h = 0; h < P; ++h) incl[h] = l[h * E + E - 1];
-  wave_inclusive_scan_multi<P>(incl);
+  wave_inclusive_scan_multi<P, C::SEMI>(incl);
 #pragma unroll
   for (int h = 0; h < P; ++h) {
-    excl[h] = wave_shift_right1(incl[h]);
+    excl[h] = wave_shift_right1<C::SEMI>(incl[h]);
     ptot[h] = wave_last_lane(incl[h]);
   }
-  double carry_in = 0.0;
+  double carry_in = semi_zero<C::SEMI>();
   if constexpr (C::MULTI != 0) {
     if (!cx.first_chunk) carry_in = cx.carry[carry_slot];
   }
-  double base = 0.0;
+  double base = semi_zero<C::SEMI>();
   if constexpr (NW == 1) {
     STAMP(cx, 2);  // local sums + wave scans
     if constexpr (C::MULTI != 0) {
       double total = ptot[0];
 #pragma unroll
-      for (int h = 1; h < P; ++h) total += ptot[h];
+      for (int h = 1; h < P; ++h) total = semi_add<C::SEMI>(total, ptot[h]);
       base = carry_in;
-      if (cx.lane == 0) cx.carry[carry_slot] = carry_in + total;
+      if (cx.lane == 0) cx.carry[carry_slot] = semi_add<C::SEMI>(carry_in, total);
     }
   } else {
     double wave_total = ptot[0];
 #pragma unroll
-    for (int h = 1; h < P; ++h) wave_total += ptot[h];
+    for (int h = 1; h < P; ++h) wave_total = semi_add<C::SEMI>(wave_total, ptot[h]);
     STAMP(cx, 2);  // local sums + wave scans
     double *tot = cx.tot + cx.buf * NW;
     if (cx.lane == 0) tot[cx.wave] = wave_total;
@@ -180,17 +183,19 @@ __device__ __forceinline__ void block_scan(WalkCtx &cx, const double (&s)[C::EP]
     // exclusive prefix of the wave totals
     static_assert(NW == 1 || NW == 4, "cross-wave prefix is written for 4 waves");
     const double t0 = tot[0], t1 = tot[1], t2 = tot[2], t3 = tot[3];
-    const double p2 = t0 + t1, p3 = p2 + t2;
-    base = cx.wave == 0 ? 0.0 : (cx.wave == 1 ? t0 : (cx.wave == 2 ? p2 : p3));
+    const double p2 = semi_add<C::SEMI>(t0, t1), p3 = semi_add<C::SEMI>(p2, t2);
+    base = cx.wave == 0 ? semi_zero<C::SEMI>() : (cx.wave == 1 ? t0 : (cx.wave == 2 ? p2 : p3));
     cx.buf ^= 1;
     if constexpr (C::MULTI == 1) {
       // LDS carry: every wave read it before the barrier above; one lane updates it
-      base += carry_in;
-      if (cx.wave == 0 && cx.lane == 0) cx.carry[carry_slot] = carry_in + (p3 + t3);
+      base = semi_add<C::SEMI>(base, carry_in);
+      if (cx.wave == 0 && cx.lane == 0)
+        cx.carry[carry_slot] = semi_add<C::SEMI>(carry_in, semi_add<C::SEMI>(p3, t3));
     } else if constexpr (C::MULTI == 2) {
-      base += carry_in;
+      base = semi_add<C::SEMI>(base, carry_in);
       // every wave stores the same value; a wave only ever re-reads its own store
-      if (cx.lane == 0) cx.carry[carry_slot] = carry_in + (p3 + t3);
+      if (cx.lane == 0)
+        cx.carry[carry_slot] = semi_add<C::SEMI>(carry_in, semi_add<C::SEMI>(p3, t3));
     }
   }
   // The last value of a lane is formed as base + (inclusive wave scan), the first
@@ -200,15 +205,15 @@ __device__ __forceinline__ void block_scan(WalkCtx &cx, const double (&s)[C::EP]
   // running sum absorbs is exactly 0, as in a sequential cumsum).
 #pragma unroll
   for (int h = 0; h < P; ++h) {
-    const double off = base + excl[h];
+    const double off = semi_add<C::SEMI>(base, excl[h]);
     x[h * E] = off;
 #pragma unroll
     for (int e = 0; e + 1 < E; ++e) {
-      c[h * E + e] = off + l[h * E + e];
+      c[h * E + e] = semi_add<C::SEMI>(off, l[h * E + e]);
       x[h * E + e + 1] = c[h * E + e];
     }
-    c[h * E + E - 1] = base + incl[h];
-    base += ptot[h];
+    c[h * E + E - 1] = semi_add<C::SEMI>(base, incl[h]);
+    base = semi_add<C::SEMI>(base, ptot[h]);
   }
   STAMP(cx, 4);  // cross-wave prefix + final adds
 }
@@ -265,12 +270,25 @@ __device__ __forceinline__ Rec load_rec(const NodeRec *recs, int pc) {
   return r;
 }
 
+// s (x)= factor.  Reals: s *= row.  Arctic: s += el * row with the multiplier in bits
+// 8-15 of the code; the product is rounded before the add like the reference's
+// `tmp + el * Z[dim]` (no fused multiply-add), so max-plus results are bit-exact.
 template <class C>
-__device__ __forceinline__ void mul_row(const WalkCtx &cx, int row, double (&s)[C::EP]) {
+__device__ __forceinline__ void mul_row(const WalkCtx &cx, int code, double (&s)[C::EP]) {
   double v[C::EP];
-  read_row<C>(cx, row, v);
+  read_row<C>(cx, code & FAC_ROW_MASK, v);
+  if constexpr (C::SEMI == 0) {
 #pragma unroll
-  for (int i = 0; i < C::EP; ++i) s[i] = s[i] * v[i];
+    for (int i = 0; i < C::EP; ++i) s[i] = s[i] * v[i];
+  } else {
+#pragma clang fp contract(off)  // the product must round before the add (no FMA)
+    const double el = (double)(int)(int8_t)((code >> 8) & 0xff);
+#pragma unroll
+    for (int i = 0; i < C::EP; ++i) {
+      const double prod = el * v[i];
+      s[i] = s[i] + prod;
+    }
+  }
 }
 
 // Letters with a reciprocal factor or more than kRecInlineFactors factors: walk
@@ -280,6 +298,10 @@ __device__ __forceinline__ void slow_factors(const WalkCtx &cx, int fac_begin, i
                                           double (&s)[C::EP]) {
   for (int f = 0; f < nf; ++f) {
     const int code = as_const(cx.a->factors)[fac_begin + f];
+    if constexpr (C::SEMI != 0) {
+      mul_row<C>(cx, code, s);
+      continue;
+    }
     double v[C::EP];
     read_row<C>(cx, code & FAC_ROW_MASK, v);
     if (code & FAC_DIV) {
@@ -440,17 +462,22 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd, int slo
   if (need1) {
     double c[EP], x[EP];
     block_scan<C>(cx, s, c, x, slot);
+    if (has_children && !need2) {
+      // Reals: children start from the exclusive shift (strictly increasing indices);
+      // Arctic: from the inclusive maximum (semiring.py:282-338 has no shift).  Taken
+      // BEFORE the emitted values are rescaled in place below.
+#pragma unroll
+      for (int i = 0; i < EP; ++i) pout[i] = C::SEMI == 0 ? x[i] : c[i];
+    }
     if (nd.emit_count() > 0) {
-      if (C::WEIGHTED && emit_mul >= 0) mul_row<C>(cx, emit_mul, c);
+      // total weighting: Reals emit c * exp(-g alpha_k), Arctic emit c - g alpha_k
+      if (C::WEIGHTED && emit_mul >= 0)
+        mul_row<C>(cx, C::SEMI == 0 ? emit_mul : fac_arctic(emit_mul, -1), c);
       if constexpr (C::MODE == 1)
         fused_all<C>(cx, nd, pre, c, x);
       else
         emit_all<C>(cx, nd, c);
       STAMP(cx, 5);  // stores
-    }
-    if (has_children && !need2) {
-#pragma unroll
-      for (int i = 0; i < EP; ++i) pout[i] = x[i];
     }
   }
   if constexpr (C::WEIGHTED) {
@@ -458,10 +485,10 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd, int slo
       double s2[EP], c[EP], x[EP];
 #pragma unroll
       for (int i = 0; i < EP; ++i) s2[i] = s[i];
-      mul_row<C>(cx, z_mul, s2);
+      mul_row<C>(cx, C::SEMI == 0 ? z_mul : fac_arctic(z_mul, 1), s2);
       block_scan<C>(cx, s2, c, x, slot + 1);
 #pragma unroll
-      for (int i = 0; i < EP; ++i) pout[i] = x[i];
+      for (int i = 0; i < EP; ++i) pout[i] = C::SEMI == 0 ? x[i] : c[i];
     }
   }
 }
@@ -637,9 +664,9 @@ __global__ __launch_bounds__(kWalkThreads) void iss_walk_kernel(const IssArgs a)
       }
       __syncthreads();
       STAMP(cx, 6);  // staging
-      double ones[C::EP];
+      double ones[C::EP];  // identity of the semiring's product: 1 (Reals), 0 (Arctic)
 #pragma unroll
-      for (int i = 0; i < C::EP; ++i) ones[i] = 1.0;
+      for (int i = 0; i < C::EP; ++i) ones[i] = C::SEMI == 0 ? 1.0 : 0.0;
       int pc = node_begin;
       Rec cur = load_rec(a.recs, pc);
       walk<C, 0>(cx, cur, pc, ones);
@@ -669,9 +696,10 @@ static int device_cu_count() {
   return cus;
 }
 
-template <int E, int P, int LV, int MULTI, bool VEC, bool W, int TEAM = 4, int MODE = 0>
+template <int E, int P, int LV, int MULTI, bool VEC, bool W, int TEAM = 4, int MODE = 0,
+          int SEMI = 0>
 static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
-  using C = WalkCfg<E, P, LV, MULTI, VEC, W, TEAM, MODE>;
+  using C = WalkCfg<E, P, LV, MULTI, VEC, W, TEAM, MODE, SEMI>;
   const size_t lds = ((size_t)a.R * C::CHUNK + 2 * C::NW + (MULTI == 1 ? a.carry_slots : 0)) *
                      sizeof(double);
   if (lds > 160 * 1024) return hipErrorInvalidValue;

@@ -21,6 +21,9 @@ hipError_t walk_inst_team1(const IssArgs &a, int levels, int chunk, hipStream_t 
 #else
 template <int P, int MULTI, bool VEC>
 static hipError_t inst_w(const IssArgs &a, hipStream_t st) {
+  if (a.semiring == kSemiArctic)
+    return a.aux ? launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, true, 4, WALK_MODE, 1>(a, st)
+                 : launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, false, 4, WALK_MODE, 1>(a, st);
   return a.aux ? launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, true, 4, WALK_MODE>(a, st)
                : launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, false, 4, WALK_MODE>(a, st);
 }

@@ -19,51 +19,67 @@ __device__ __forceinline__ cptr<T> as_const(const T *p) {
 }
 
 // ---------------------------------------------------------------- wave scan
-// DPP fetch of a double: the value of the source lane, 0.0 where the lane has no
-// source.  FULL = all rows enabled: bound_ctrl supplies the zeros and no "old"
-// value has to be materialised; otherwise disabled rows keep old = 0.
-template <int CTRL, int ROW_MASK>
+// The scan is written for both semirings: SEMI 0 = Reals (the "sum" is +, identity
+// 0.0), SEMI 1 = Arctic (the "sum" is max, identity -inf).
+template <int SEMI>
+__device__ __forceinline__ double semi_add(double a, double b) {
+  if constexpr (SEMI == 0) return a + b;
+  return fmax(a, b);
+}
+template <int SEMI>
+__device__ __forceinline__ double semi_zero() {
+  if constexpr (SEMI == 0) return 0.0;
+  return -__builtin_inf();
+}
+
+// DPP fetch of a double: the value of the source lane, the identity where the lane
+// has no source.  Reals with all rows enabled: bound_ctrl supplies the zeros and no
+// "old" value has to be materialised; otherwise lanes without a source keep old.
+template <int CTRL, int ROW_MASK, int SEMI = 0>
 __device__ __forceinline__ double dpp_fetch(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  if constexpr (ROW_MASK == 0xf) {
+  if constexpr (SEMI == 0 && ROW_MASK == 0xf) {
     lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   } else {
+    constexpr int id_hi = SEMI == 0 ? 0 : (int)0xfff00000;  // high word of -inf
     lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(id_hi, hi, CTRL, ROW_MASK, 0xf, false);
   }
   return __hiloint2double(hi, lo);
 }
 
+template <int SEMI = 0>
 __device__ __forceinline__ double wave_inclusive_scan(double v) {
-  v += dpp_fetch<0x111, 0xf>(v);  // row_shr:1
-  v += dpp_fetch<0x112, 0xf>(v);  // row_shr:2
-  v += dpp_fetch<0x114, 0xf>(v);  // row_shr:4
-  v += dpp_fetch<0x118, 0xf>(v);  // row_shr:8
-  v += dpp_fetch<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
-  v += dpp_fetch<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
+  v = semi_add<SEMI>(v, dpp_fetch<0x111, 0xf, SEMI>(v));  // row_shr:1
+  v = semi_add<SEMI>(v, dpp_fetch<0x112, 0xf, SEMI>(v));  // row_shr:2
+  v = semi_add<SEMI>(v, dpp_fetch<0x114, 0xf, SEMI>(v));  // row_shr:4
+  v = semi_add<SEMI>(v, dpp_fetch<0x118, 0xf, SEMI>(v));  // row_shr:8
+  v = semi_add<SEMI>(v, dpp_fetch<0x142, 0xa, SEMI>(v));  // row_bcast:15 -> rows 1,3
+  v = semi_add<SEMI>(v, dpp_fetch<0x143, 0xc, SEMI>(v));  // row_bcast:31 -> rows 2,3
   return v;
 }
 
 // P independent scans, advanced step by step so their DPP latencies overlap
-template <int P>
+template <int P, int SEMI = 0>
 __device__ __forceinline__ void wave_inclusive_scan_multi(double (&v)[P]) {
 #pragma unroll
-  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x111, 0xf>(v[h]);
+  for (int h = 0; h < P; ++h) v[h] = semi_add<SEMI>(v[h], dpp_fetch<0x111, 0xf, SEMI>(v[h]));
 #pragma unroll
-  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x112, 0xf>(v[h]);
+  for (int h = 0; h < P; ++h) v[h] = semi_add<SEMI>(v[h], dpp_fetch<0x112, 0xf, SEMI>(v[h]));
 #pragma unroll
-  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x114, 0xf>(v[h]);
+  for (int h = 0; h < P; ++h) v[h] = semi_add<SEMI>(v[h], dpp_fetch<0x114, 0xf, SEMI>(v[h]));
 #pragma unroll
-  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x118, 0xf>(v[h]);
+  for (int h = 0; h < P; ++h) v[h] = semi_add<SEMI>(v[h], dpp_fetch<0x118, 0xf, SEMI>(v[h]));
 #pragma unroll
-  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x142, 0xa>(v[h]);
+  for (int h = 0; h < P; ++h) v[h] = semi_add<SEMI>(v[h], dpp_fetch<0x142, 0xa, SEMI>(v[h]));
 #pragma unroll
-  for (int h = 0; h < P; ++h) v[h] += dpp_fetch<0x143, 0xc>(v[h]);
+  for (int h = 0; h < P; ++h) v[h] = semi_add<SEMI>(v[h], dpp_fetch<0x143, 0xc, SEMI>(v[h]));
 }
 
+template <int SEMI = 0>
 __device__ __forceinline__ double wave_shift_right1(double v) {
-  return dpp_fetch<0x138, 0xf>(v);  // wave_shr:1, lane 0 gets 0.0
+  return dpp_fetch<0x138, 0xf, SEMI>(v);  // wave_shr:1, lane 0 gets the identity
 }
 
 __device__ __forceinline__ double wave_last_lane(double v) {

@@ -66,7 +66,10 @@ class ISS(Seed):
                 and self.mode == ISSMode.SINGLE:
             raise NotImplementedError(
                 "Arctic argmax is not implemented when using ISSMode.SINGLE")
-        if not isinstance(self.semiring, Reals):
+        if isinstance(self.semiring, Arctic):
+            if self.semiring._argmax:
+                raise NotImplementedError("Arctic argmax is not on the MI355X path")
+        elif not isinstance(self.semiring, Reals):
             raise NotImplementedError(
                 f"semiring {type(self.semiring).__name__} is not on the MI355X hot path")
         for w in self.words:
@@ -88,12 +91,13 @@ class ISS(Seed):
         else:
             wmode = nat.FR_W_TOTAL if self.weighting.total else nat.FR_W_NONTOTAL
             alphas = [np.asarray(self.words[i].alpha, dtype=np.float32) for i in indices]
-        key = (indices, self.mode, wmode,
+        arctic = isinstance(self.semiring, Arctic)
+        key = (indices, self.mode, wmode, arctic,
                None if alphas is None else tuple(a.tobytes() for a in alphas))
         plan = self._plans.get(key)
         if plan is None:
             plan = nat.Plan([self.words[i].table() for i in indices],
-                            [self._depth(i) for i in indices], alphas, wmode)
+                            [self._depth(i) for i in indices], alphas, wmode, arctic=arctic)
             self._plans[key] = plan
         return plan
 

@@ -4,7 +4,8 @@
 is the reference's per-word operator; :class:`Reals` implements it with the HIP
 trie-walk kernel through the C ABI (``fr_iterated_sum_fast_host``).  The batched
 device path used by :class:`fruits_amd.ISS` goes through the same kernel for all
-words at once.  Arctic and Bayesian are outside the MI355X hot path.
+words at once.  Arctic (a "next" row of the scope table) runs on the same kernel;
+Bayesian is outside the MI355X path.
 """
 from __future__ import annotations
 
@@ -62,11 +63,24 @@ class Reals(Semiring):
 
 
 class Arctic(Semiring):
+    """(R u {-inf}, max, +): letters add ``el * Z[dim]``, the scan is a running
+    maximum and - unlike Reals - there is no shift between letters
+    (fruits/iss/semiring.py:282-400).  Same HIP kernel with the scan operator and
+    the letter operation exchanged; results are bit-exact (max is associative).
+    ``argmax=True`` is outside the MI355X path."""
+
     def __init__(self, argmax: bool = False) -> None:
         self._argmax = argmax
 
-    def iterated_sum_fast(self, *args, **kwargs):
-        raise NotImplementedError("the Arctic semiring is not on the MI355X hot path yet")
+    def iterated_sum_fast(self, Z, word, alpha, lookup, extended, total_weighting):
+        if self._argmax:
+            raise NotImplementedError("Arctic argmax is not on the MI355X path")
+        Z = _check_input(Z)
+        word = np.asarray(word, dtype=np.int32)
+        if lookup is not None and not np.any(lookup) and (alpha is None or not np.any(alpha)):
+            lookup = None
+        return nat.iterated_sum_fast_host(Z, word, alpha, lookup, extended, total_weighting,
+                                          arctic=True)
 
 
 class Bayesian(Semiring):

@@ -44,6 +44,9 @@ extern "C" {
 /* plan flags */
 #define FR_PLAN_SHARE_PREFIXES 1 /* walk the prefix trie (K scans); 0 = one chain
                                     per word, prefixes recomputed like the reference */
+#define FR_PLAN_ARCTIC 2         /* (max, +) semiring instead of (+, x):
+                                    Arctic._iterated_sum_fast, fruits/iss/semiring.py:282-400
+                                    (argmax=False); "next" row of SURVEY.md 8f */
 
 /* fr_plan_info selectors */
 #define FR_INFO_ROWS 0       /* K = number of output rows (iterated sums)        */
@@ -131,7 +134,8 @@ int fr_iss_run(fr_plan_t *plan, const double *d_X, int64_t N, int64_t D, int64_t
  * host arrays in, host array out, synchronous:
  *   Z (N,D,T) f64, word (L,Dw) i32, alpha (L) f32, lookup (N,T) f64 or NULL
  *   (NULL = the unweighted call of semiring.py:27-28), extended in [1,L],
- *   total_weighting -> out (N, extended, T) f64 (caller allocated). */
+ *   total_weighting (bit 0; bit 1 set = Arctic semiring, semiring.py:354-400)
+ *   -> out (N, extended, T) f64 (caller allocated). */
 int fr_iterated_sum_fast_host(const double *h_Z, int64_t N, int64_t D, int64_t T,
                               const int32_t *word, int32_t L, int32_t Dw,
                               const float *alpha, const double *h_lookup,

@@ -52,7 +52,7 @@ def num_threads() -> int:
     return int(lib().orc_num_threads())
 
 
-def iterated_sum_fast(Z, word, alpha, lookup, extended, total, nthreads=0):
+def iterated_sum_fast(Z, word, alpha, lookup, extended, total, nthreads=0, semiring="Reals"):
     Z = np.ascontiguousarray(Z, dtype=np.float64)
     word = np.ascontiguousarray(word, dtype=np.int32)
     alpha = np.ascontiguousarray(alpha, dtype=np.float32)
@@ -66,14 +66,15 @@ def iterated_sum_fast(Z, word, alpha, lookup, extended, total, nthreads=0):
         _p(Z, _dp), C.c_int64(N), C.c_int64(D), C.c_int64(T), _p(word, _ip),
         C.c_int(L), C.c_int(Dw), _p(alpha, _fp),
         _p(lk, _dp) if lk is not None else None, C.c_int64(extended),
-        C.c_int(1 if total else 0), _p(out, _dp), C.c_int(nthreads))
+        C.c_int((1 if total else 0) | (2 if semiring == "Arctic" else 0)), _p(out, _dp),
+        C.c_int(nthreads))
     if rc != 0:
         raise ValueError("orc_iterated_sum_fast: bad arguments")
     return out
 
 
 def iss_transform(X, word_strings, mode="SINGLE", alphas=None, lookup=None,
-                  total=False, nthreads=0, out=None):
+                  total=False, nthreads=0, out=None, semiring="Reals"):
     """Same contract as ref_numpy.iss_transform -> (K, N, T)."""
     X = np.ascontiguousarray(X, dtype=np.float64)
     N, D, T = X.shape
@@ -111,7 +112,8 @@ def iss_transform(X, word_strings, mode="SINGLE", alphas=None, lookup=None,
         _p(exps, _ip), _p(word_off, _lp), _p(Ls, _ip), _p(Dws, _ip),
         _p(alpha, _fp) if alpha is not None else None, _p(alpha_off, _lp),
         _p(depth, _ip), _p(lk, _dp) if lk is not None else None,
-        C.c_int(1 if total else 0), _p(out, _dp), C.c_int(nthreads))
+        C.c_int((1 if total else 0) | (2 if semiring == "Arctic" else 0)), _p(out, _dp),
+        C.c_int(nthreads))
     if rc != 0:
         raise ValueError("orc_iss_batch: word dimension exceeds input dimension")
     return out

@@ -121,6 +121,51 @@ static void single_unweighted(const double *Z, int64_t T, const int32_t *word, i
     }
 }
 
+/* Arctic semiring (max, +): fruits/iss/semiring.py:282-309 (_arctic_single) and
+ * :317-338 (_total_weighted_arctic_single).  Letters ADD el * Z[dim]; the scan is a
+ * running maximum; there is no shift between letters.  w == NULL: unweighted call
+ * (alpha = 0, lookup = 0, total branch, semiring.py:27-35) - adding 0.0 is skipped. */
+static void cummax(double *v, int64_t T)
+{
+    for (int64_t t = 1; t < T; ++t) v[t] = v[t - 1] > v[t] ? v[t - 1] : v[t];
+}
+
+static void single_arctic(const double *Z, int64_t T, const int32_t *word, int L, int Dw,
+                          const float *alpha, const double *w, int total, int E, double *out,
+                          double *tmp)
+{
+    for (int64_t t = 0; t < T; ++t) tmp[t] = 0.0;
+    for (int k = 0; k < L; ++k) {
+        for (int d = 0; d < Dw; ++d) {
+            double el = (double)word[k * Dw + d];
+            const double *z = Z + (int64_t)d * T;
+            for (int64_t t = 0; t < T; ++t) tmp[t] = tmp[t] + el * z[t];
+        }
+        double *o = (L - k <= E) ? out + (int64_t)(E - (L - k)) * T : NULL;
+        if (w == NULL || total) {
+            double a = w ? (double)alpha[k] : 0.0;
+            if (w) for (int64_t t = 0; t < T; ++t) tmp[t] = tmp[t] + w[t] * a;
+            cummax(tmp, T);
+            if (o) for (int64_t t = 0; t < T; ++t) o[t] = w ? tmp[t] - w[t] * a : tmp[t];
+            if (k < L - 1 && w) for (int64_t t = 0; t < T; ++t) tmp[t] = tmp[t] - w[t] * a;
+        } else {
+            if (k > 0) {
+                double a = (double)alpha[k - 1];
+                for (int64_t t = 0; t < T; ++t) tmp[t] = tmp[t] - w[t] * a;
+            }
+            if (o) {
+                o[0] = tmp[0];
+                for (int64_t t = 1; t < T; ++t) o[t] = o[t - 1] > tmp[t] ? o[t - 1] : tmp[t];
+            }
+            if (k < L - 1) {
+                double a = (double)alpha[k];
+                for (int64_t t = 0; t < T; ++t) tmp[t] = tmp[t] + w[t] * a;
+                cummax(tmp, T);
+            }
+        }
+    }
+}
+
 /* Z (N,D,T); word (L,Dw); alpha (L); lookup (N,T) or NULL (= unweighted);
  * out (N,E,T) with arbitrary strides so the batch entry can write (K,N,T). */
 static void iterated_sum_fast_strided(const double *Z, int64_t N, int64_t D, int64_t T,
@@ -130,6 +175,8 @@ static void iterated_sum_fast_strided(const double *Z, int64_t N, int64_t D, int
                                       int64_t out_n_stride, int64_t out_e_stride,
                                       int nthreads)
 {
+    const int arctic = total & 2; /* bit 1 selects the Arctic semiring */
+    total &= 1;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
@@ -141,7 +188,10 @@ static void iterated_sum_fast_strided(const double *Z, int64_t N, int64_t D, int
         for (int64_t j = 0; j < N; ++j) {
             const double *Zj = Z + j * D * T;
             memset(res, 0, (size_t)T * (size_t)E * sizeof(double));
-            if (lookup == NULL)
+            if (arctic)
+                single_arctic(Zj, T, word, L, Dw, alpha, lookup ? lookup + j * T : NULL, total,
+                              E, res, tmp);
+            else if (lookup == NULL)
                 single_unweighted(Zj, T, word, L, Dw, E, res, tmp);
             else if (total)
                 single_total(Zj, T, word, L, Dw, alpha, lookup + j * T, E, res, tmp);

@@ -279,7 +279,41 @@ def iterated_sum_fast(Z, word, alpha, lookup, extended, total_weighting):
     return out
 
 
-def iterated_sums(Z, word_rows, alpha=None, lookup=None, extended=1, total=False):
+def arctic_iterated_sum_fast(Z, word, alpha, lookup, extended, total_weighting):
+    """fruits/iss/semiring.py:354-400 (Arctic._iterated_sum_fast, argmax=False) with
+    its bodies ``_arctic_single`` (:282-309) and ``_total_weighted_arctic_single``
+    (:317-338), vectorised over N.  (max, +): letters ADD ``el * Z[dim]``, the scan
+    is a running maximum, and there is no shift between letters."""
+    N, _, T = Z.shape
+    L = len(word)
+    word = np.asarray(word, dtype=np.int32).reshape(L, -1)
+    alpha = np.asarray(alpha, dtype=np.float32)
+    lookup = lookup[:N]
+    out = np.zeros((N, extended, T))
+    tmp = np.zeros((N, T))
+    for k in range(L):
+        for d, el in enumerate(word[k]):
+            tmp = tmp + el * Z[:, d, :]
+        if total_weighting:
+            tmp = tmp + lookup * alpha[k]
+            tmp = np.maximum.accumulate(tmp, axis=1)
+            if L - k <= extended:
+                out[:, extended - (L - k), :] = tmp - lookup * alpha[k]
+            if k < L - 1:
+                tmp = tmp - lookup * alpha[k]
+        else:
+            if k > 0:
+                tmp = tmp - lookup * alpha[k - 1]
+            if L - k <= extended:
+                out[:, extended - (L - k), :] = np.maximum.accumulate(tmp, axis=1)
+            if k < L - 1:
+                tmp = tmp + lookup * alpha[k]
+                tmp = np.maximum.accumulate(tmp, axis=1)
+    return out
+
+
+def iterated_sums(Z, word_rows, alpha=None, lookup=None, extended=1, total=False,
+                  semiring="Reals"):
     """fruits/iss/semiring.py:14-41 (Semiring.iterated_sums) for a SimpleWord:
     no weighting => zero alpha, zero lookup, total=True (:27-28, :35)."""
     L = len(word_rows)
@@ -292,12 +326,12 @@ def iterated_sums(Z, word_rows, alpha=None, lookup=None, extended=1, total=False
                   else np.asarray(alpha, dtype=np.float32))
         lookup_ = lookup
         total_ = total
-    return iterated_sum_fast(Z, np.array(word_rows, dtype=np.int32), alpha_,
-                             lookup_, extended, total_)
+    fn = iterated_sum_fast if semiring == "Reals" else arctic_iterated_sum_fast
+    return fn(Z, np.array(word_rows, dtype=np.int32), alpha_, lookup_, extended, total_)
 
 
 def iss_transform(X, word_strings, mode="SINGLE", alphas=None, lookup=None,
-                  total=False):
+                  total=False, semiring="Reals"):
     """fruits/iss/iss.py:21-67 (_calculate_ISS, one batch of all words)
     -> (K, N, T) in the reference's row order."""
     X = np.asarray(X, dtype=np.float64)
@@ -311,7 +345,7 @@ def iss_transform(X, word_strings, mode="SINGLE", alphas=None, lookup=None,
     for i, s in enumerate(word_strings):
         rows = parse_word(s)
         a = None if alphas is None else alphas[i]
-        r = iterated_sums(X, rows, a, lookup, plan[i], total)
+        r = iterated_sums(X, rows, a, lookup, plan[i], total, semiring)
         out[idx:idx + plan[i]] = np.swapaxes(r, 0, 1)
         idx += plan[i]
     return out
@@ -495,7 +529,8 @@ def _iterate_iss(X, iss_list, X_raw, idx=0):
         return
     i = iss_list[idx]
     lookup, total = _weight_lookup(i.get("weighting"), X, X_raw)
-    its = iss_transform(X, i["words"], i["mode"], i.get("alphas"), lookup, total)
+    its = iss_transform(X, i["words"], i["mode"], i.get("alphas"), lookup, total,
+                        i.get("semiring", "Reals"))
     for itsum in its:
         yield from _iterate_iss(itsum[:, None, :], iss_list, X_raw, idx + 1)
 

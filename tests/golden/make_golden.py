@@ -141,7 +141,7 @@ def make_weighting(spec):
 
 
 def iss_case(name, x_key, words, mode="SINGLE", alphas=None, weighting=None,
-             store_slice=None):
+             store_slice=None, semiring="Reals"):
     X = arrays[x_key] if isinstance(x_key, str) else x_key[1]
     ws = [fruits.words.SimpleWord(s) for s in words]
     if alphas is not None:
@@ -149,10 +149,11 @@ def iss_case(name, x_key, words, mode="SINGLE", alphas=None, weighting=None,
             if a is not None:
                 w.alpha = a
     iss = fruits.ISS(ws, mode=getattr(fruits.ISSMode, mode),
+                     semiring=getattr(fruits.semiring, semiring)(),
                      weighting=make_weighting(weighting))
     out = iss.fit_transform(X)
     entry = {
-        "name": name, "words": list(words), "mode": mode,
+        "name": name, "words": list(words), "mode": mode, "semiring": semiring,
         "alphas": alphas, "weighting": weighting,
         "K": int(out.shape[0]),
         "labels": [iss.label(i) for i in range(iss.n_iterated_sums())],
@@ -266,6 +267,39 @@ c2u = {"seed": 1, "dist": "uniform", "shape": [2048, 3, 1024]}
 iss_case("config2_ext_uniform", ("gen", gen(c2u)), W23, "EXTENDED",
          store_slice=[0, 2047])
 manifest["iss"][-1]["x_gen"] = c2u
+
+# Arctic semiring (max, +): reference tests/signature/test_semiring.py:10-33 + random
+iss_case("arctic_x1_six_words", "X_1", ["[1]", "[2]", "[11]", "[12]", "[1][1]", "[1][2]"],
+         semiring="Arctic")
+put("iss/arctic_x1_six_words_expected", np.array([
+    [[-4, 0.8, 0.8, 5, 5], [5, 8, 8, 8, 8]],
+    [[2, 2, 2, 2, 2], [-5, -1, -1, -0.5, -0.5]],
+    [[-8, 1.6, 1.6, 10, 10], [10, 16, 16, 16, 16]],
+    [[-2, 1.8, 1.8, 5, 5], [0, 7, 7, 7, 7]],
+    [[-8, 1.6, 1.6, 10, 10], [10, 16, 16, 16, 16]],
+    [[-2, 1.8, 1.8, 5., 5.], [0., 7., 7., 7.5, 7.5]],
+]))
+ALT = [str(w) for w in fruits.words.alternate_sign([
+    fruits.words.SimpleWord(6 * "[1]"), fruits.words.SimpleWord(6 * "[2]"),
+    fruits.words.SimpleWord(3 * "[1][2]"), fruits.words.SimpleWord(3 * "[2][1]")])]
+manifest["alt_words"] = ALT
+iss_case("arctic_w23_ext_G", "G_5_3_37", W23, "EXTENDED", semiring="Arctic")
+iss_case("arctic_w32_single_U", "U_7_2_129", W32, "SINGLE", semiring="Arctic")
+iss_case("arctic_alt_ext_G", "G_5_3_37", ALT, "EXTENDED", semiring="Arctic")
+iss_case("arctic_neg_words", "P_4_2_33", ["[-1][-2]", "[-12][-2-21]", "[1][-1]", "[-1-1][22]",
+                                           "[111][-2-2-2]"], "EXTENDED", semiring="Arctic")
+iss_case("arctic_idx_nontotal", "U_6_3_40", ["[12][2][33]", "[1][3]"], "EXTENDED",
+         alphas=[[.6, .2, .5], None], weighting={"kind": "Indices", "scale": 2.0},
+         semiring="Arctic")
+iss_case("arctic_idx_total", "U_6_3_40", ["[12][2][33]", "[1][3]"], "EXTENDED",
+         alphas=[[.6, .2, .5], None], weighting={"kind": "Indices", "scale": 2.0, "total": True},
+         semiring="Arctic")
+iss_case("arctic_l1_G", "G_5_3_37", ["[1][2]", "[1][2][3]", "[3]"], "EXTENDED",
+         weighting={"kind": "L1", "scale": 4.0}, semiring="Arctic")
+c2a = {"seed": 0, "dist": "normal", "shape": [2048, 3, 1024]}
+iss_case("arctic_config2_ext", ("gen", gen(c2a)), W23, "EXTENDED", store_slice=[0, 2047],
+         semiring="Arctic")
+manifest["iss"][-1]["x_gen"] = c2a
 
 # per-word operator (iterated_sum_fast, fruits/iss/semiring.py:203-219)
 Z = arrays["U_6_3_40"]
@@ -386,6 +420,7 @@ def build_fruit(spec):
         for i in sl["iss"]:
             ws = [fruits.words.SimpleWord(s) for s in i["words"]]
             fr.add(fruits.ISS(ws, mode=getattr(fruits.ISSMode, i["mode"]),
+                              semiring=getattr(fruits.semiring, i.get("semiring", "Reals"))(),
                               weighting=make_weighting(i.get("weighting"))))
         for s in sl["sieves"]:
             kw = {k: (tuple(v) if isinstance(v, list) and k == "q" else v)
@@ -483,6 +518,21 @@ fruit_case("twi_small", "G_10_1_128", twi, np_seed=11)
 twi_hot = json.loads(json.dumps(twi))
 twi_hot["slices"][0]["sieves"] = [{"kind": "NPI"}, {"kind": "END"}]
 fruit_case("twi_small_hot", "G_16_3_96", twi_hot, np_seed=12)
+
+# fruit_twi slice 2 shape: Arctic ISS over alternate_sign chains -> NPI, END
+fruit_case("twi_arctic_small", "G_10_1_128", {"name": "twi2", "slices": [
+    {"iss": [{"words": [str(w) for w in fruits.words.alternate_sign(
+        [fruits.words.SimpleWord(12 * "[1]")])], "mode": "EXTENDED", "semiring": "Arctic"}],
+     "sieves": [{"kind": "NPI"}, {"kind": "END"}], "fit_sample_size": 1.0}]}, np_seed=15)
+# fruit_reduced slice 2 shape: NEW(INC) -> Arctic ISS -> NPI/MPI inc 0..2, END
+fruit_case("reduced_arctic_small", "G_10_1_128", {"name": "red2", "slices": [
+    {"preps": [{"kind": "NEW", "inner": {"kind": "INC"}}],
+     "iss": [{"words": ALT, "mode": "EXTENDED", "semiring": "Arctic"}],
+     "sieves": [{"kind": "NPI", "q": [0.5, 1.0], "inc": 0},
+                {"kind": "NPI", "q": [0.5, 1.0], "inc": 1},
+                {"kind": "MPI", "q": [0.5, 1.0], "inc": 2},
+                {"kind": "END"}],
+     "fit_sample_size": 1.0}]}, np_seed=16)
 
 # chained ISS (reference tests/signature/test_consecutive.py) with END
 fruit_case("consecutive_end", "U_9_3_60", {"slices": [

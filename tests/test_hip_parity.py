@@ -57,6 +57,7 @@ def make_iss(fr, case):
             if a is not None:
                 w.alpha = a
     return fr.ISS(ws, mode=getattr(fr.ISSMode, case["mode"]),
+                  semiring=getattr(fr.semiring, case.get("semiring", "Reals"))(),
                   weighting=make_weighting(fr, case.get("weighting")))
 
 
@@ -70,6 +71,15 @@ def test_iss_golden(fr, case):
     if "series" in case:
         out = out[:, case["series"], :]
     ref = G[case["out"]]
+    if case.get("semiring") == "Arctic":
+        # (max, +): max is associative and the letter sums round like the reference's,
+        # so results are bit-exact - except through an L1 lookup, which is itself a
+        # (re-associated) device scan
+        if (case.get("weighting") or {}).get("kind") == "L1":
+            np.testing.assert_allclose(out, ref, rtol=1e-12, atol=1e-12)
+        else:
+            np.testing.assert_array_equal(out, ref)
+        return
     rowwise_close(out, ref)
     if "U_" in case.get("x", "") or case.get("x_gen", {}).get("dist") == "uniform":
         if not any("-" in w for w in case["words"]):
@@ -86,6 +96,36 @@ def test_x1_hand_computed(fr):
     np.testing.assert_allclose(
         G["iss/x1_six_words_expected"][0],
         fr.ISS([ws[0].copy()]).fit_transform(G["X_1"])[0], atol=1e-12)
+
+
+def test_arctic_hand_computed_and_identity(fr):
+    # reference tests/signature/test_semiring.py:10-33 and test_simple.py:81-88
+    ws = [fr.words.SimpleWord(s) for s in ["[1]", "[2]", "[11]", "[12]", "[1][1]", "[1][2]"]]
+    res = list(fr.ISS(ws, semiring=fr.semiring.Arctic()).batch_transform(G["X_1"], batch_size=1))
+    for i, r in enumerate(res):
+        np.testing.assert_allclose(G["iss/arctic_x1_six_words_expected"][i], r[0], atol=1e-12)
+    X = G["X_1"]
+    a = fr.ISS([fr.words.SimpleWord("[1][2]")], semiring=fr.semiring.Arctic()).fit_transform(-X)
+    b = fr.ISS([fr.words.SimpleWord("[-1][-2]")], semiring=fr.semiring.Arctic()).fit_transform(X)
+    np.testing.assert_array_equal(a, b)
+    with pytest.raises(NotImplementedError):
+        fr.ISS([fr.words.SimpleWord("[1]")], semiring=fr.semiring.Arctic(argmax=True),
+               mode=fr.ISSMode.EXTENDED).fit_transform(X)
+
+
+@pytest.mark.parametrize("T", [5, 511, 1024, 1025, 3000])
+def test_arctic_ragged_and_long_chains(fr, T):
+    rng = np.random.default_rng(T)
+    X = rng.standard_normal((4, 2, T))
+    words = [str(w) for w in fr.words.alternate_sign(
+        [fr.words.SimpleWord(24 * "[1]"), fr.words.SimpleWord(12 * "[1][2]")])]
+    for weighting in (None, {"kind": "Indices", "scale": 3.0},
+                      {"kind": "Indices", "scale": 3.0, "total": True}):
+        iss = fr.ISS([fr.words.SimpleWord(s) for s in words], mode=fr.ISSMode.EXTENDED,
+                     semiring=fr.semiring.Arctic(), weighting=make_weighting(fr, weighting))
+        lookup, total = orc._weight_lookup(weighting, X, X)
+        ref = corc.iss_transform(X, words, "EXTENDED", None, lookup, total, semiring="Arctic")
+        np.testing.assert_array_equal(iss.fit_transform(X), ref)
 
 
 def test_theoretical_identity(fr):
@@ -253,6 +293,7 @@ def build_fruit(fr, spec):
         for i in sl["iss"]:
             ws = [fr.words.SimpleWord(s) for s in i["words"]]
             fruit.add(fr.ISS(ws, mode=getattr(fr.ISSMode, i["mode"]),
+                             semiring=getattr(fr.semiring, i.get("semiring", "Reals"))(),
                              weighting=make_weighting(fr, i.get("weighting"))))
         for s in sl["sieves"]:
             kw = {k: (tuple(v) if k == "q" else v) for k, v in s.items() if k != "kind"}

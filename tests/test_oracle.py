@@ -15,6 +15,13 @@ def _lookup(case, X, X_raw=None):
     return orc._weight_lookup(case.get("weighting"), X, X if X_raw is None else X_raw)
 
 
+def test_arctic_x1_hand_computed():
+    # reference tests/signature/test_semiring.py:10-33
+    out = orc.iss_transform(G["X_1"], ["[1]", "[2]", "[11]", "[12]", "[1][1]", "[1][2]"],
+                            semiring="Arctic")
+    np.testing.assert_allclose(out, G["iss/arctic_x1_six_words_expected"], rtol=1e-12)
+
+
 def test_x1_hand_computed():
     # reference tests/signature/test_simple.py:11-34
     out = orc.iss_transform(G["X_1"], ["[1]", "[2]", "[11]", "[12]", "[1][1]", "[1][2]"])
@@ -52,7 +59,7 @@ def test_iss_cases(case):
     X = G.x_of(case)
     lookup, total = _lookup(case, X)
     out = orc.iss_transform(X, case["words"], case["mode"], case["alphas"],
-                            lookup, total)
+                            lookup, total, case.get("semiring", "Reals"))
     assert out.shape[0] == case["K"]
     if "series" in case:
         out = out[:, case["series"], :]

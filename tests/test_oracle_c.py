@@ -15,7 +15,7 @@ def test_iss_cases(case):
     X = G.x_of(case)
     lookup, total = orc._weight_lookup(case.get("weighting"), X, X)
     out = corc.iss_transform(X, case["words"], case["mode"], case["alphas"],
-                             lookup, total)
+                             lookup, total, semiring=case.get("semiring", "Reals"))
     if "series" in case:
         out = out[:, case["series"], :]
     np.testing.assert_allclose(out, G[case["out"]], **RT)
