@@ -31,6 +31,7 @@ EXPORTS = [
     "fr_pathlen_lookup", "fr_sieve", "fr_pre_transform", "fr_standardize",
     "fr_pipeline_create", "fr_pipeline_destroy", "fr_pipeline_info",
     "fr_pipeline_workspace_bytes", "fr_pipeline_run", "fr_pipeline_set_quantiles",
+    "fr_select_ranks",
 ]
 
 _lib = None
@@ -399,6 +400,25 @@ def pre_transform(Ad, inc: int):
     rc = lib().fr_pre_transform(dptr(Ad), C.c_int64(N), C.c_int64(T), C.c_int64(Ad.stride(0)),
                                 C.c_int32(inc), dptr(out), stream_ptr())
     check(rc, "fr_pre_transform")
+    return out
+
+
+def select_ranks(block, job_row, job_inc, job_rank) -> np.ndarray:
+    """Order statistics of differenced (N, T) blocks of the (rows, N, T) device
+    tensor ``block`` (fr_select_ranks); exact."""
+    rows, N, T = block.shape
+    jr = np.ascontiguousarray(job_row, dtype=np.int32)
+    ji = np.ascontiguousarray(job_inc, dtype=np.int32)
+    jk = np.ascontiguousarray(job_rank, dtype=np.int64)
+    out = np.zeros(len(jr))
+    if not block.is_contiguous():
+        raise ValueError("block must be contiguous")
+    rc = lib().fr_select_ranks(
+        dptr(block), C.c_int64(rows), C.c_int64(N), C.c_int64(T), C.c_int32(len(jr)),
+        jr.ctypes.data_as(C.POINTER(C.c_int32)), ji.ctypes.data_as(C.POINTER(C.c_int32)),
+        jk.ctypes.data_as(C.POINTER(C.c_int64)), out.ctypes.data_as(C.POINTER(C.c_double)),
+        stream_ptr())
+    check(rc, "fr_select_ranks")
     return out
 
 

@@ -624,6 +624,55 @@ int fr_sieve(int32_t kind, const double *d_A, int64_t N, int64_t T, int64_t a_st
   return FR_OK;
 }
 
+int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32_t n_jobs,
+                    const int32_t *job_row, const int32_t *job_inc, const int64_t *job_rank,
+                    double *h_out, void *stream) {
+  if (rows < 0 || N < 1 || T < 1 || n_jobs < 0 || (n_jobs > 0 && (!job_row || !job_inc ||
+                                                                   !job_rank || !h_out)))
+    return fail(FR_E_ARG, "fr_select_ranks: bad argument");
+  if (n_jobs == 0) return FR_OK;
+  if (!d_A) return fail(FR_E_ARG, "fr_select_ranks: null device pointer");
+  struct HostJob {
+    const double *base;
+    unsigned long long prefix;
+    long long k;
+    int inc, pad;
+  };
+  static_assert(sizeof(HostJob) == fr::kSelJobBytes, "job layout");
+  std::vector<HostJob> jobs(n_jobs);
+  for (int j = 0; j < n_jobs; ++j) {
+    if (job_row[j] < 0 || job_row[j] >= rows || job_inc[j] < 0 || job_inc[j] > 8 ||
+        job_rank[j] < 0 || job_rank[j] >= N * T)
+      return fail(FR_E_ARG, "fr_select_ranks: job " + std::to_string(j) + " out of range");
+    jobs[j] = HostJob{d_A + (int64_t)job_row[j] * N * T, 0ull, (long long)job_rank[j], job_inc[j], 0};
+  }
+  hipStream_t st = (hipStream_t)stream;
+  void *d_jobs = nullptr, *d_hist = nullptr, *d_out = nullptr;
+  int rc = FR_OK;
+  do {
+    hipError_t e;
+    if ((e = hipMalloc(&d_jobs, jobs.size() * sizeof(HostJob))) != hipSuccess ||
+        (e = hipMalloc(&d_hist, (size_t)n_jobs * 256 * 4)) != hipSuccess ||
+        (e = hipMalloc(&d_out, (size_t)n_jobs * 8)) != hipSuccess ||
+        (e = hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(HostJob),
+                            hipMemcpyHostToDevice, st)) != hipSuccess ||
+        (e = hipMemsetAsync(d_hist, 0, (size_t)n_jobs * 256 * 4, st)) != hipSuccess ||
+        (e = fr::launch_select_ranks(d_jobs, n_jobs, N, T, static_cast<unsigned int *>(d_hist),
+                                     static_cast<double *>(d_out), st)) != hipSuccess ||
+        (e = hipMemcpyAsync(h_out, d_out, (size_t)n_jobs * 8, hipMemcpyDeviceToHost, st)) !=
+            hipSuccess ||
+        (e = hipStreamSynchronize(st)) != hipSuccess) {
+      rc = hip_fail(e, "fr_select_ranks");
+    }
+  } while (0);
+  const std::string keep = g_err;
+  if (d_jobs) (void)hipFree(d_jobs);
+  if (d_hist) (void)hipFree(d_hist);
+  if (d_out) (void)hipFree(d_out);
+  if (rc != FR_OK) g_err = keep;
+  return rc;
+}
+
 int fr_pre_transform(const double *d_A, int64_t N, int64_t T, int64_t a_stride, int32_t inc,
                      double *d_out, void *stream) {
   if (N < 0 || T < 0 || inc < 0 || inc > 8) return fail(FR_E_ARG, "fr_pre_transform: bad argument");

@@ -255,6 +255,85 @@ __global__ __launch_bounds__(256) void standardize_kernel(const double *__restri
   for (int64_t t = threadIdx.x; t < T; t += blockDim.x) o[t] = (x[t] - mean) / den;
 }
 
+// ---------------------------------------------------------------- rank selection (fit)
+// SegmentSieve._fit needs np.quantile of the pre-transformed fit sample
+// (fruits/sieving/segment.py:66-75, increment.py:73-74).  np.quantile interpolates
+// between two ORDER STATISTICS; those are found here exactly by an 8-pass radix
+// select over the order-preserving 64-bit image of the doubles (one job per wanted
+// rank), so the (N_fit, T) rows never leave the device.
+struct SelJob {
+  const double *base;        // (N, T) row block of one iterated sum
+  unsigned long long prefix; // key bits fixed so far
+  long long k;               // rank among the elements that match the prefix
+  int inc;
+  int pad;
+};
+
+__device__ __forceinline__ unsigned long long order_key(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_to_double(unsigned long long k) {
+  const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)u);
+}
+
+__global__ __launch_bounds__(256) void select_hist_kernel(const SelJob *__restrict__ jobs,
+                                                           int64_t N, int64_t T, int shift,
+                                                           unsigned int *__restrict__ hist) {
+  __shared__ unsigned int lh[256];
+  const int job = blockIdx.y;
+  lh[threadIdx.x] = 0;
+  __syncthreads();
+  const double *base = jobs[job].base;
+  const unsigned long long prefix = jobs[job].prefix;
+  const int inc = jobs[job].inc;
+  const int64_t total = N * T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / T, t = i - n * T;
+    const unsigned long long key = order_key(diff_at(base + n * T, t, inc));
+    const bool match = shift == 56 || (key >> (shift + 8)) == (prefix >> (shift + 8));
+    if (match) atomicAdd(&lh[(key >> shift) & 255], 1u);
+  }
+  __syncthreads();
+  if (lh[threadIdx.x]) atomicAdd(&hist[job * 256 + threadIdx.x], lh[threadIdx.x]);
+}
+
+__global__ void select_pick_kernel(SelJob *__restrict__ jobs, int shift,
+                                   unsigned int *__restrict__ hist, double *__restrict__ out) {
+  const int job = blockIdx.x;
+  if (threadIdx.x == 0) {
+    long long k = jobs[job].k, run = 0;
+    int d = 0;
+    for (; d < 255; ++d) {
+      const long long c = hist[job * 256 + d];
+      if (k < run + c) break;
+      run += c;
+    }
+    jobs[job].k = k - run;
+    jobs[job].prefix |= (unsigned long long)d << shift;
+    if (shift == 0) out[job] = key_to_double(jobs[job].prefix);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[job * 256 + i] = 0;
+}
+
+hipError_t launch_select_ranks(void *jobs, int n_jobs, int64_t N, int64_t T, unsigned int *hist,
+                               double *out, hipStream_t st) {
+  if (n_jobs <= 0 || N * T <= 0) return hipSuccess;
+  int64_t bpj = (N * T + 256 * 16 - 1) / (256 * 16);
+  if (bpj > 512) bpj = 512;
+  if (bpj < 1) bpj = 1;
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    hipLaunchKernelGGL(select_hist_kernel, dim3((unsigned)bpj, (unsigned)n_jobs), dim3(256), 0, st,
+                       static_cast<const SelJob *>(jobs), N, T, shift, hist);
+    hipLaunchKernelGGL(select_pick_kernel, dim3((unsigned)n_jobs), dim3(64), 0, st,
+                       static_cast<SelJob *>(jobs), shift, hist, out);
+  }
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- launchers
 int walk_chunk_elems(int64_t T) { return T <= 512 ? 512 : 1024; }
 

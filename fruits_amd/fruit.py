@@ -312,6 +312,46 @@ class FruitSlice:
                 else:
                     yield from self._iterate_iss_device(block[k].unsqueeze(1), iss_index + 1)
 
+    # ---- device-side fit ------------------------------------------------------------
+    def _fit_on_device(self, Sd, cache) -> bool:
+        """Fits the per-iterated-sum sieve copies without moving the fit sample's
+        iterated sums to the host: the order statistics np.quantile interpolates
+        between are selected on the device (fr_select_ranks).  Returns False when a
+        sieve or the ISS layout needs the host path."""
+        from .sieving.segment import SegmentSieve
+        if os.environ.get("FRUITS_AMD_DEVICE_FIT", "1") == "0" or len(self._iss) != 1:
+            return False
+        for sv in self._sieves:
+            if sv.requires_fitting and not (isinstance(sv, SegmentSieve)
+                                            and 0 <= getattr(sv, "_inc", 0) <= 8):
+                return False
+        iss = self._iss[0]
+        Ns, T = int(Sd.shape[0]), int(Sd.shape[2])
+        n = Ns * T
+        lookup = iss.lookup_device(Sd)
+        for s, e in iss.word_batches(Ns, T):
+            block = iss.transform_device(Sd, s, e, lookup)
+            copies, rows, incs, ranks, owners = [], [], [], [], []
+            for k in range(block.shape[0]):
+                fitted = [sieve.copy() for sieve in self._sieves]
+                for sieve in fitted:
+                    sieve._cache = cache
+                    if sieve.requires_fitting:
+                        reqs = sieve._quantile_requests(n)
+                        owners.append((sieve, reqs, len(rows)))
+                        for (_, lo, hi, _) in reqs:
+                            rows += [k, k]
+                            incs += [sieve._inc, sieve._inc]
+                            ranks += [lo, hi]
+                copies.append(fitted)
+            vals = nat.select_ranks(block, rows, incs, ranks) if rows else np.zeros(0)
+            for sieve, reqs, first in owners:
+                lo_vals = [vals[first + 2 * j] for j in range(len(reqs))]
+                hi_vals = [vals[first + 2 * j + 1] for j in range(len(reqs))]
+                sieve._set_quantiles_from_stats(reqs, lo_vals, hi_vals)
+            self._sieves_extended.extend(copies)
+        return True
+
     # ---- fused ISS + sieves (one launch, no (K, N, T) tensor) --------------------
     def _fusable(self) -> bool:
         from .sieving.increment import MPI, NPI
@@ -385,6 +425,9 @@ class FruitSlice:
             self._fitted = True
             return
         self._sieves_extended = []
+        if self._fit_on_device(Sd, cache):
+            self._fitted = True
+            return
         for itsum in self._iterate_iss_device(Sd):
             host = None
             fitted = [sieve.copy() for sieve in self._sieves]

@@ -75,6 +75,44 @@ class SegmentSieve(FeatureSieve, ABC):
                 qs[i] = np.quantile(X, q)
         self._quantiles = np.sort(qs)
 
+    # device-side fit: np.quantile's two order statistics come from fr_select_ranks
+    def _quantile_requests(self, n: int):
+        """[(index in q, lower rank, upper rank, gamma)] for the thresholds that need
+        data, exactly as np.quantile(method="linear") places them: virtual index
+        (n-1)*q, its floor and floor+1 (clipped), gamma = the fractional part."""
+        reqs = []
+        for i, q in enumerate(self._q):
+            if q in (1.0, -1.0) or q == 0:
+                continue
+            pos = (n - 1) * q
+            lo = int(np.floor(pos))
+            gamma = pos - lo
+            if pos >= n - 1:
+                lo = hi = n - 1
+            elif pos < 0:
+                lo = hi = 0
+            else:
+                hi = lo + 1
+            reqs.append((i, lo, hi, gamma))
+        return reqs
+
+    def _set_quantiles_from_stats(self, reqs, lo_vals, hi_vals) -> None:
+        qs = np.zeros(len(self._q))
+        for i, q in enumerate(self._q):
+            if q == 1.0:
+                qs[i] = np.inf
+            elif q == -1.0:
+                qs[i] = -np.inf
+        for (i, _, _, gamma), a, b in zip(reqs, lo_vals, hi_vals):
+            # numpy's _lerp (lib/_function_base_impl.py): a + (b-a)*t, from the other end
+            # when t >= 0.5
+            d = b - a
+            r = a + d * gamma
+            if gamma >= 0.5:
+                r = b - d * (1 - gamma)
+            qs[i] = r
+        self._quantiles = np.sort(qs)
+
     def _get_unfitted_quantiles(self) -> None:
         qs = np.zeros(len(self._q))
         for i, q in enumerate(self._q):

@@ -222,6 +222,17 @@ int fr_pipeline_run(fr_pipeline_t *pipeline, const double *d_X, int64_t N, int64
 int fr_pre_transform(const double *d_A, int64_t N, int64_t T, int64_t a_stride, int32_t inc,
                      double *d_out, void *stream);
 
+/* ------------------------------------------------------------------ fit ("next" row)
+ * Order statistics for SegmentSieve._fit / IncrementSieve._fit
+ * (fruits/sieving/segment.py:66-75, increment.py:73-74): np.quantile(X, q)
+ * interpolates between the two order statistics around q*(n-1); job j returns the
+ * job_rank[j]-th smallest (0-based) of the job_inc[j]-times differenced
+ * (N, T) block number job_row[j] of the device tensor d_A (rows, N, T).  Exact
+ * (radix select); synchronous; allocates its scratch (fit is not a capture path). */
+int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32_t n_jobs,
+                    const int32_t *job_row, const int32_t *job_inc, const int64_t *job_rank,
+                    double *h_out, void *stream);
+
 /* ------------------------------------------------------------------ STD ("next" row)
  * STD._transform with separately=True (fruits/preparation/transform.py:141-147):
  * every one of the rows = N*D series becomes (x - mean) / (std + eps); std is the

@@ -446,3 +446,41 @@ def test_fused_ragged_and_multichunk(fr, T):
     ref = orc.fruit_transform(spec, orc.fruit_fit(spec, X), X)
     labels = [fruit.label(i) for i in range(fruit.nfeatures())]
     compare_features(got, ref, labels, count_frac=0.05)
+
+
+@pytest.mark.parametrize("name", ["cfg3_small", "reduced_slice1_small", "readme", "readme_fullfit"])
+def test_device_fit_equals_host_fit(fr, name, monkeypatch):
+    """Thresholds fitted from device-selected order statistics are bit-identical to
+    np.quantile on the downloaded rows."""
+    case = [c for c in G.cases("fruit") if c["name"] == name][0]
+    X = G[case["x"]]
+    qs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FRUITS_AMD_DEVICE_FIT", flag)
+        fruit = build_fruit(fr, case["spec"])
+        np.random.seed(case["np_seed"])
+        fruit.fit(X)
+        qs.append([[np.asarray(sv._quantiles) for sv in row if hasattr(sv, "_quantiles")]
+                   for slc in fruit._slices for row in slc._sieves_extended])
+    assert len(qs[0]) == len(qs[1]) > 0
+    for a, b in zip(qs[0], qs[1]):
+        assert len(a) == len(b)
+        for u, v in zip(a, b):
+            np.testing.assert_array_equal(u, v)
+
+
+def test_select_ranks_against_numpy(fr):
+    from fruits_amd import _native as nat
+    rng = np.random.default_rng(9)
+    A = rng.standard_normal((3, 7, 129))
+    A[1, :, ::5] = 0.0            # ties
+    A[2] *= 1e-300                # denormal range / sign handling
+    Ad = nat.to_device(A)
+    rows, incs, ranks, want = [], [], [], []
+    for r in range(3):
+        for inc in (0, 1, 2):
+            flat = np.sort(orc.pre_transform(A[r], inc).ravel())
+            for k in (0, 1, flat.size // 2, flat.size - 2, flat.size - 1):
+                rows.append(r); incs.append(inc); ranks.append(k); want.append(flat[k])
+    got = nat.select_ranks(Ad, rows, incs, ranks)
+    np.testing.assert_array_equal(got, np.array(want))

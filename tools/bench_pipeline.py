@@ -75,3 +75,21 @@ if which in ("cfg2", "all"):
 if which in ("cfg5", "all"):
     run("cfg5_l1", 1024, 6, 4096, fr.words.of_weight(9, dim=1), fr.iss.weighting.L1(),
         [fr.sieving.NPI(), fr.sieving.END()])
+
+def run_arctic(N, D, T, L):
+    X = np.random.default_rng(0).standard_normal((N, D, T))
+    words = fr.words.alternate_sign([fr.words.SimpleWord(L * "[1]"), fr.words.SimpleWord(L * "[2]"),
+                                     fr.words.SimpleWord((L // 2) * "[1][2]"),
+                                     fr.words.SimpleWord((L // 2) * "[2][1]")])
+    iss = fr.ISS(words, mode=fr.ISSMode.EXTENDED, semiring=fr.semiring.Arctic())
+    plan = iss._plan(0, len(words)); K = plan.rows
+    Xd = nat.to_device(X)
+    out = torch.empty((K, N, T), dtype=torch.float64, device=Xd.device)
+    t = graph_time(lambda: plan.run(Xd, None, out=out))
+    b = 8.0 * N * T * (plan.dims_used + K)
+    print(json.dumps({"name": f"arctic_alt{L}", "N": N, "T": T, "W": len(words), "K": K, "nodes": plan.nodes,
+                      "materialise_launch_us": round(t, 1), "GBs": b / (t * 1e-6) / 1e9,
+                      "elements_per_s": N * K * T / (t * 1e-6)}))
+
+if which in ("arctic", "all"):
+    run_arctic(2048, 3, 1024, 24)
