@@ -107,7 +107,7 @@ WorkLayout work_layout(const fr::Plan &p, int64_t N, int64_t T, int64_t lookup_r
   if (p.weighting != 0)
     w.aux_bytes = align_up((size_t)p.aux_tables() * (size_t)lookup_rows * (size_t)T * 8, 256);
   if (T > fr::walk_chunk_elems(T))
-    w.carry_bytes = align_up((size_t)N * 2 * p.nodes.size() * 8, 256);
+    w.carry_bytes = align_up((size_t)N * 3 * p.nodes.size() * 8, 256);
   return w;
 }
 
@@ -324,7 +324,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     int max_nodes = 0;
     for (size_t g = 0; g + 1 < gp.group_begin.size(); ++g)
       max_nodes = std::max(max_nodes, gp.group_begin[g + 1] - gp.group_begin[g]);
-    a.carry_slots = 2 * max_nodes;
+    a.carry_slots = 3 * max_nodes;
     // rows + carries must leave room for >= 4 workgroups per CU (160 KiB LDS)
     const size_t rows_bytes = (size_t)a.R * fr::walk_chunk_elems(T) * 8;
     a.carry_in_lds = (env_int("FRUITS_HIP_LDS_CARRY", 1) != 0 &&
@@ -397,10 +397,10 @@ fr_pipeline_t *fr_pipeline_create(fr_plan_t *plan, int32_t n_sieves, const int32
     int code = FR_E_ARG;
     if (bad.empty() && sv.kind != FR_SIEVE_END) {
       if (sv.Q1 < 2) bad = "a band sieve needs >= 2 thresholds";
-      else if (sv.inc < 0 || sv.inc > 1) {
-        bad = "the fused epilogue supports inc 0 and 1 only";
+      else if (sv.inc < 0 || sv.inc > 2) {
+        bad = "the fused epilogue supports inc 0, 1 and 2 only";
         code = FR_E_LIMIT;
-      } else if (sv.inc == 1 && plan->p->weighting == FR_W_TOTAL) {
+      } else if (sv.inc >= 1 && plan->p->weighting == FR_W_TOTAL) {
         bad = "increments of totally weighted sums are not fused";
         code = FR_E_LIMIT;
       }

@@ -45,7 +45,7 @@ struct IssArgs {
   int32_t nchunks;
   int32_t xcd_map;
   int32_t persistent;       // grid = one resident round of workgroups
-  int32_t carry_slots;      // 2 * (largest group's node count): LDS carry slots
+  int32_t carry_slots;      // 3 * (largest group's node count): LDS carry slots
   int32_t carry_in_lds;     // multi-chunk carries fit in LDS
   int32_t semiring;         // kSemiReals / kSemiArctic
   int32_t wave_rows;        // TEAM = 1 kernel: one wave per row, 4 groups per workgroup

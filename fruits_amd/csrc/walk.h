@@ -72,12 +72,16 @@ __device__ __forceinline__ int lds_pos(int i) {
   }
 }
 
+constexpr int kCarrySlots = 3;  // per node: scan, second scan (non-total), d1 tail (inc = 2)
 constexpr int kStageRows = 3;  // rows staged per batch (registers: 4 * U VGPRs per row)
 
 struct WalkCtx {
   const IssArgs *a;
   const double *rows;   // LDS: staged rows [R][CHUNK]
   double *tot;          // LDS: wave totals [2][NW]
+  double *tail;         // LDS: last first-difference of every wave [2][NW] (fused inc = 2)
+  int tail_buf;
+  int slot;             // carry slot base of the node being processed
   double *out_base;     // out + n*out_n_stride + t0
   double *feat_row;     // MODE 1: feats + n*feat_stride
   double *cnt_row;      // MODE 1: band population of MPI features
@@ -354,9 +358,60 @@ __device__ __forceinline__ double bits_to_double(int lo, int hi) {
   return __hiloint2double(hi, lo);
 }
 
+// First differences d1[t] = c[t] - c[t-1] of the element BEFORE each of the lane's
+// elements (second differences need them): inside a lane the neighbour, across lanes
+// a DPP shift, across pieces lane 63, across waves an LDS exchange (one extra barrier,
+// taken by every wave since the op list is uniform), across chunks a carry slot.
 template <class C>
-__device__ __forceinline__ void fused_op(const WalkCtx &cx, const int32_t *w,
-                                         const double (&c)[C::EP], const double (&x)[C::EP]) {
+__device__ __forceinline__ void prev_first_differences(WalkCtx &cx, const double (&d1)[C::EP],
+                                                       double (&dp)[C::EP]) {
+  constexpr int E = C::E, P = C::P, NW = C::NW;
+  double last[P];
+#pragma unroll
+  for (int h = 0; h < P; ++h) {
+    last[h] = wave_last_lane(d1[h * E + E - 1]);
+    const double from_left = wave_shift_right1<0>(d1[h * E + E - 1]);
+    dp[h * E] = from_left;
+#pragma unroll
+    for (int e = 1; e < E; ++e) dp[h * E + e] = d1[h * E + e - 1];
+  }
+  double before_wave = 0.0;  // d1 of the element just before this wave's span
+  if constexpr (NW > 1) {
+    double *tl = cx.tail + cx.tail_buf * NW;
+    if (cx.lane == 0) tl[cx.wave] = last[P - 1];
+    lds_barrier();
+    if (cx.wave > 0) before_wave = tl[cx.wave - 1];
+    cx.tail_buf ^= 1;
+    if constexpr (C::MULTI != 0) {
+      const double carried = cx.first_chunk ? 0.0 : cx.carry[cx.slot + 2];
+      if (cx.wave == 0) before_wave = carried;
+      const double chunk_last = tl[NW - 1];
+      if (C::MULTI == 1 ? (cx.wave == 0 && cx.lane == 0) : (cx.lane == 0))
+        cx.carry[cx.slot + 2] = chunk_last;
+    }
+  } else if constexpr (C::MULTI != 0) {
+    before_wave = cx.first_chunk ? 0.0 : cx.carry[cx.slot + 2];
+    if (cx.lane == 0) cx.carry[cx.slot + 2] = last[P - 1];
+  }
+  if (cx.lane == 0) {
+    dp[0] = before_wave;
+#pragma unroll
+    for (int h = 1; h < P; ++h) dp[h * E] = last[h - 1];
+  }
+}
+
+// per-node scratch of the epilogue: the previous first differences are computed (and
+// their chunk carry advanced) at most once per node, whatever the number of inc = 2 ops
+template <int EP>
+struct FusedScratch {
+  double dp[EP];
+  bool have_dp = false;
+};
+
+template <class C>
+__device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w,
+                                         const double (&c)[C::EP], const double (&x)[C::EP],
+                                         FusedScratch<C::EP> &sc) {
   constexpr int E = C::E, P = C::P, EP = C::EP;
   const int kind = w[0] & 0xff, inc = w[0] >> 8, col = w[1];
   if (kind == FR_SIEVE_END_K) {
@@ -376,6 +431,29 @@ __device__ __forceinline__ void fused_op(const WalkCtx &cx, const int32_t *w,
   const int lo = w[2], hi = w[3];
   const double qlo = bits_to_double(w[4], w[5]), qhi = bits_to_double(w[6], w[7]);
   const int t_first = (int)cx.t0 + cx.wave * C::SPAN + cx.lane * E;  // element (h=0, e=0)
+  double d[EP];
+  if (inc == 0) {
+#pragma unroll
+    for (int i = 0; i < EP; ++i) d[i] = c[i];
+  } else {
+    // increments are zero-padded at t = 0 (fruits/cache.py:8-13)
+#pragma unroll
+    for (int h = 0; h < P; ++h)
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        d[h * E + e] = (t_first + h * C::PIECE + e == 0) ? 0.0 : c[h * E + e] - x[h * E + e];
+    if (inc == 2) {
+      if (!sc.have_dp) {
+        prev_first_differences<C>(cx, d, sc.dp);
+        sc.have_dp = true;
+      }
+#pragma unroll
+      for (int h = 0; h < P; ++h)
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+          d[h * E + e] = (t_first + h * C::PIECE + e == 0) ? 0.0 : d[h * E + e] - sc.dp[h * E + e];
+    }
+  }
   int cnt = 0;
   double sum = 0.0;
 #pragma unroll
@@ -383,8 +461,7 @@ __device__ __forceinline__ void fused_op(const WalkCtx &cx, const int32_t *w,
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int t = t_first + h * C::PIECE + e;
-      // increments are zero-padded at t = 0 (fruits/cache.py:8-13)
-      const double v = inc == 0 ? c[h * E + e] : (t == 0 ? 0.0 : c[h * E + e] - x[h * E + e]);
+      const double v = d[h * E + e];
       const bool in = t >= lo && t < hi && qlo < v && v <= qhi;
       cnt += __popcll(__ballot(in));
       if (kind == FR_SIEVE_MPI_K) sum += in ? v : 0.0;
@@ -402,16 +479,17 @@ __device__ __forceinline__ void fused_op(const WalkCtx &cx, const int32_t *w,
 }
 
 template <class C>
-__device__ __forceinline__ void fused_all(const WalkCtx &cx, const Rec &nd, const Ops2 &pre,
+__device__ __forceinline__ void fused_all(WalkCtx &cx, const Rec &nd, const Ops2 &pre,
                                           const double (&c)[C::EP], const double (&x)[C::EP]) {
   const IssArgs &a = *cx.a;
   const int ne = nd.emit_count(), n = a.n_ops;
   int64_t k = nd.w[7];
   Ops2 o = pre;  // ops 0-1 of the first row were requested at the start of the node
+  FusedScratch<C::EP> sc;
   for (int j = 0;;) {
     for (int i = 0;;) {
-      fused_op<C>(cx, o.w, c, x);
-      if (i + 1 < n) fused_op<C>(cx, o.w + 8, c, x);
+      fused_op<C>(cx, o.w, c, x, sc);
+      if (i + 1 < n) fused_op<C>(cx, o.w + 8, c, x, sc);
       i += 2;
       if (i >= n) break;
       o = load_ops2(a, k, i);
@@ -427,6 +505,7 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd, int slo
                                              const double (&pin)[C::EP],
                                              double (&pout)[C::EP]) {
   constexpr int EP = C::EP;
+  cx.slot = slot;
   double s[EP];
 #pragma unroll
   for (int i = 0; i < EP; ++i) s[i] = pin[i];
@@ -497,8 +576,8 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd, int slo
 // group, global ones by its plan-wide id
 template <class C>
 __device__ __forceinline__ int carry_slot_of(const WalkCtx &cx, const Rec &nd, int pc) {
-  if constexpr (C::MULTI == 1) return 2 * (pc - cx.pc_begin);
-  return 2 * nd.node_id();
+  if constexpr (C::MULTI == 1) return kCarrySlots * (pc - cx.pc_begin);
+  return kCarrySlots * nd.node_id();
 }
 
 // Walks the records of one group.  cx.cur always holds the record at cx.pc; the
@@ -568,6 +647,7 @@ __global__ __launch_bounds__(kWalkThreads) void iss_walk_kernel(const IssArgs a)
   cx.a = &a;
   cx.rows = lds;
   cx.tot = lds + (int64_t)a.R * C::CHUNK;
+  cx.tail = cx.tot + 2 * C::NW;
   cx.tid = tid;
   cx.lane = tid & 63;
   {
@@ -576,6 +656,7 @@ __global__ __launch_bounds__(kWalkThreads) void iss_walk_kernel(const IssArgs a)
     cx.team = w / C::TEAM;
   }
   cx.buf = 0;
+  cx.tail_buf = 0;
   double *rows_w = lds;
   // TEAM = 1: a unit is a series, its G = TEAMS groups go to the 4 waves
   const int64_t units = C::TEAM == 1 ? a.N : a.N * a.G;
@@ -606,9 +687,9 @@ __global__ __launch_bounds__(kWalkThreads) void iss_walk_kernel(const IssArgs a)
       g = (int)(u % a.G);
     }
     if constexpr (C::MULTI == 1)
-      cx.carry = lds + (int64_t)a.R * C::CHUNK + 2 * C::NW;
+      cx.carry = lds + (int64_t)a.R * C::CHUNK + 4 * C::NW;
     else
-      cx.carry = a.carry ? a.carry + n * (2 * (int64_t)a.total_nodes) : nullptr;
+      cx.carry = a.carry ? a.carry + n * (kCarrySlots * (int64_t)a.total_nodes) : nullptr;
     const int node_begin = as_const(a.group_begin)[g];
     cx.pc_begin = node_begin;
     for (int64_t chunk = 0; chunk < a.nchunks; ++chunk) {
@@ -700,7 +781,8 @@ template <int E, int P, int LV, int MULTI, bool VEC, bool W, int TEAM = 4, int M
           int SEMI = 0>
 static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
   using C = WalkCfg<E, P, LV, MULTI, VEC, W, TEAM, MODE, SEMI>;
-  const size_t lds = ((size_t)a.R * C::CHUNK + 2 * C::NW + (MULTI == 1 ? a.carry_slots : 0)) *
+  const size_t lds = ((size_t)a.R * C::CHUNK + 2 * C::NW + 2 * C::NW +
+                      (MULTI == 1 ? a.carry_slots : 0)) *
                      sizeof(double);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static size_t lds_attr = 0;  // per instantiation

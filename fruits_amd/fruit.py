@@ -361,7 +361,7 @@ class FruitSlice:
         for sv in self._sieves:
             if type(sv) not in (NPI, MPI, END) or sv._has_float_cuts():
                 return False
-            if type(sv) is not END and sv._inc not in (0, 1):
+            if type(sv) is not END and sv._inc not in (0, 1, 2):
                 return False
         return True
 

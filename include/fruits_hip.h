@@ -185,7 +185,7 @@ int fr_sieve(int32_t kind, const double *d_A, int64_t N, int64_t T, int64_t a_st
  * ISS + sieves in ONE launch: replaces the loop of FruitSlice.transform
  * (fruits/fruit.py:538-550) - for every iterated sum, for every sieve,
  * sieve.transform(itsum) - without ever materialising the (K, N, T) tensor.
- * Sieves: NPI / MPI with inc in {0, 1} and END, integer cuts (the same for all
+ * Sieves: NPI / MPI with inc in {0, 1, 2} and END, integer cuts (the same for all
  * series).  Feature (n, k*per_sum + col_s + j*(Q1_s-1) + q) is the reference's
  * column order (iterated sum, then sieve, then segment, then band).
  *

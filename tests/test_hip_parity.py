@@ -406,7 +406,8 @@ def test_word_sharded_blocks_reassemble(fr, world):
 
 
 @pytest.mark.parametrize("name", ["readme", "cfg3_small", "cfg3_small_unweighted", "twi_small",
-                                  "twi_small_hot", "x1_two_slices_end"])
+                                  "twi_small_hot", "x1_two_slices_end", "reduced_slice1_small",
+                                  "reduced_arctic_small", "twi_arctic_small"])
 def test_fused_matches_materialised(fr, name, monkeypatch):
     """The fused ISS+sieve launch against the materialising path (fr_iss_run +
     fr_sieve per iterated sum): END and inc=0 features are bit-identical, inc=1
@@ -435,7 +436,9 @@ def test_fused_ragged_and_multichunk(fr, T):
     spec = {"slices": [{"preps": [{"kind": "INC"}],
                         "iss": [{"words": G.manifest["words"]["3,2"]["words"], "mode": "EXTENDED"}],
                         "sieves": [{"kind": "NPI", "q": [0.5, 1.0]}, {"kind": "NPI", "inc": 0},
-                                   {"kind": "MPI", "cut": [T // 2, -1]}, {"kind": "END", "cut": [1, -1]}],
+                                   {"kind": "MPI", "cut": [T // 2, -1]}, {"kind": "END", "cut": [1, -1]},
+                                   {"kind": "NPI", "q": [0.5, 1.0], "inc": 2},
+                                   {"kind": "MPI", "inc": 2, "cut": [max(T // 3, 1), -1]}],
                         "fit_sample_size": 1.0}]}
     fruit = build_fruit(fr, spec)
     np.random.seed(3)

@@ -43,13 +43,20 @@ def run(name, N, D, T, words, weighting, sieves):
     work = torch.empty(max(wb, 1), dtype=torch.uint8, device=Pd.device)
     t_fused = graph_time(lambda: pipe.run(Pd, lk, feats=feats, work=work))
     plan = iss._plan(0, len(words)); K = plan.rows
-    out = torch.empty((K, N, T), dtype=torch.float64, device=Pd.device)
-    wb2 = plan.workspace_bytes(N, T, 0 if lk is None else lk.shape[0])
-    work2 = torch.empty(max(wb2, 1), dtype=torch.uint8, device=Pd.device)
-    t_mat = graph_time(lambda: plan.run(Pd, lk, out=out, work=work2))
-    os.environ["FRUITS_AMD_FUSED"] = "0"; slc._fused_cache = {}
-    t0 = time.perf_counter(); f0 = fruit.transform(X); t_e2e_plain = time.perf_counter() - t0
-    os.environ["FRUITS_AMD_FUSED"] = "1"; slc._fused_cache = {}
+    if K * N * T * 8 < 40e9:
+        out = torch.empty((K, N, T), dtype=torch.float64, device=Pd.device)
+        wb2 = plan.workspace_bytes(N, T, 0 if lk is None else lk.shape[0])
+        work2 = torch.empty(max(wb2, 1), dtype=torch.uint8, device=Pd.device)
+        t_mat = graph_time(lambda: plan.run(Pd, lk, out=out, work=work2))
+        del out
+    else:
+        t_mat = float("nan")
+    if K * N * T * 8 < 40e9:
+        os.environ["FRUITS_AMD_FUSED"] = "0"; slc._fused_cache = {}
+        t0 = time.perf_counter(); f0 = fruit.transform(X); t_e2e_plain = time.perf_counter() - t0
+        os.environ["FRUITS_AMD_FUSED"] = "1"; slc._fused_cache = {}
+    else:
+        f0, t_e2e_plain = f1, float("nan")
     diff = np.abs(f0 - f1)
     eq_bytes = 8.0 * N * T * (plan.dims_used + K)
     res = {"name": name, "N": N, "D": D, "T": T, "W": len(words), "K": K, "F": int(pipe.n_features),
@@ -93,3 +100,7 @@ def run_arctic(N, D, T, L):
 
 if which in ("arctic", "all"):
     run_arctic(2048, 3, 1024, 24)
+
+if which in ("cfg4",):
+    run("cfg4_indices_1gpu", 8192, 3, 1024, fr.words.of_weight(6, dim=2), fr.iss.weighting.Indices(),
+        [fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END()])
