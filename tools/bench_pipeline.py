@@ -104,3 +104,34 @@ if which in ("arctic", "all"):
 if which in ("cfg4",):
     run("cfg4_indices_1gpu", 8192, 3, 1024, fr.words.of_weight(6, dim=2), fr.iss.weighting.Indices(),
         [fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END()])
+
+def run_reduced1(N, D, T):
+    """fruit_reduced.py slice 1 verbatim: NEW(INC) -> STD -> ISS(of_weight(4,2), EXT, Indices) ->
+    NPI x3 (inc 0,1,2), MPI x3, END; fit_sample_size = 1.0"""
+    X = np.random.default_rng(0).standard_normal((N, D, T))
+    fruit = fr.Fruit("reduced slice 1")
+    fruit.add(fr.preparation.NEW(fr.preparation.INC()))
+    fruit.add(fr.preparation.STD)
+    fruit.add(fr.ISS(fr.words.of_weight(4, 2), mode=fr.ISSMode.EXTENDED, weighting=fr.iss.weighting.Indices()))
+    for inc in (0, 1, 2): fruit.add(fr.sieving.NPI(q=(0.5, 1.0), inc=inc))
+    for inc in (0, 1, 2): fruit.add(fr.sieving.MPI(q=(0.5, 1.0), inc=inc))
+    fruit.add(fr.sieving.END)
+    for slc in fruit: slc.fit_sample_size = 1.0
+    np.random.seed(0)
+    t0 = time.perf_counter(); fruit.fit(X); t_fit = time.perf_counter() - t0
+    fruit.transform(X)
+    t0 = time.perf_counter(); f1 = fruit.transform(X); t_tr = time.perf_counter() - t0
+    os.environ["FRUITS_AMD_FUSED"] = "0"; os.environ["FRUITS_AMD_DEVICE_FIT"] = "0"
+    for slc in fruit: slc._fused_cache = {}
+    t0 = time.perf_counter(); f0 = fruit.transform(X); t_tr0 = time.perf_counter() - t0
+    np.random.seed(0)
+    t0 = time.perf_counter(); fruit.fit(X); t_fit0 = time.perf_counter() - t0
+    os.environ["FRUITS_AMD_FUSED"] = "1"; os.environ["FRUITS_AMD_DEVICE_FIT"] = "1"
+    d = np.abs(f0 - f1)
+    print(json.dumps({"name": "fruit_reduced_slice1", "N": N, "D": D, "T": T, "features": int(f1.shape[1]),
+                      "fit_device_s": round(t_fit, 3), "fit_host_quantiles_s": round(t_fit0, 3),
+                      "transform_fused_ms": round(t_tr * 1e3, 2), "transform_unfused_ms": round(t_tr0 * 1e3, 2),
+                      "frac_entries_differing": float((d > 1e-9 * (1 + np.abs(f0))).mean())}))
+
+if which in ("reduced1", "all"):
+    run_reduced1(2048, 1, 1024)
