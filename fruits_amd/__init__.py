@@ -9,6 +9,7 @@ kernels behind the C ABI of ``include/fruits_hip.h``; there is no CPU fallback.
 from . import cache, callback, iss, preparation, seed, sieving
 from .fruit import Fruit, FruitSlice
 from .iss import semiring, words
+from .iss.cos import CosWISS
 from .iss.iss import ISS, ISSMode
 
 __version__ = "0.1.0"

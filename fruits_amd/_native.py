@@ -31,7 +31,7 @@ EXPORTS = [
     "fr_pathlen_lookup", "fr_sieve", "fr_pre_transform", "fr_standardize",
     "fr_pipeline_create", "fr_pipeline_destroy", "fr_pipeline_info",
     "fr_pipeline_workspace_bytes", "fr_pipeline_run", "fr_pipeline_set_quantiles",
-    "fr_select_ranks",
+    "fr_select_ranks", "fr_coswiss_combine",
 ]
 
 _lib = None
@@ -431,4 +431,17 @@ def standardize(Xd, div_std: bool, eps: float):
                               C.c_int32(1 if div_std else 0), C.c_double(eps), dptr(out),
                               stream_ptr())
     check(rc, "fr_standardize")
+    return out
+
+
+def coswiss_combine(terms_d, begin_d, coeff_d, desc_d, trig_d, out, out_row_stride: int):
+    """out[j] = sum of the weighted terms of output row j (fr_coswiss_combine);
+    ``out`` is a device view whose rows are ``out_row_stride`` doubles apart."""
+    n_terms, N, T = (int(v) for v in terms_d.shape)
+    n_out = int(begin_d.shape[0]) - 1
+    rc = lib().fr_coswiss_combine(dptr(terms_d), C.c_int64(n_terms), C.c_int64(N), C.c_int64(T),
+                                  C.c_int32(n_out), dptr(begin_d), dptr(coeff_d), dptr(desc_d),
+                                  dptr(trig_d), dptr(out), C.c_int64(out_row_stride),
+                                  stream_ptr())
+    check(rc, "fr_coswiss_combine")
     return out

@@ -693,4 +693,21 @@ int fr_standardize(const double *d_X, int64_t rows, int64_t T, int32_t div_std, 
   return FR_OK;
 }
 
+int fr_coswiss_combine(const double *d_terms, int64_t n_terms, int64_t N, int64_t T,
+                       int32_t n_out, const int32_t *d_begin, const double *d_coeff,
+                       const int32_t *d_desc, const double *d_trig, double *d_out,
+                       int64_t out_row_stride, void *stream) {
+  if (n_terms < 0 || N < 0 || T < 0 || n_out < 0)
+    return fail(FR_E_ARG, "fr_coswiss_combine: bad shape");
+  if (N == 0 || T == 0 || n_out == 0) return FR_OK;
+  if (N * (int64_t)n_out > 0x7fffffffLL) return fail(FR_E_LIMIT, "fr_coswiss_combine: grid too large");
+  if (out_row_stride < N * T) return fail(FR_E_ARG, "fr_coswiss_combine: rows of d_out overlap");
+  if (!d_terms || !d_begin || !d_coeff || !d_desc || !d_trig || !d_out)
+    return fail(FR_E_ARG, "fr_coswiss_combine: null device pointer");
+  hipError_t e = fr::launch_coswiss_combine(d_terms, N, T, n_out, d_begin, d_coeff, d_desc, d_trig,
+                                            d_out, out_row_stride, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "coswiss combine launch");
+  return FR_OK;
+}
+
 }  // extern "C"

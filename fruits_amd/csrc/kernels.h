@@ -79,6 +79,10 @@ hipError_t launch_select_ranks(void *jobs, int n_jobs, int64_t N, int64_t T, uns
 constexpr int kSelJobBytes = 32;
 hipError_t launch_pre_transform(const double *A, int64_t N, int64_t T, int64_t a_stride, int inc,
                                 double *out, hipStream_t st);
+hipError_t launch_coswiss_combine(const double *A, int64_t N, int64_t T, int n_out,
+                                  const int32_t *begin, const double *coeff, const int32_t *desc,
+                                  const double *trig, double *out, int64_t out_row_stride,
+                                  hipStream_t st);
 hipError_t launch_standardize(const double *X, int64_t rows, int64_t T, int div_std, double eps,
                               double *out, hipStream_t st);
 

@@ -445,6 +445,38 @@ hipError_t launch_pre_transform(const double *A, int64_t N, int64_t T, int64_t a
   return hipGetLastError();
 }
 
+// CosWISS term reduction (fruits/iss/cos.py:38-48): block (j, n) sums the terms of output
+// row j for series n in the reference's order, `res += coeff * (tmp * sin^a * cos^b)`.
+__global__ __launch_bounds__(256) void coswiss_combine_kernel(
+    const double *__restrict__ A, int64_t N, int64_t T, const int32_t *__restrict__ begin,
+    const double *__restrict__ coeff, const int32_t *__restrict__ desc,
+    const double *__restrict__ trig, double *__restrict__ out, int64_t out_row_stride) {
+#pragma clang fp contract(off)
+  const int64_t j = blockIdx.x / N, n = blockIdx.x % N;
+  const int i0 = begin[j], i1 = begin[j + 1];
+  for (int64_t t = threadIdx.x; t < T; t += 256) {
+    const double sn = trig[t], cs = trig[T + t];
+    double acc = 0.0;
+    for (int i = i0; i < i1; ++i) {
+      double v = A[((int64_t)desc[3 * i] * N + n) * T + t];
+      for (int k = desc[3 * i + 1]; k > 0; --k) v = v * sn;
+      for (int k = desc[3 * i + 2]; k > 0; --k) v = v * cs;
+      acc += coeff[i] * v;
+    }
+    out[j * out_row_stride + n * T + t] = acc;
+  }
+}
+
+hipError_t launch_coswiss_combine(const double *A, int64_t N, int64_t T, int n_out,
+                                  const int32_t *begin, const double *coeff, const int32_t *desc,
+                                  const double *trig, double *out, int64_t out_row_stride,
+                                  hipStream_t st) {
+  if (N <= 0 || T <= 0 || n_out <= 0) return hipSuccess;
+  hipLaunchKernelGGL(coswiss_combine_kernel, dim3((unsigned)(N * n_out)), dim3(256), 0, st, A, N,
+                     T, begin, coeff, desc, trig, out, out_row_stride);
+  return hipGetLastError();
+}
+
 hipError_t launch_standardize(const double *X, int64_t rows, int64_t T, int div_std, double eps,
                               double *out, hipStream_t st) {
   if (rows <= 0 || T <= 0) return hipSuccess;

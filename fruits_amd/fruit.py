@@ -358,6 +358,8 @@ class FruitSlice:
         from .sieving.segment import END
         if os.environ.get("FRUITS_AMD_FUSED", "1") == "0" or len(self._iss) != 1:
             return False
+        if type(self._iss[0]) is not ISS:           # CosWISS reduces terms first
+            return False
         for sv in self._sieves:
             if type(sv) not in (NPI, MPI, END) or sv._has_float_cuts():
                 return False

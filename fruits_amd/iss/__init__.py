@@ -1,3 +1,4 @@
 from . import semiring, weighting, words
 from .cache import CachePlan
+from .cos import CosWISS
 from .iss import ISS, ISSMode

@@ -240,6 +240,23 @@ int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32
 int fr_standardize(const double *d_X, int64_t rows, int64_t T, int32_t div_std, double eps,
                    double *d_out, void *stream);
 
+/* ------------------------------------------------------------------ CosWISS ("next" row)
+ * The cosine weighted ISS (fruits/iss/cos.py:11-49) expands cos(a-b)^s into products of
+ * sin / cos powers (cos.py:265-287); every product ("term") is an ordinary Reals ISS of
+ * the word over the input extended by one sin and one cos row per frequency, i.e. a
+ * fr_plan_create / fr_iss_run program (the terms of all words share prefixes).  This
+ * entry point is the remaining reduction `result += weightings[i,0] * tmp` with the
+ * total-weighting factors of cos.py:38-48:
+ *   d_out[j*out_row_stride + n*T + t] =
+ *       sum_{i in [d_begin[j], d_begin[j+1])} d_coeff[i] * d_terms[d_desc[3i], n, t]
+ *                                             * sin[t]^d_desc[3i+1] * cos[t]^d_desc[3i+2]
+ * summed in ascending i.  d_terms (n_terms, N, T); d_trig (2, T) = sin, cos of one
+ * frequency; all pointers device memory.  Enqueues one kernel, no allocation. */
+int fr_coswiss_combine(const double *d_terms, int64_t n_terms, int64_t N, int64_t T,
+                       int32_t n_out, const int32_t *d_begin, const double *d_coeff,
+                       const int32_t *d_desc, const double *d_trig, double *d_out,
+                       int64_t out_row_stride, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

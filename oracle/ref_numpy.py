@@ -352,6 +352,76 @@ def iss_transform(X, word_strings, mode="SINGLE", alphas=None, lookup=None,
 
 
 # --------------------------------------------------------------------------
+# CosWISS (cosine weighted ISS) - "next" row
+# --------------------------------------------------------------------------
+
+def coswiss_weightings(n_letters, exponent, total):
+    """fruits/iss/cos.py:265-287 (CosWISS._get_weightings): cos(a-b)^s expanded into
+    products of sin/cos powers; row = [coefficient, sin/cos powers per letter ...]."""
+    import itertools as it
+    p = n_letters + 1 if total else n_letters
+    trig_id, trig_exp, coeff = [], [exponent, 0], 1
+    for k in range(exponent + 1):
+        trig_id.append((coeff, trig_exp[0], trig_exp[1]))
+        trig_exp[0] -= 1
+        trig_exp[1] += 1
+        coeff = coeff * (exponent - k) // (k + 1)
+    W = np.zeros(((exponent + 1) ** (p - 1), 2 * p + 1), dtype=np.int32)
+    W[:, 0] = 1
+    for c, comb in enumerate(it.product(trig_id, repeat=p - 1)):
+        for i in range(p - 1):
+            W[c, 0] *= comb[i][0]
+            W[c, 2 * i + 1] += comb[i][1]
+            W[c, 2 * i + 3] += comb[i][1]
+            W[c, 2 * i + 2] += comb[i][2]
+            W[c, 2 * i + 4] += comb[i][2]
+    return W
+
+
+def coswiss_trig(T, freq):
+    """sin / cos tables of fruits/iss/cos.py:23-24.  ``freq`` is float32 in the
+    reference's numba signature (f4) and is promoted to float64 before the product
+    with (T-1); this follows numba's typing (the un-jitted code would multiply in
+    float32) - the goldens use frequencies for which both agree."""
+    f = float(np.float32(freq))
+    ang = np.pi * np.arange(T) / (f * (T - 1))
+    return np.sin(ang), np.cos(ang)
+
+
+def coswiss_transform(X, word_strings, freqs, exponent=2, total=False):
+    """fruits/iss/cos.py:11-49,167-181,289-330 (_coswiss_single, _coswiss,
+    CosWISS.batch_transform without ffn / dropout) -> (W*F, N, T), rows word-major."""
+    N, _, T = X.shape
+    out = np.zeros((len(word_strings) * len(freqs), N, T))
+    for w, ws in enumerate(word_strings):
+        word = parse_word(ws)
+        L = len(word)
+        Wt = coswiss_weightings(L, exponent, total)
+        for f, freq in enumerate(freqs):
+            sin_w, cos_w = coswiss_trig(T, freq)
+            res = np.zeros((N, T))
+            for i in range(Wt.shape[0]):
+                tmp = np.ones((N, T))
+                for k in range(L):
+                    if k > 0:
+                        tmp = _shift(tmp)
+                    tmp = _letters(tmp, X, word[k])
+                    for _ in range(Wt[i, 2 * k + 1]):
+                        tmp = tmp * sin_w
+                    for _ in range(Wt[i, 2 * k + 2]):
+                        tmp = tmp * cos_w
+                    tmp = np.cumsum(tmp, axis=1)
+                if Wt.shape[1] == 2 * L + 3:
+                    for _ in range(Wt[i, 2 * L + 1]):
+                        tmp = tmp * sin_w
+                    for _ in range(Wt[i, 2 * L + 2]):
+                        tmp = tmp * cos_w
+                res += Wt[i, 0] * tmp
+            out[w * len(freqs) + f] = res
+    return out
+
+
+# --------------------------------------------------------------------------
 # sieves
 # --------------------------------------------------------------------------
 
@@ -528,9 +598,13 @@ def _iterate_iss(X, iss_list, X_raw, idx=0):
         yield X[:, 0, :]
         return
     i = iss_list[idx]
-    lookup, total = _weight_lookup(i.get("weighting"), X, X_raw)
-    its = iss_transform(X, i["words"], i["mode"], i.get("alphas"), lookup, total,
-                        i.get("semiring", "Reals"))
+    if i.get("kind") == "CosWISS":
+        its = coswiss_transform(X, i["words"], i["freqs"], i.get("exponent", 2),
+                                i.get("total_weighting", False))
+    else:
+        lookup, total = _weight_lookup(i.get("weighting"), X, X_raw)
+        its = iss_transform(X, i["words"], i["mode"], i.get("alphas"), lookup, total,
+                            i.get("semiring", "Reals"))
     for itsum in its:
         yield from _iterate_iss(itsum[:, None, :], iss_list, X_raw, idx + 1)
 

@@ -301,6 +301,33 @@ iss_case("arctic_config2_ext", ("gen", gen(c2a)), W23, "EXTENDED", store_slice=[
          semiring="Arctic")
 manifest["iss"][-1]["x_gen"] = c2a
 
+# CosWISS ("next" row): frequencies exactly representable in float32 AND with an exact
+# float32 product freq*(T-1), so the un-jitted run agrees with numba's f4->f8 promotion
+manifest["coswiss"] = []
+
+
+def cos_case(name, x_key, words, freqs, **kw):
+    X = arrays[x_key]
+    cw = fruits.CosWISS([fruits.words.SimpleWord(s) for s in words], freqs, **kw)
+    out = cw.fit_transform(X)
+    manifest["coswiss"].append({
+        "name": name, "x": x_key, "words": list(words), "freqs": list(freqs), "kw": kw,
+        "labels": [cw.label(i) for i in range(cw.n_iterated_sums())],
+        "weightings": {s: fruits.CosWISS([fruits.words.SimpleWord(s)], [0.5], **kw)
+                       ._get_weightings(fruits.words.SimpleWord(s)).tolist() for s in words},
+        "out": put(f"cos/{name}", out)})
+
+
+put("U_5_3_65", np.random.default_rng(41).random((5, 3, 65)))   # T-1 = 64
+cos_case("e1", "U_5_3_65", ["[1][23]", "[12][2][33]"], [0.5], exponent=1)
+cos_case("e1_total", "U_5_3_65", ["[1][23]", "[12][2][33]"], [0.5], exponent=1,
+         total_weighting=True)
+cos_case("e2_multi", "U_5_3_65", ["[1]", "[12]", "[1][2]", "[2][13]", "[1][2][3]"],
+         [0.5, 0.25, 2.0], exponent=2)
+cos_case("e2_total_multi", "U_5_3_65", ["[1]", "[1][2]", "[11][2][3]"], [0.25, 1.0],
+         exponent=2, total_weighting=True)
+cos_case("e3", "U_5_3_65", ["[1][-2]", "[3][1][1]"], [0.5], exponent=3)
+
 # per-word operator (iterated_sum_fast, fruits/iss/semiring.py:203-219)
 Z = arrays["U_6_3_40"]
 word = fruits.words.SimpleWord("[12][2][33]")
@@ -419,6 +446,10 @@ def build_fruit(spec):
                 fr.add(getattr(fruits.preparation, kind)(**kw))
         for i in sl["iss"]:
             ws = [fruits.words.SimpleWord(s) for s in i["words"]]
+            if i.get("kind") == "CosWISS":
+                fr.add(fruits.CosWISS(freqs=i["freqs"], words=ws, exponent=i.get("exponent", 2),
+                                      total_weighting=i.get("total_weighting", False)))
+                continue
             fr.add(fruits.ISS(ws, mode=getattr(fruits.ISSMode, i["mode"]),
                               semiring=getattr(fruits.semiring, i.get("semiring", "Reals"))(),
                               weighting=make_weighting(i.get("weighting"))))
@@ -533,6 +564,19 @@ fruit_case("reduced_arctic_small", "G_10_1_128", {"name": "red2", "slices": [
                 {"kind": "MPI", "q": [0.5, 1.0], "inc": 2},
                 {"kind": "END"}],
      "fit_sample_size": 1.0}]}, np_seed=16)
+
+# fruit_reduced slice 3 shape: NEW(INC) -> STD -> CosWISS -> NPI/MPI, END
+put("G_8_1_65", np.random.default_rng(42).standard_normal((8, 1, 65)))
+fruit_case("reduced_coswiss_small", "G_8_1_65", {"name": "red3", "slices": [
+    {"preps": [{"kind": "NEW", "inner": {"kind": "INC"}}, {"kind": "STD"}],
+     "iss": [{"kind": "CosWISS", "words": manifest["words"]["1,2"]["words"]
+              + manifest["words"]["2,2"]["words"], "freqs": [0.5, 0.25], "exponent": 1,
+              "total_weighting": True, "mode": "SINGLE"}],
+     "sieves": [{"kind": "NPI", "q": [0.5, 1.0], "inc": 0},
+                {"kind": "NPI", "q": [0.5, 1.0], "inc": 1},
+                {"kind": "MPI", "q": [0.5, 1.0], "inc": 2},
+                {"kind": "END"}],
+     "fit_sample_size": 1.0}]}, np_seed=17)
 
 # chained ISS (reference tests/signature/test_consecutive.py) with END
 fruit_case("consecutive_end", "U_9_3_60", {"slices": [

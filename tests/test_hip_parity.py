@@ -277,6 +277,53 @@ def test_sieves(fr, case):
     np.testing.assert_array_equal(sv.copy().fit_transform(A) if not case["fit"] else out, out)
 
 
+@pytest.mark.parametrize("case", G.manifest.get("coswiss", []), ids=lambda c: c["name"])
+def test_coswiss_golden(fr, case):
+    # reference tests/signature/test_cosine.py checks the same quantity against a
+    # brute-force definition at rtol 1e-5; here: the reference's output itself
+    X = G[case["x"]]
+    cw = fr.CosWISS([fr.words.SimpleWord(s) for s in case["words"]], case["freqs"], **case["kw"])
+    assert cw.n_iterated_sums() == len(case["labels"])
+    assert [cw.label(i) for i in range(cw.n_iterated_sums())] == case["labels"]
+    for s, w in case["weightings"].items():
+        assert cw._get_weightings(fr.words.SimpleWord(s)).tolist() == w
+    ref = G[case["out"]]
+    out = cw.fit_transform(X)
+    assert out.shape == ref.shape
+    scale = np.abs(ref).max(axis=2, keepdims=True)
+    assert np.all(np.abs(out - ref) <= RTOL * np.maximum(np.abs(ref), 1e-3 * scale))
+    # batch_transform yields batch_size words x all frequencies at a time
+    F = len(case["freqs"])
+    parts = list(cw.batch_transform(X, batch_size=1))
+    assert len(parts) == len(case["words"]) and parts[0].shape[0] == F
+    np.testing.assert_array_equal(np.concatenate(parts), out)
+
+
+def test_coswiss_brute_force(fr):
+    # the definition the reference tests against (tests/signature/test_cosine.py:8-40):
+    # sum_{j<k<=t} x_j y_k cos(pi (k-j) / (f (T-1)))^s, in plain loops
+    rng = np.random.default_rng(5)
+    X = rng.random((3, 2, 24))
+    T, f = 24, 0.7
+    fq = float(np.float32(f))
+    for s in (1, 2):
+        out = fr.CosWISS([fr.words.SimpleWord("[1][2]")], [f], exponent=s).fit_transform(X)
+        g = np.pi * np.arange(T) / (fq * (T - 1))
+        ref = np.zeros((3, T))
+        for k in range(T):
+            for j in range(k):
+                ref[:, k:] += (X[:, 0, j] * X[:, 1, k] * np.cos(g[k] - g[j]) ** s)[:, None]
+        np.testing.assert_allclose(out[0], ref, rtol=1e-9, atol=1e-11)
+
+
+def test_coswiss_unsupported(fr):
+    cw = fr.CosWISS([fr.words.SimpleWord("[1]")], [0.5], dropout=0.5)
+    with pytest.raises(NotImplementedError):
+        cw.transform_device(None)
+    with pytest.raises(ValueError):
+        fr.CosWISS([object()], [0.5])
+
+
 def build_fruit(fr, spec):
     fruit = fr.Fruit(spec.get("name", ""))
     for sl in spec["slices"]:
@@ -292,6 +339,10 @@ def build_fruit(fr, spec):
                 fruit.add(getattr(fr.preparation, p["kind"])(**kw))
         for i in sl["iss"]:
             ws = [fr.words.SimpleWord(s) for s in i["words"]]
+            if i.get("kind") == "CosWISS":
+                fruit.add(fr.CosWISS(freqs=i["freqs"], words=ws, exponent=i.get("exponent", 2),
+                                     total_weighting=i.get("total_weighting", False)))
+                continue
             fruit.add(fr.ISS(ws, mode=getattr(fr.ISSMode, i["mode"]),
                              semiring=getattr(fr.semiring, i.get("semiring", "Reals"))(),
                              weighting=make_weighting(fr, i.get("weighting"))))

@@ -302,3 +302,22 @@ def test_fruit_api_errors():
     f2.add(fr.preparation.INC(zero_padding=False))
     f2.add(fr.ISS(fr.words.of_weight(4, dim=2)))
     assert len(f2.get_slice().get_iss()[0].words) == 82
+
+
+@pytest.mark.parametrize("case", G.manifest.get("coswiss", []), ids=lambda c: c["name"])
+def test_coswiss_host_tables(case):
+    # expansion table, labels and term programs of CosWISS (fruits/iss/cos.py:230-287,345-351)
+    cw = fr.CosWISS([fr.words.SimpleWord(s) for s in case["words"]], case["freqs"], **case["kw"])
+    assert cw.n_iterated_sums() == len(case["labels"])
+    assert [cw.label(i) for i in range(cw.n_iterated_sums())] == case["labels"]
+    assert not cw.requires_fitting
+    for s, w in case["weightings"].items():
+        assert cw._get_weightings(fr.words.SimpleWord(s)).tolist() == w
+    T = G[case["x"]].shape[2]
+    trig = cw._trig(T)
+    for f, freq in enumerate(case["freqs"]):
+        sn, cs = orc.coswiss_trig(T, freq)
+        np.testing.assert_array_equal(trig[f, 0], sn)
+        np.testing.assert_array_equal(trig[f, 1], cs)
+    c2 = cw._copy()
+    assert c2._freqs == cw._freqs and c2._exponent == cw._exponent

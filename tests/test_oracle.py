@@ -113,3 +113,15 @@ def test_fruit(case):
         np.testing.assert_allclose(
             orc.fruit_transform(case["spec"], fitted, G[case["x_test"]]),
             G[case["out_test"]], **RT)
+
+
+@pytest.mark.parametrize("case", G.manifest.get("coswiss", []), ids=lambda c: c["name"])
+def test_coswiss(case):
+    kw = case["kw"]
+    out = orc.coswiss_transform(G[case["x"]], case["words"], case["freqs"],
+                                kw.get("exponent", 2), kw.get("total_weighting", False))
+    np.testing.assert_allclose(out, G[case["out"]], rtol=1e-11, atol=1e-12)
+    for s, w in case["weightings"].items():
+        got = orc.coswiss_weightings(len(orc.parse_word(s)), kw.get("exponent", 2),
+                                     kw.get("total_weighting", False))
+        assert got.tolist() == w
