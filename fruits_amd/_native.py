@@ -31,7 +31,7 @@ EXPORTS = [
     "fr_pathlen_lookup", "fr_sieve", "fr_pre_transform", "fr_standardize",
     "fr_pipeline_create", "fr_pipeline_destroy", "fr_pipeline_info",
     "fr_pipeline_workspace_bytes", "fr_pipeline_run", "fr_pipeline_set_quantiles",
-    "fr_select_ranks", "fr_coswiss_combine",
+    "fr_select_ranks", "fr_coswiss_combine", "fr_plan_create_coswiss",
 ]
 
 _lib = None
@@ -65,6 +65,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     L.fr_last_error.restype = C.c_char_p
     L.fr_plan_create.restype = C.c_void_p
+    L.fr_plan_create_coswiss.restype = C.c_void_p
     L.fr_plan_destroy.restype = None
     L.fr_plan_destroy.argtypes = [C.c_void_p]
     L.fr_plan_info.restype = C.c_int64
@@ -257,6 +258,35 @@ class Plan:
             stream_ptr())
         check(rc, "fr_iss_run")
         return out
+
+
+class CosPlan(Plan):
+    """Device program of a cosine weighted ISS (fr_plan_create_coswiss): rows
+    word-major, ``len(freqs)`` rows per word."""
+
+    MAX_EXPONENT = 4
+    MAX_LETTERS = 16
+
+    def __init__(self, words: Sequence[np.ndarray], freqs, exponent: int, total: bool):
+        L = lib()
+        self._h = None
+        mats = [np.ascontiguousarray(w, dtype=np.int32) for w in words]
+        W = len(mats)
+        exps = (np.concatenate([m.ravel() for m in mats]) if W else
+                np.zeros(0, np.int32)).astype(np.int32)
+        Ls = np.array([m.shape[0] for m in mats], dtype=np.int32)
+        Dws = np.array([m.shape[1] for m in mats], dtype=np.int32)
+        fq = np.asarray(freqs, dtype=np.float32).ravel()
+        ip = C.POINTER(C.c_int32)
+        h = L.fr_plan_create_coswiss(
+            C.c_int32(W), exps.ctypes.data_as(ip), Ls.ctypes.data_as(ip), Dws.ctypes.data_as(ip),
+            C.c_int32(fq.size), fq.ctypes.data_as(C.POINTER(C.c_float)), C.c_int32(exponent),
+            C.c_int32(1 if total else 0))
+        if not h:
+            raise ValueError(last_error())
+        self._h = C.c_void_p(h)
+        self.weighting = FR_W_NONE
+        self.n_words = W
 
 
 class Pipeline:

@@ -82,6 +82,34 @@ int ensure_device_program(fr::Plan &p, fr::GroupedProgram &gp) {
   return FR_OK;
 }
 
+int ensure_cos_program(fr::CosProgram &c) {
+  if (c.d_blob) return FR_OK;
+  size_t off = 0;
+  const size_t o_lb = off;    off = align_up(off + c.letter_begin.size() * 4, 64);
+  const size_t o_fb = off;    off = align_up(off + c.fac_begin.size() * 4, 64);
+  const size_t o_fac = off;   off = align_up(off + c.factors.size() * 4, 64);
+  const size_t o_fr = off;    off = align_up(off + c.freqs.size() * 4, 64);
+  std::vector<char> host(off + 64, 0);
+  std::memcpy(host.data() + o_lb, c.letter_begin.data(), c.letter_begin.size() * 4);
+  std::memcpy(host.data() + o_fb, c.fac_begin.data(), c.fac_begin.size() * 4);
+  std::memcpy(host.data() + o_fac, c.factors.data(), c.factors.size() * 4);
+  std::memcpy(host.data() + o_fr, c.freqs.data(), c.freqs.size() * 4);
+  void *d = nullptr;
+  HIP_TRY(hipMalloc(&d, host.size()));
+  hipError_t e = hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    return hip_fail(e, "hipMemcpy(coswiss program)");
+  }
+  char *b = static_cast<char *>(d);
+  c.d_blob = d;
+  c.d_letter_begin = reinterpret_cast<const int32_t *>(b + o_lb);
+  c.d_fac_begin = reinterpret_cast<const int32_t *>(b + o_fb);
+  c.d_factors = reinterpret_cast<const int32_t *>(b + o_fac);
+  c.d_freqs = reinterpret_cast<const float *>(b + o_fr);
+  return FR_OK;
+}
+
 int choose_groups(const fr::Plan &p, int64_t N, int requested) {
   const int U = p.units();
   if (U <= 1) return 1;
@@ -104,6 +132,10 @@ struct WorkLayout {
 
 WorkLayout work_layout(const fr::Plan &p, int64_t N, int64_t T, int64_t lookup_rows) {
   WorkLayout w;
+  if (p.cos) {  // the (F, 2, T) sin / cos tables
+    w.aux_bytes = align_up((size_t)p.cos->F * 2 * (size_t)T * 8, 256);
+    return w;
+  }
   if (p.weighting != 0)
     w.aux_bytes = align_up((size_t)p.aux_tables() * (size_t)lookup_rows * (size_t)T * 8, 256);
   if (T > fr::walk_chunk_elems(T))
@@ -180,9 +212,28 @@ fr_plan_t *fr_plan_create(int32_t W, const int32_t *exps, const int32_t *L, cons
   return h;
 }
 
+fr_plan_t *fr_plan_create_coswiss(int32_t W, const int32_t *exps, const int32_t *L,
+                                  const int32_t *Dw, int32_t n_freqs, const float *freqs,
+                                  int32_t exponent, int32_t total_weighting) {
+  std::string err;
+  fr::Plan *p = fr::build_coswiss_plan(W, exps, L, Dw, n_freqs, freqs, exponent,
+                                       total_weighting, err);
+  if (!p) {
+    g_err = err;
+    return nullptr;
+  }
+  fr_plan_t *h = new fr_plan_t;
+  h->p = p;
+  return h;
+}
+
 void fr_plan_destroy(fr_plan_t *plan) {
   if (!plan) return;
   if (plan->p) {
+    if (plan->p->cos) {
+      if (plan->p->cos->d_blob) (void)hipFree(plan->p->cos->d_blob);
+      delete plan->p->cos;
+    }
     for (auto &kv : plan->p->programs)
       if (kv.second.d_blob) (void)hipFree(kv.second.d_blob);
     delete plan->p;
@@ -253,8 +304,51 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   if (p.max_dim > D)
     return fail(FR_E_DIM, w + ": a word references dimension " + std::to_string(p.max_dim) +
                               " but the input has only " + std::to_string(D));
-  if (N == 0 || T == 0 || p.K == 0 || p.nodes.empty()) return FR_OK;
+  if (N == 0 || T == 0 || p.K == 0 || (!p.cos && p.nodes.empty())) return FR_OK;
   if (!d_X || (!fu && !d_out)) return fail(FR_E_ARG, w + ": null device pointer");
+  if (p.cos) {
+    fr::CosProgram &c = *p.cos;
+    if (c.exponent > fr::kCosMaxExponent || p.levels > 16)
+      return fail(FR_E_LIMIT, w + ": CosWISS kernels cover exponents <= 4 and words of <= 16 "
+                              "letters");
+    const size_t need = work_layout(p, N, T, 0).total();
+    if (!d_work || (size_t)work_bytes < need)
+      return fail(FR_E_NOMEM, w + ": workspace too small (need " + std::to_string(need) +
+                                  " bytes)");
+    int rc = ensure_cos_program(c);
+    if (rc != FR_OK) return rc;
+    double *trig = static_cast<double *>(d_work);
+    hipError_t e = fr::launch_trig_tables(c.d_freqs, c.F, T, trig, st);
+    if (e != hipSuccess) return hip_fail(e, "trig_tables launch");
+    fr::IssArgs a{};
+    a.X = d_X;
+    a.aux = trig;
+    a.out = d_out;
+    a.N = N;
+    a.D = D;
+    a.T = T;
+    a.out_k_stride = out_k_stride;
+    a.out_n_stride = out_n_stride;
+    a.factors = c.d_factors;
+    a.cw_letter_begin = c.d_letter_begin;
+    a.cw_fac_begin = c.d_fac_begin;
+    a.cw_W = c.W;
+    a.cw_F = c.F;
+    a.cw_total = c.total ? 1 : 0;
+    a.vec_ok = (T % 2 == 0) && aligned16(d_X) && aligned16(trig) &&
+               (fu || (aligned16(d_out) && (out_k_stride % 2 == 0) && (out_n_stride % 2 == 0)));
+    if (fu) {
+      a.ops = fu->ops;
+      a.feats = fu->feats;
+      a.cnt = fu->cnt;
+      a.feat_stride = fu->feat_stride;
+      a.n_ops = fu->n_ops;
+      a.n_ops_padded = fu->n_ops_padded;
+    }
+    e = fr::launch_coswiss(a, c.exponent, st);
+    if (e != hipSuccess) return hip_fail(e, "coswiss launch");
+    return FR_OK;
+  }
   if (p.weighting != 0) {
     if (!d_lookup) return fail(FR_E_ARG, w + ": weighted plan needs a lookup");
     if (lookup_rows != 1 && lookup_rows != N)

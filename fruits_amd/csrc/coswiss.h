@@ -1,0 +1,232 @@
+// Cosine weighted ISS (fruits/iss/cos.py) for gfx950 - the "next" row behind the ISS
+// hot path, built from the same pieces as the trie walk (walk.h).
+//
+// The reference expands every cos(g_a - g_b)^S between two consecutive letters into
+// sum_m C(S,m) (sin g_a sin g_b)^(S-m) (cos g_a cos g_b)^m and then evaluates ALL
+// (S+1)^(p-1) products of those terms as separate iterated sums (cos.py:11-49,
+// 265-287).  The sum over the terms factorises letter by letter: with
+// q_m[t] = sin^(S-m)[t] * cos^m[t],
+//     A_m^(0)  = cumsum(letter_0 * q_m)
+//     u^(k)    = sum_m C(S,m) * q_m * shift(A_m^(k-1))
+//     A_m^(k)  = cumsum(u^(k) * letter_k * q_m)          (S+1 scans per letter)
+// and the result is cumsum(u^(L-1) * letter_(L-1)) or, with total weighting,
+// sum_m C(S,m) q_m A_m^(L-1).  That is (S+1)*L scans instead of up to
+// (S+1)^L * L, the same value up to the rounding of a re-associated sum (the
+// reference itself is compiled with fastmath=True).
+//
+// One 256-thread workgroup per (series n, word w, frequency f); the S+1 running
+// prefixes live in registers, rows are read straight from global memory in the
+// walk kernel's lane layout (they are L2 hits: all W*F units of a series run
+// back to back), only wave totals cross waves (block_scan of walk.h).
+#pragma once
+#include "walk.h"
+
+namespace fr {
+
+constexpr int kCosMaxLetters = 16;  // carry slots reserved per unit (multi-chunk series)
+
+template <class C>
+__device__ __forceinline__ void load_global_row(const WalkCtx &cx, const double *gp,
+                                                double (&v)[C::EP]) {
+  // gp = row + t0; the lane's elements in the layout of read_row / emit_store
+  constexpr int E = C::E, P = C::P;
+  static_assert(E == 2, "written for E = 2");
+  const int64_t T = cx.a->T;
+#pragma unroll
+  for (int h = 0; h < P; ++h) {
+    const int idx = cx.wave * C::SPAN + h * C::PIECE + cx.lane * E;
+    const int64_t t = cx.t0 + idx;
+    if (cx.a->vec_ok) {
+      vd2 q = {0.0, 0.0};
+      if (cx.full_chunk || t < T) q = *reinterpret_cast<const vd2 *>(gp + idx);
+      v[h * 2] = q.x;
+      v[h * 2 + 1] = q.y;
+    } else {
+      v[h * 2] = t < T ? gp[idx] : 0.0;
+      v[h * 2 + 1] = t + 1 < T ? gp[idx + 1] : 0.0;
+    }
+  }
+}
+
+// v *= sin^(S-M) * cos^M by repeated multiplication, sines first (cos.py:37-40)
+template <int S, int M, int EP>
+__device__ __forceinline__ void mul_trig(double (&v)[EP], const double (&sn)[EP],
+                                         const double (&cs)[EP]) {
+#pragma unroll
+  for (int k = 0; k < S - M; ++k)
+#pragma unroll
+    for (int i = 0; i < EP; ++i) v[i] = v[i] * sn[i];
+#pragma unroll
+  for (int k = 0; k < M; ++k)
+#pragma unroll
+    for (int i = 0; i < EP; ++i) v[i] = v[i] * cs[i];
+}
+
+constexpr double cos_binom(int s, int m) {
+  double c = 1.0;
+  for (int k = 0; k < m; ++k) c = c * (s - k) / (k + 1);
+  return c;
+}
+
+template <class C, int S>
+struct CosState {
+  double xa[S + 1][C::EP];  // exclusive prefixes of the previous letter's S+1 scans
+  double sn[C::EP], cs[C::EP];
+  bool last;
+};
+
+// scan number M of one letter: A_M = cumsum(s * q_M)
+template <class C, int S, int M>
+__device__ __forceinline__ void cos_scan(WalkCtx &cx, CosState<C, S> &st,
+                                         const double (&s)[C::EP], int slot,
+                                         double (&res)[C::EP]) {
+  constexpr int EP = C::EP;
+  double v[EP], c[EP];
+#pragma unroll
+  for (int i = 0; i < EP; ++i) v[i] = s[i];
+  mul_trig<S, M, EP>(v, st.sn, st.cs);
+  block_scan<C>(cx, v, c, st.xa[M], slot + M);
+  if (st.last) {  // total weighting: result += C(S,M) * (A_M * q_M), cos.py:42-48
+    mul_trig<S, M, EP>(c, st.sn, st.cs);
+#pragma unroll
+    for (int i = 0; i < EP; ++i) res[i] += cos_binom(S, M) * c[i];
+  }
+  if constexpr (M < S) cos_scan<C, S, M + 1>(cx, st, s, slot, res);
+}
+
+template <class C, int S, int M>
+__device__ __forceinline__ void cos_combine(const CosState<C, S> &st, double (&u)[C::EP]) {
+  constexpr int EP = C::EP;
+  double v[EP];
+#pragma unroll
+  for (int i = 0; i < EP; ++i) v[i] = st.xa[M][i];
+  mul_trig<S, M, EP>(v, st.sn, st.cs);
+#pragma unroll
+  for (int i = 0; i < EP; ++i) u[i] += cos_binom(S, M) * v[i];
+  if constexpr (M < S) cos_combine<C, S, M + 1>(st, u);
+}
+
+// one (series, word, frequency) unit for one time chunk
+template <class C, int S>
+__device__ __forceinline__ void coswiss_unit(WalkCtx &cx, const double *xrow, const double *trig,
+                                             int lb, int le, bool total, int k_out) {
+  constexpr int EP = C::EP;
+  const IssArgs &a = *cx.a;
+  CosState<C, S> st;
+  double res[EP], resx[EP];
+  load_global_row<C>(cx, trig, st.sn);
+  load_global_row<C>(cx, trig + a.T, st.cs);
+  Ops2 pre;
+  if constexpr (C::MODE == 1) pre = load_ops2(a, k_out, 0);
+#pragma unroll
+  for (int i = 0; i < EP; ++i) res[i] = resx[i] = 0.0;
+  const int L = le - lb;
+  for (int k = 0; k < L; ++k) {
+    double s[EP];
+    if (k == 0) {
+#pragma unroll
+      for (int i = 0; i < EP; ++i) s[i] = 1.0;
+    } else {
+#pragma unroll
+      for (int i = 0; i < EP; ++i) s[i] = 0.0;
+      cos_combine<C, S, 0>(st, s);
+    }
+    // the letters, one factor per occurrence in ascending dimension (cos.py:30-36)
+    const int fb = as_const(a.cw_fac_begin)[lb + k], fe = as_const(a.cw_fac_begin)[lb + k + 1];
+    for (int f = fb; f < fe; ++f) {
+      const int code = as_const(a.factors)[f];
+      double v[EP];
+      load_global_row<C>(cx, xrow + (int64_t)(code & FAC_ROW_MASK) * a.T, v);
+      if (code & FAC_DIV) {
+#pragma unroll
+        for (int i = 0; i < EP; ++i) s[i] = s[i] / v[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < EP; ++i) s[i] = s[i] * v[i];
+      }
+    }
+    const int slot = k * (S + 1);
+    st.last = k == L - 1;
+    if (st.last && !total) {
+      block_scan<C>(cx, s, res, resx, slot);
+      break;
+    }
+    cos_scan<C, S, 0>(cx, st, s, slot, res);
+  }
+  if constexpr (C::MODE == 1) {
+    Rec nd;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) nd.w[i] = 0;
+    nd.w[6] = 1;
+    nd.w[7] = k_out;
+    cx.slot = kCosMaxLetters * (S + 1);
+    if (total) prev_first_differences<C>(cx, res, resx);  // resx[t] = res[t-1]
+    cx.slot += 3;
+    fused_all<C>(cx, nd, pre, res, resx);
+  } else {
+    emit_store<C>(cx, res, cx.out_base + (int64_t)k_out * a.out_k_stride);
+  }
+}
+
+template <class C, int S>
+__global__ __launch_bounds__(kWalkThreads) void coswiss_kernel(const IssArgs a) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x;
+  WalkCtx cx;
+  cx.a = &a;
+  cx.rows = nullptr;
+  cx.tot = lds;
+  cx.tail = lds + 2 * C::NW;
+  cx.carry = lds + 4 * C::NW;
+  cx.tid = tid;
+  cx.lane = tid & 63;
+  cx.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  cx.team = 0;
+  cx.buf = 0;
+  cx.tail_buf = 0;
+  cx.pc_begin = 0;
+  const int64_t per_series = (int64_t)a.cw_W * a.cw_F;
+  const int64_t units = a.N * per_series;
+  for (int64_t u = blockIdx.x; u < units; u += gridDim.x) {
+    const int64_t n = u / per_series;
+    const int j = (int)(u % per_series);
+    const int w = j / a.cw_F, f = j % a.cw_F;
+    const int lb = as_const(a.cw_letter_begin)[w], le = as_const(a.cw_letter_begin)[w + 1];
+    for (int64_t chunk = 0; chunk < a.nchunks; ++chunk) {
+      const int64_t t0 = chunk * C::CHUNK;
+      cx.t0 = t0;
+      cx.first_chunk = chunk == 0;
+      cx.full_chunk = t0 + C::CHUNK <= a.T;
+      cx.out_base = a.out + n * a.out_n_stride + t0;
+      if constexpr (C::MODE == 1) {
+        cx.feat_row = a.feats + n * a.feat_stride;
+        cx.cnt_row = a.cnt + n * a.feat_stride;
+      }
+      coswiss_unit<C, S>(cx, a.X + n * a.D * a.T + t0, a.aux + (int64_t)f * 2 * a.T + t0, lb, le,
+                         a.cw_total != 0, j);
+    }
+  }
+}
+
+template <int P, int MULTI, bool VEC, int MODE, int S>
+static hipError_t launch_coswiss_cfg(const IssArgs &a, hipStream_t st) {
+  using C = WalkCfg<2, P, 1, MULTI, VEC, false, 4, MODE, 0>;
+  const size_t lds = (4 * C::NW + (kCosMaxLetters * (S + 1) + 8)) * sizeof(double);
+  const int64_t units = a.N * a.cw_W * a.cw_F;
+  static int per_cu = 0;
+  if (per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, coswiss_kernel<C, S>, kWalkThreads,
+                                                     lds) != hipSuccess || nb < 1)
+      nb = 1;
+    per_cu = nb;
+  }
+  int64_t blocks = (int64_t)per_cu * device_cu_count();
+  if (blocks > units) blocks = units;
+  if (blocks < 1) return hipSuccess;
+  hipLaunchKernelGGL((coswiss_kernel<C, S>), dim3((unsigned)blocks), dim3(kWalkThreads), lds, st,
+                     a);
+  return hipGetLastError();
+}
+
+}  // namespace fr

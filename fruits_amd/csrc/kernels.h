@@ -55,6 +55,12 @@ struct IssArgs {
   double *cnt;              // same shape: band population of MPI features
   int64_t feat_stride;
   int32_t n_ops, n_ops_padded;
+  // CosWISS programs (coswiss.h): letters of word w = [cw_letter_begin[w], ..+1), factors of
+  // letter l = factors[cw_fac_begin[l] .. cw_fac_begin[l+1]) as dimension | FAC_DIV; aux
+  // holds the (F, 2, T) sin / cos tables
+  const int32_t *cw_letter_begin;
+  const int32_t *cw_fac_begin;
+  int32_t cw_W, cw_F, cw_total;
   unsigned long long *dbg;  // diagnostic stamps (timing build only)
   int32_t debug;            // timing experiments (FRUITS_HIP_DEBUG), 0 in production
 };
@@ -79,6 +85,9 @@ hipError_t launch_select_ranks(void *jobs, int n_jobs, int64_t N, int64_t T, uns
 constexpr int kSelJobBytes = 32;
 hipError_t launch_pre_transform(const double *A, int64_t N, int64_t T, int64_t a_stride, int inc,
                                 double *out, hipStream_t st);
+constexpr int kCosMaxExponent = 4;
+hipError_t launch_coswiss(IssArgs &a, int exponent, hipStream_t st);
+hipError_t launch_trig_tables(const float *freqs, int F, int64_t T, double *out, hipStream_t st);
 hipError_t launch_coswiss_combine(const double *A, int64_t N, int64_t T, int n_out,
                                   const int32_t *begin, const double *coeff, const int32_t *desc,
                                   const double *trig, double *out, int64_t out_row_stride,

@@ -368,6 +368,49 @@ hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st) {
   return walk_inst_m0_l8(a, chunk, st);
 }
 
+// CosWISS: one kernel per (series, word, frequency) unit, see coswiss.h
+hipError_t coswiss_inst_s1(const IssArgs &, int, hipStream_t);
+hipError_t coswiss_inst_s2(const IssArgs &, int, hipStream_t);
+hipError_t coswiss_inst_s3(const IssArgs &, int, hipStream_t);
+hipError_t coswiss_inst_s4(const IssArgs &, int, hipStream_t);
+
+hipError_t launch_coswiss(IssArgs &a, int exponent, hipStream_t st) {
+  const int chunk = walk_chunk_elems(a.T);
+  a.nchunks = (int32_t)((a.T + chunk - 1) / chunk);
+  if (a.N * a.cw_W * a.cw_F <= 0) return hipSuccess;
+  switch (exponent) {
+    case 1: return coswiss_inst_s1(a, chunk, st);
+    case 2: return coswiss_inst_s2(a, chunk, st);
+    case 3: return coswiss_inst_s3(a, chunk, st);
+    case 4: return coswiss_inst_s4(a, chunk, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// sin / cos tables of fruits/iss/cos.py:23-24; the float32 frequency is promoted to
+// double before the product with T-1 (numba's typing of the reference's f4 argument)
+__global__ void trig_tables_kernel(const float *__restrict__ freqs, int F, int64_t T,
+                                   double *__restrict__ out) {
+  const int64_t total = (int64_t)F * T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t f = i / T, t = i % T;
+    const double ang = (3.14159265358979323846 * (double)t) / ((double)freqs[f] * (double)(T - 1));
+    out[(f * 2) * T + t] = sin(ang);
+    out[(f * 2 + 1) * T + t] = cos(ang);
+  }
+}
+
+hipError_t launch_trig_tables(const float *freqs, int F, int64_t T, double *out, hipStream_t st) {
+  const int64_t total = (int64_t)F * T;
+  if (total <= 0) return hipSuccess;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(trig_tables_kernel, dim3((unsigned)blocks), dim3(256), 0, st, freqs, F, T,
+                     out);
+  return hipGetLastError();
+}
+
 // MPI features: mean = sum / population (0 for an empty band, increment.py:158-161)
 __global__ void mpi_finalize_kernel(double *__restrict__ feats, const double *__restrict__ cnt,
                                     int64_t N, int64_t stride, const int32_t *__restrict__ cols,

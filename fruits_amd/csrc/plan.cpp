@@ -126,6 +126,59 @@ double node_cost(const NodeDesc &nd) {
 
 }  // namespace
 
+Plan *build_coswiss_plan(int W, const int32_t *exps, const int32_t *L, const int32_t *Dw, int F,
+                         const float *freqs, int exponent, int total, std::string &err) {
+  if (W < 0 || F < 0 || (W > 0 && (!exps || !L || !Dw)) || (F > 0 && !freqs)) {
+    err = "fr_plan_create_coswiss: null argument";
+    return nullptr;
+  }
+  if (exponent < 1) {
+    err = "fr_plan_create_coswiss: exponent must be >= 1";
+    return nullptr;
+  }
+  Plan *p = new Plan();
+  CosProgram *c = new CosProgram();
+  p->cos = c;
+  p->W = W;
+  p->K = W * F;
+  c->W = W;
+  c->F = F;
+  c->exponent = exponent;
+  c->total = total != 0;
+  c->freqs.assign(freqs, freqs + F);
+  c->letter_begin.push_back(0);
+  c->fac_begin.push_back(0);
+  const int32_t *e = exps;
+  for (int i = 0; i < W; ++i) {
+    if (L[i] < 1 || Dw[i] < 1) {
+      err = "fr_plan_create_coswiss: word " + std::to_string(i) + " has invalid L/Dw";
+      delete c;
+      delete p;
+      return nullptr;
+    }
+    for (int k = 0; k < L[i]; ++k) {
+      for (int d = 0; d < Dw[i]; ++d) {
+        const int32_t el = e[k * Dw[i] + d];
+        if (el == 0) continue;
+        if (d > FAC_ROW_MASK) {
+          err = "fr_plan_create_coswiss: dimension beyond " + std::to_string(FAC_ROW_MASK + 1);
+          delete c;
+          delete p;
+          return nullptr;
+        }
+        for (int r = 0; r < (el < 0 ? -el : el); ++r)
+          c->factors.push_back(d | (el < 0 ? FAC_DIV : 0));
+        p->max_dim = std::max(p->max_dim, d + 1);
+      }
+      c->fac_begin.push_back((int32_t)c->factors.size());
+    }
+    p->levels = std::max(p->levels, (int)L[i]);
+    c->letter_begin.push_back((int32_t)c->fac_begin.size() - 1);
+    e += (size_t)L[i] * Dw[i];
+  }
+  return p;
+}
+
 Plan *build_plan(int W, const int32_t *exps, const int32_t *L, const int32_t *Dw,
                  const float *alpha, const int32_t *depth, int weighting, int flags,
                  std::string &err) {

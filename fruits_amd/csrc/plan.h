@@ -70,7 +70,23 @@ struct GroupedProgram {       // node order for one choice of G (groups per seri
   const float *d_alphas = nullptr;
 };
 
+// Program of a cosine weighted ISS (fruits/iss/cos.py): the letters of every word as
+// factor codes (dimension | FAC_DIV, one per occurrence, ascending dimension) plus the
+// frequencies; evaluated by coswiss_kernel (coswiss.h), one unit per (word, frequency).
+struct CosProgram {
+  int W = 0, F = 0, exponent = 0;
+  bool total = false;
+  std::vector<float> freqs;
+  std::vector<int32_t> letter_begin;   // W+1
+  std::vector<int32_t> fac_begin;      // letters+1
+  std::vector<int32_t> factors;
+  void *d_blob = nullptr;
+  const int32_t *d_letter_begin = nullptr, *d_fac_begin = nullptr, *d_factors = nullptr;
+  const float *d_freqs = nullptr;
+};
+
 struct Plan {
+  CosProgram *cos = nullptr;  // non-null: a CosWISS program (no trie, K = W*F)
   int W = 0;
   int weighting = 0;
   int semiring = kSemiReals;
@@ -101,6 +117,9 @@ struct Plan {
 Plan *build_plan(int W, const int32_t *exps, const int32_t *L, const int32_t *Dw,
                  const float *alpha, const int32_t *depth, int weighting, int flags,
                  std::string &err);
+// CosWISS program of W simple words x F frequencies (rows word-major, cos.py:167-181).
+Plan *build_coswiss_plan(int W, const int32_t *exps, const int32_t *L, const int32_t *Dw, int F,
+                         const float *freqs, int exponent, int total, std::string &err);
 // Node order for G groups (LPT assignment of units to groups), cached in the plan.
 GroupedProgram &grouped(Plan &p, int G);
 

@@ -417,14 +417,19 @@ __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w,
   if (kind == FR_SIEVE_END_K) {
     const int rel = w[2] - (int)cx.t0;  // w[2] = index of the value to pick
     if (rel >= 0 && rel < C::CHUNK) {
-      const int wv = rel / C::SPAN, in = rel % C::SPAN;
-      const int sel = (in / C::PIECE) * E + (in % E), ln = (in % C::PIECE) / E;
-      double val = c[0];
+      const int wv = rel / C::SPAN;
+      if (cx.wave == wv) {
+        // every lane compares the positions of its own elements (static register
+        // indices: a computed index into c[] would send the array through scratch).
+        // An add onto the zero-initialised feature, so that this buffer only ever sees
+        // atomics: a plain store here would make the compiler drain vmcnt first.
+        const int in = rel - wv * C::SPAN - cx.lane * E;
 #pragma unroll
-      for (int i = 1; i < EP; ++i) val = (sel == i) ? c[i] : val;
-      // (an add onto the zero-initialised feature, so that this buffer only ever sees
-      // atomics: a plain store here would make the compiler drain vmcnt first)
-      if (cx.wave == wv && cx.lane == ln) unsafeAtomicAdd(&cx.feat_row[col], val);
+        for (int h = 0; h < P; ++h)
+#pragma unroll
+          for (int e = 0; e < E; ++e)
+            if (in == h * C::PIECE + e) unsafeAtomicAdd(&cx.feat_row[col], c[h * E + e]);
+      }
     }
     return;
   }

@@ -358,8 +358,11 @@ class FruitSlice:
         from .sieving.segment import END
         if os.environ.get("FRUITS_AMD_FUSED", "1") == "0" or len(self._iss) != 1:
             return False
-        if type(self._iss[0]) is not ISS:           # CosWISS reduces terms first
-            return False
+        if type(self._iss[0]) is not ISS:
+            from .iss.cos import CosWISS
+            # the factorised CosWISS kernels fuse; the term-by-term path reduces first
+            if type(self._iss[0]) is not CosWISS or not self._iss[0]._native():
+                return False
         for sv in self._sieves:
             if type(sv) not in (NPI, MPI, END) or sv._has_float_cuts():
                 return False

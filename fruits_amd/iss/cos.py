@@ -4,15 +4,21 @@ dropout variants).
 ``cos(pi*(i_k - i_{k+1})/(f*(T-1)))**s`` expands into products of powers of
 ``sin`` and ``cos`` of the single time steps (fruits/iss/cos.py:265-287), so every
 product - a *term* - is an ordinary Reals iterated sum of the word over the input
-extended by one sin and one cos row.  The reference evaluates the terms one after
-another in numba (cos.py:11-49); here all terms of all words of one frequency are
-compiled into ONE prefix-sharing device program (the same walk kernel as
-``ISS``), and ``fr_coswiss_combine`` reduces them with the binomial coefficients
-in the reference's order.
+extended by one sin and one cos row.  The reference evaluates the
+``(s+1)**(p-1)`` terms one after another in numba (cos.py:11-49).  Two device paths:
+
+* exponents 1..4 (``fr_plan_create_coswiss``, csrc/coswiss.h): the sum over the terms
+  factorises letter by letter, so one workgroup per (series, word, frequency) needs
+  ``s+1`` scans per letter; the plan behaves like any other (``fr_iss_run``, fused
+  sieve pipelines).
+* larger exponents: the reference's own formulation - all terms of all words of one
+  frequency compiled into ONE prefix-sharing walk program, reduced by
+  ``fr_coswiss_combine`` in the reference's order.
 """
 from __future__ import annotations
 
 import itertools
+import os
 from typing import Generator, Optional, Sequence
 
 import numpy as np
@@ -116,6 +122,21 @@ class CosWISS(ISS):
         self._programs[key] = prog
         return prog
 
+    def _native(self) -> bool:
+        """Whether the factorised device kernels cover this configuration."""
+        return (1 <= self._exponent <= nat.CosPlan.MAX_EXPONENT
+                and max((len(w) for w in self.words), default=0) <= nat.CosPlan.MAX_LETTERS
+                and os.environ.get("FRUITS_AMD_COSWISS_TERMS", "0") != "1")
+
+    def _plan(self, start: int, stop: int) -> nat.Plan:
+        key = ("cos", start, stop)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = nat.CosPlan([self.words[i].table() for i in range(start, stop)],
+                               self._freqs, self._exponent, self._total_weighting)
+            self._plans[key] = plan
+        return plan
+
     def _n_terms(self, w: int) -> int:
         p = len(self.words[w]) + 1 if self._total_weighting else len(self.words[w])
         return (self._exponent + 1) ** (p - 1)
@@ -132,11 +153,15 @@ class CosWISS(ISS):
         if batch_size is not None:
             return [(s, min(s + batch_size, W)) for s in range(0, W, batch_size)]
         budget = max(_device_budget_bytes() // max(8 * N * T, 1), 1)
+        native = self._native()
         out, s = [], 0
         while s < W:
             e, rows = s, 0
-            while e < W and (e == s or rows + self._n_terms(e) + len(self._freqs) <= budget):
-                rows += self._n_terms(e) + len(self._freqs)
+            while e < W:
+                need = len(self._freqs) + (0 if native else self._n_terms(e))
+                if e > s and rows + need > budget:
+                    break
+                rows += need
                 e += 1
             out.append((s, e))
             s = e
@@ -156,6 +181,12 @@ class CosWISS(ISS):
             out = t.empty(((stop - start) * F, N, T), dtype=t.float64, device=Xd.device)
         if out.numel() == 0 or stop == start:
             return out
+        if self._native():
+            plan = self._plan(start, stop)
+            if plan.max_dim > D:
+                raise IndexError(
+                    f"a word references dimension {plan.max_dim} but the input has only {D}")
+            return plan.run(Xd, None, out=out, layout="KNT")
         plan, begin_d, coeff_d, desc_d = self._program(start, stop, D)
         trig = t.from_numpy(self._trig(T)).to(Xd.device)              # (F, 2, T)
         Xa = t.empty((N, D + 2, T), dtype=t.float64, device=Xd.device)

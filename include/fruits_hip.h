@@ -241,7 +241,21 @@ int fr_standardize(const double *d_X, int64_t rows, int64_t T, int32_t div_std, 
                    double *d_out, void *stream);
 
 /* ------------------------------------------------------------------ CosWISS ("next" row)
- * The cosine weighted ISS (fruits/iss/cos.py:11-49) expands cos(a-b)^s into products of
+ * CosWISS.batch_transform without ffn / dropout (fruits/iss/cos.py:11-49,167-181,
+ * 289-330): the cosine weighted iterated sums of W simple words (exps / L / Dw as in
+ * fr_plan_create) for n_freqs frequencies (float32 like the reference's f4 argument),
+ * cosine exponent 1..4, optionally with total weighting.  The result is a plan like
+ * any other: fr_iss_run writes its K = W*n_freqs rows (row = word*n_freqs + freq,
+ * cos.py:167-181; d_lookup is ignored), fr_plan_workspace_bytes sizes the sin / cos
+ * tables the run computes, and fr_pipeline_create fuses the sieves onto it.  The device
+ * kernel sums the reference's (exponent+1)^(p-1) terms in factorised form, letter by
+ * letter ((exponent+1) scans per letter) - equal up to re-association rounding. */
+fr_plan_t *fr_plan_create_coswiss(int32_t W, const int32_t *exps, const int32_t *L,
+                                  const int32_t *Dw, int32_t n_freqs, const float *freqs,
+                                  int32_t exponent, int32_t total_weighting);
+
+/* The reference's own formulation, term by term, for exponents beyond the kernels above:
+ * the cosine weighted ISS (fruits/iss/cos.py:11-49) expands cos(a-b)^s into products of
  * sin / cos powers (cos.py:265-287); every product ("term") is an ordinary Reals ISS of
  * the word over the input extended by one sin and one cos row per frequency, i.e. a
  * fr_plan_create / fr_iss_run program (the terms of all words share prefixes).  This

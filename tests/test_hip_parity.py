@@ -316,6 +316,96 @@ def test_coswiss_brute_force(fr):
         np.testing.assert_allclose(out[0], ref, rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("words,exponent,total", [
+    (["[1][1][1][1]"], 3, False),            # reference test_cosine.py:86-110
+    (["[1][1][1]"], 4, False),               # reference test_cosine.py:113-134
+    (["[1][1][1]", "[11][-1]"], 4, True),
+    (["[1]", "[2][1]", "[12][2][33]", "[3][11]", "[11][23][1]"], 2, True),
+])
+def test_coswiss_vs_oracle(fr, words, exponent, total):
+    X = np.random.default_rng(len(words) + exponent).random((10, 3, 50)) + 0.25
+    freqs = [0.05, 0.5, 0.45]                 # fruit_reduced uses i/20
+    cw = fr.CosWISS([fr.words.SimpleWord(s) for s in words], freqs, exponent=exponent,
+                    total_weighting=total)
+    out = cw.fit_transform(X)
+    ref = orc.coswiss_transform(X, words, freqs, exponent, total)
+    assert out.shape == ref.shape
+    # the terms cancel (alternating trig products): tolerance relative to the row scale
+    scale = np.abs(ref).max(axis=2, keepdims=True)
+    assert np.all(np.abs(out - ref) <= RTOL * np.maximum(np.abs(ref), 1e-3 * scale))
+
+
+@pytest.mark.parametrize("T", [700, 1024, 1030, 2051])
+@pytest.mark.parametrize("total", [False, True])
+def test_coswiss_long_series(fr, T, total):
+    # chunk sizes 512 / 1024, several chunks (carries), odd lengths (scalar accesses)
+    rng = np.random.default_rng(T)
+    X = rng.standard_normal((6, 2, T)) / np.sqrt(T)
+    words = ["[1]", "[2][1]", "[1][2][2]", "[12][1][-2][1]"] if T < 2000 else ["[1]", "[2][1]"]
+    X[:, 1] = np.abs(X[:, 1]) + 0.5
+    freqs = [0.15, 0.5]
+    for exponent in (1, 2):
+        cw = fr.CosWISS([fr.words.SimpleWord(s) for s in words], freqs, exponent=exponent,
+                        total_weighting=total)
+        out = cw.fit_transform(X)
+        ref = orc.coswiss_transform(X, words, freqs, exponent, total)
+        scale = np.abs(ref).max(axis=2, keepdims=True)
+        assert np.all(np.abs(out - ref) <= RTOL * np.maximum(np.abs(ref), 1e-3 * scale))
+
+
+def test_coswiss_term_path(fr, monkeypatch):
+    # exponents beyond the factorised kernels use the reference's term-by-term form
+    X = np.random.default_rng(3).random((4, 2, 40)) + 0.25
+    words, freqs = ["[1][2]", "[2][1][1]"], [0.3, 0.5]
+    ref5 = orc.coswiss_transform(X, words, freqs, 5, True)
+    cw5 = fr.CosWISS([fr.words.SimpleWord(s) for s in words], freqs, exponent=5,
+                     total_weighting=True)
+    assert not cw5._native()
+    out5 = cw5.fit_transform(X)
+    scale = np.abs(ref5).max(axis=2, keepdims=True)
+    assert np.all(np.abs(out5 - ref5) <= RTOL * np.maximum(np.abs(ref5), 1e-3 * scale))
+    # and both forms agree where both exist
+    cw2 = fr.CosWISS([fr.words.SimpleWord(s) for s in words], freqs, exponent=2)
+    a = cw2.fit_transform(X)
+    monkeypatch.setenv("FRUITS_AMD_COSWISS_TERMS", "1")
+    b = fr.CosWISS([fr.words.SimpleWord(s) for s in words], freqs, exponent=2).fit_transform(X)
+    np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("T", [96, 1024, 1100])
+@pytest.mark.parametrize("total", [False, True])
+def test_coswiss_fused_pipeline(fr, monkeypatch, T, total):
+    # NEW(INC) -> STD -> CosWISS -> NPI / MPI (inc 0, 1, 2) + END in one launch
+    # (experiments/fruit_reduced.py:52-69) vs the materialised path vs the oracle
+    rng = np.random.default_rng(T + total)
+    X = rng.standard_normal((24, 1, T)).cumsum(axis=2)
+    spec = {"slices": [{
+        "preps": [{"kind": "NEW", "inner": {"kind": "INC"}}, {"kind": "STD"}],
+        "iss": [{"kind": "CosWISS", "words": ["[1]", "[2]", "[1][2]", "[2][1][1]"],
+                 "freqs": [0.05, 0.25], "exponent": 2, "total_weighting": total,
+                 "mode": "SINGLE"}],
+        "sieves": [{"kind": "NPI", "q": [0.5, 1.0], "inc": 0},
+                   {"kind": "NPI", "q": [0.5, 1.0], "inc": 1},
+                   {"kind": "NPI", "q": [0.5, 1.0], "inc": 2},
+                   {"kind": "MPI", "q": [0.5, 1.0], "inc": 0},
+                   {"kind": "MPI", "q": [0.5, 1.0], "inc": 1},
+                   {"kind": "MPI", "q": [0.5, 1.0], "inc": 2},
+                   {"kind": "END"}],
+        "fit_sample_size": 1.0}]}
+    fruit = build_fruit(fr, spec)
+    fruit.fit(X)
+    assert fruit.get_slice()._fused(T) is not None
+    fused = fruit.transform(X)
+    labels = [fruit.label(i) for i in range(fruit.nfeatures())]
+    monkeypatch.setenv("FRUITS_AMD_FUSED", "0")
+    fruit.get_slice()._fused_cache = {}
+    plain = fruit.transform(X)
+    compare_features(fused, plain, labels, count_frac=0.02)
+    ofr = orc.fruit_fit(spec, X)
+    ref = orc.fruit_transform(spec, ofr, X)
+    compare_features(fused, ref, labels, count_frac=0.05)
+
+
 def test_coswiss_unsupported(fr):
     cw = fr.CosWISS([fr.words.SimpleWord("[1]")], [0.5], dropout=0.5)
     with pytest.raises(NotImplementedError):
