@@ -2,7 +2,7 @@
 
 Same public surface as the reference package for the path
 ``INC -> ISS (Reals, SimpleWords, optional Indices / L1 weighting) -> NPI / END``
-(plus NEW, STD and MPI): ``fruits_amd.ISS(...).fit_transform(X)`` and
+(plus NEW, STD, MPI, the Arctic semiring and CosWISS): ``fruits_amd.ISS(...).fit_transform(X)`` and
 ``fruits_amd.Fruit.fit / transform``.  All arithmetic runs in hand-written HIP
 kernels behind the C ABI of ``include/fruits_hip.h``; there is no CPU fallback.
 """
