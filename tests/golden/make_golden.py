@@ -578,6 +578,43 @@ fruit_case("reduced_coswiss_small", "G_8_1_65", {"name": "red3", "slices": [
                 {"kind": "END"}],
      "fit_sample_size": 1.0}]}, np_seed=17)
 
+# experiments/fruit_reduced.py VERBATIM (all four slices) on a small batch; T-1 = 64 keeps the
+# float32 product freq*(T-1) exact for the experiment's frequencies i/20
+SIEVES7 = [{"kind": "NPI", "q": [0.5, 1.0], "inc": 0}, {"kind": "NPI", "q": [0.5, 1.0], "inc": 1},
+           {"kind": "NPI", "q": [0.5, 1.0], "inc": 2}, {"kind": "MPI", "q": [0.5, 1.0], "inc": 0},
+           {"kind": "MPI", "q": [0.5, 1.0], "inc": 1}, {"kind": "MPI", "q": [0.5, 1.0], "inc": 2},
+           {"kind": "END"}]
+ALT24 = [str(w) for w in fruits.words.alternate_sign([
+    fruits.words.SimpleWord(24 * "[1]"), fruits.words.SimpleWord(24 * "[2]"),
+    fruits.words.SimpleWord(12 * "[1][2]"), fruits.words.SimpleWord(12 * "[2][1]")])]
+COSW = (manifest["words"]["1,2"]["words"] + manifest["words"]["2,2"]["words"]
+        + manifest["words"]["3,2"]["words"])
+reduced = {"name": "Reduced Fruit", "slices": [
+    {"preps": [{"kind": "NEW", "inner": {"kind": "INC"}}, {"kind": "STD"}],
+     "iss": [{"words": W42, "mode": "EXTENDED", "weighting": {"kind": "Indices"}}],
+     "sieves": SIEVES7, "fit_sample_size": 1.0},
+    {"preps": [{"kind": "NEW", "inner": {"kind": "INC"}}],
+     "iss": [{"words": ALT24, "mode": "EXTENDED", "semiring": "Arctic"}],
+     "sieves": SIEVES7, "fit_sample_size": 1.0}] + [
+    {"preps": [{"kind": "NEW", "inner": {"kind": "INC"}}, {"kind": "STD"}],
+     "iss": [{"kind": "CosWISS", "words": COSW, "freqs": [i / 20 for i in range(1, 11, 2)],
+              "exponent": e, "total_weighting": True, "mode": "SINGLE"}],
+     "sieves": SIEVES7, "fit_sample_size": 1.0} for e in (1, 2)]}
+put("G_6_1_65", np.random.default_rng(43).standard_normal((6, 1, 65)).cumsum(axis=2))
+fruit_case("fruit_reduced_verbatim", "G_6_1_65", reduced, np_seed=18)
+# ... and the experiment file itself gives the same features as the spec above
+import importlib.util
+_sp = importlib.util.spec_from_file_location(
+    "ref_fruit_reduced", os.path.join(REF, "experiments", "fruit_reduced.py"))
+_mod = importlib.util.module_from_spec(_sp)
+_sp.loader.exec_module(_mod)
+np.random.seed(18)
+_mod.fruit.fit(arrays["G_6_1_65"])
+_out = _mod.fruit.transform(arrays["G_6_1_65"])
+_case = [c for c in manifest["fruit"] if c["name"] == "fruit_reduced_verbatim"][0]
+assert np.array_equal(_out, arrays[_case["out"]], equal_nan=True), "spec != experiments/fruit_reduced.py"
+assert _mod.fruit.nfeatures() == _case["nfeatures"]
+
 # chained ISS (reference tests/signature/test_consecutive.py) with END
 fruit_case("consecutive_end", "U_9_3_60", {"slices": [
     {"iss": [{"words": ["[12][1]", "[1][32]", "[11][121][3]"], "mode": "EXTENDED"},
