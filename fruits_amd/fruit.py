@@ -105,15 +105,15 @@ class Fruit:
             raise RuntimeError("Missing call of self.fit")
         X = _check_batch(X)
         cache_ = SharedSeedCache(X) if cache is None else cache
-        result = np.zeros((X.shape[0], self.nfeatures()))
-        col = 0
+        t = nat.torch()
+        blocks = []
         for slc in self._slices:
             for cb in callbacks:
                 cb.on_next_slice()
-            k = slc.nfeatures()
-            result[:, col:col + k] = slc.transform(X, callbacks, cache_)
-            col += k
-        return np.nan_to_num(result, copy=False, nan=0.0)
+            blocks.append(slc.transform_device(X, callbacks, cache_))
+        # assembled on the device: one download instead of a strided host copy per slice
+        result = blocks[0] if len(blocks) == 1 else t.cat(blocks, dim=1)
+        return nat.to_host(t.nan_to_num(result, nan=0.0))
 
     def fit_transform(self, X: np.ndarray,
                       callbacks: Optional[list[AbstractCallback]] = None) -> np.ndarray:
@@ -448,6 +448,12 @@ class FruitSlice:
     def transform(self, X: np.ndarray,
                   callbacks: Optional[list[AbstractCallback]] = None,
                   cache: Optional[SharedSeedCache] = None) -> np.ndarray:
+        return nat.to_host(self.transform_device(X, callbacks, cache))
+
+    def transform_device(self, X: np.ndarray,
+                         callbacks: Optional[list[AbstractCallback]] = None,
+                         cache: Optional[SharedSeedCache] = None):
+        """``transform`` with the ``(N, nfeatures)`` result left on the device."""
         callbacks = callbacks or []
         if not self._fitted:
             raise RuntimeError("Missing call of self.fit")
@@ -462,8 +468,7 @@ class FruitSlice:
         self._attach(cache)
         fused = None if callbacks else self._fused(int(Pd.shape[2]))
         if fused is not None:
-            feats = fused.run(Pd, self._iss[0].lookup_device(Pd))
-            return nat.to_host(feats)
+            return fused.run(Pd, self._iss[0].lookup_device(Pd))
         feats = t.zeros((X.shape[0], self.nfeatures()), dtype=t.float64, device=Pd.device)
         col = 0
         for i, itsum in enumerate(self._iterate_iss_device(Pd)):
@@ -477,10 +482,11 @@ class FruitSlice:
                 for cb in callbacks:
                     cb.on_sieve(nat.to_host(feats[col:col + nf]))
                 col += nf
-        out = nat.to_host(feats)
-        for cb in callbacks:
-            cb.on_sieving_end(out)
-        return out
+        if callbacks:
+            out = nat.to_host(feats)
+            for cb in callbacks:
+                cb.on_sieving_end(out)
+        return feats
 
     def fit_transform(self, X: np.ndarray) -> np.ndarray:
         self.fit(X)

@@ -135,3 +135,53 @@ def run_reduced1(N, D, T):
 
 if which in ("reduced1", "all"):
     run_reduced1(2048, 1, 1024)
+
+
+def build_reduced():
+    """experiments/fruit_reduced.py, all four slices."""
+    fruit = fr.Fruit("Reduced Fruit")
+    iss_r = fr.ISS(fr.words.of_weight(4, 2), mode=fr.ISSMode.EXTENDED,
+                   weighting=fr.iss.weighting.Indices())
+    iss_a = fr.ISS(fr.words.alternate_sign([
+        fr.words.SimpleWord(24 * "[1]"), fr.words.SimpleWord(24 * "[2]"),
+        fr.words.SimpleWord(12 * "[1][2]"), fr.words.SimpleWord(12 * "[2][1]")]),
+        mode=fr.ISSMode.EXTENDED, semiring=fr.semiring.Arctic())
+    cos_words = (list(fr.words.of_weight(1, 2)) + list(fr.words.of_weight(2, 2))
+                 + list(fr.words.of_weight(3, 2)))
+
+    def sieves():
+        for inc in (0, 1, 2): fruit.add(fr.sieving.NPI(q=(0.5, 1.0), inc=inc))
+        for inc in (0, 1, 2): fruit.add(fr.sieving.MPI(q=(0.5, 1.0), inc=inc))
+        fruit.add(fr.sieving.END)
+    fruit.cut(); fruit.add(fr.preparation.NEW(fr.preparation.INC())); fruit.add(fr.preparation.STD)
+    fruit.add(iss_r); sieves()
+    fruit.cut(); fruit.add(fr.preparation.NEW(fr.preparation.INC())); fruit.add(iss_a); sieves()
+    for e in (1, 2):
+        fruit.cut(); fruit.add(fr.preparation.NEW(fr.preparation.INC())); fruit.add(fr.preparation.STD)
+        fruit.add(fr.CosWISS(freqs=[i / 20 for i in range(1, 11, 2)], words=cos_words, exponent=e,
+                             total_weighting=True))
+        sieves()
+    for slc in fruit: slc.fit_sample_size = 1.0
+    return fruit
+
+
+def run_reduced_full(N, T):
+    X = np.random.default_rng(0).standard_normal((N, 1, T)).cumsum(axis=2)
+    fruit = build_reduced()
+    np.random.seed(0)
+    t0 = time.perf_counter(); fruit.fit(X); torch.cuda.synchronize(); t_fit = time.perf_counter() - t0
+    fruit.transform(X)
+    t0 = time.perf_counter(); f1 = fruit.transform(X); t_tr = time.perf_counter() - t0
+    per_slice = []
+    for i, slc in enumerate(fruit):
+        cache = fr.cache.SharedSeedCache(X)
+        slc.transform(X, cache=cache)
+        t0 = time.perf_counter(); slc.transform(X, cache=cache); per_slice.append(round((time.perf_counter() - t0) * 1e3, 2))
+    print(json.dumps({"name": "fruit_reduced_full", "N": N, "T": T, "features": int(f1.shape[1]),
+                      "fit_s": round(t_fit, 3), "transform_ms": round(t_tr * 1e3, 2),
+                      "per_slice_transform_ms": per_slice,
+                      "fused": [s._fused(T) is not None for s in fruit],
+                      "nan_features": int(np.isnan(f1).sum())}))
+
+if which in ("reduced", "all"):
+    run_reduced_full(2048, 1024)
