@@ -121,8 +121,8 @@ __device__ __forceinline__ void coswiss_unit(WalkCtx &cx, const double *xrow, co
 #pragma unroll
   for (int i = 0; i < EP; ++i) res[i] = resx[i] = 0.0;
   const int L = le - lb;
+  double s[EP];
   for (int k = 0; k < L; ++k) {
-    double s[EP];
     if (k == 0) {
 #pragma unroll
       for (int i = 0; i < EP; ++i) s[i] = 1.0;
@@ -162,7 +162,7 @@ __device__ __forceinline__ void coswiss_unit(WalkCtx &cx, const double *xrow, co
     cx.slot = kCosMaxLetters * (S + 1);
     if (total) prev_first_differences<C>(cx, res, resx);  // resx[t] = res[t-1]
     cx.slot += 3;
-    fused_all<C>(cx, nd, pre, res, resx);
+    fused_all<C>(cx, nd, pre, res, resx, total ? nullptr : s);
   } else {
     emit_store<C>(cx, res, cx.out_base + (int64_t)k_out * a.out_k_stride);
   }

@@ -408,10 +408,16 @@ struct FusedScratch {
   bool have_dp = false;
 };
 
+// `s` is the scan input the values came from (c = cumsum(s)) or nullptr.  With it, a
+// Reals first difference is formed as fl(x + s) - x, the step a SEQUENTIAL cumsum
+// takes from the same prefix (np.cumsum in the reference): a summand the running sum
+// absorbs gives an increment of exactly 0, as in the reference, where the difference of
+// two parallel-scan values is +-1 ulp of noise - which "number of positive increments"
+// (NPI with its default q = (0, 1)) would count at random.
 template <class C>
 __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w,
                                          const double (&c)[C::EP], const double (&x)[C::EP],
-                                         FusedScratch<C::EP> &sc) {
+                                         const double *s, FusedScratch<C::EP> &sc) {
   constexpr int E = C::E, P = C::P, EP = C::EP;
   const int kind = w[0] & 0xff, inc = w[0] >> 8, col = w[1];
   if (kind == FR_SIEVE_END_K) {
@@ -445,8 +451,12 @@ __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w,
 #pragma unroll
     for (int h = 0; h < P; ++h)
 #pragma unroll
-      for (int e = 0; e < E; ++e)
-        d[h * E + e] = (t_first + h * C::PIECE + e == 0) ? 0.0 : c[h * E + e] - x[h * E + e];
+      for (int e = 0; e < E; ++e) {
+        const int i = h * E + e;
+        double step = c[i] - x[i];
+        if (C::SEMI == 0 && s != nullptr) step = (x[i] + s[i]) - x[i];
+        d[i] = (t_first + h * C::PIECE + e == 0) ? 0.0 : step;
+      }
     if (inc == 2) {
       if (!sc.have_dp) {
         prev_first_differences<C>(cx, d, sc.dp);
@@ -485,7 +495,8 @@ __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w,
 
 template <class C>
 __device__ __forceinline__ void fused_all(WalkCtx &cx, const Rec &nd, const Ops2 &pre,
-                                          const double (&c)[C::EP], const double (&x)[C::EP]) {
+                                          const double (&c)[C::EP], const double (&x)[C::EP],
+                                          const double *s) {
   const IssArgs &a = *cx.a;
   const int ne = nd.emit_count(), n = a.n_ops;
   int64_t k = nd.w[7];
@@ -493,8 +504,8 @@ __device__ __forceinline__ void fused_all(WalkCtx &cx, const Rec &nd, const Ops2
   FusedScratch<C::EP> sc;
   for (int j = 0;;) {
     for (int i = 0;;) {
-      fused_op<C>(cx, o.w, c, x, sc);
-      if (i + 1 < n) fused_op<C>(cx, o.w + 8, c, x, sc);
+      fused_op<C>(cx, o.w, c, x, s, sc);
+      if (i + 1 < n) fused_op<C>(cx, o.w + 8, c, x, s, sc);
       i += 2;
       if (i >= n) break;
       o = load_ops2(a, k, i);
@@ -558,7 +569,7 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd, int slo
       if (C::WEIGHTED && emit_mul >= 0)
         mul_row<C>(cx, C::SEMI == 0 ? emit_mul : fac_arctic(emit_mul, -1), c);
       if constexpr (C::MODE == 1)
-        fused_all<C>(cx, nd, pre, c, x);
+        fused_all<C>(cx, nd, pre, c, x, (C::WEIGHTED && emit_mul >= 0) ? nullptr : s);
       else
         emit_all<C>(cx, nd, c);
       STAMP(cx, 5);  // stores

@@ -628,3 +628,83 @@ def test_select_ranks_against_numpy(fr):
                 rows.append(r); incs.append(inc); ranks.append(k); want.append(flat[k])
     got = nat.select_ranks(Ad, rows, incs, ranks)
     np.testing.assert_array_equal(got, np.array(want))
+
+
+# --------------------------------------------------------------------------
+# BASELINE configs[2..4] at their full sizes: the experiment fruits verbatim
+# --------------------------------------------------------------------------
+_SIEVES7 = [{"kind": "NPI", "q": [0.5, 1.0], "inc": 0}, {"kind": "NPI", "q": [0.5, 1.0], "inc": 1},
+            {"kind": "NPI", "q": [0.5, 1.0], "inc": 2}, {"kind": "MPI", "q": [0.5, 1.0], "inc": 0},
+            {"kind": "MPI", "q": [0.5, 1.0], "inc": 1}, {"kind": "MPI", "q": [0.5, 1.0], "inc": 2},
+            {"kind": "END"}]
+
+
+def _experiment_spec(fr, which):
+    """experiments/fruit_reduced.py, fruit_general.py, fruit_twi.py as test specs."""
+    def ow(w, d):
+        return [str(x) for x in fr.words.of_weight(w, d)]
+
+    def alt(n):
+        return [str(x) for x in fr.words.alternate_sign([
+            fr.words.SimpleWord(n * "[1]"), fr.words.SimpleWord(n * "[2]"),
+            fr.words.SimpleWord((n // 2) * "[1][2]"), fr.words.SimpleWord((n // 2) * "[2][1]")])]
+    new_inc = {"kind": "NEW", "inner": {"kind": "INC"}}
+    if which == "twi":
+        return {"name": "Time Warping Invariant Fruit", "slices": [
+            {"preps": [{"kind": "INC"}],
+             "iss": [{"words": ow(9, 1), "mode": "EXTENDED", "weighting": {"kind": "L1"}}],
+             "sieves": [{"kind": "NPI"}, {"kind": "MPI"}, {"kind": "END"}], "fit_sample_size": 1.0},
+            {"iss": [{"words": [str(x) for x in fr.words.alternate_sign(
+                [fr.words.SimpleWord(48 * "[1]")])], "mode": "EXTENDED", "semiring": "Arctic"}],
+             "sieves": [{"kind": "NPI"}, {"kind": "END"}], "fit_sample_size": 1.0}]}
+    wr, na, cw = (4, 24, 3) if which == "reduced" else (6, 48, 4)
+    cos_words = sum((ow(w, 2) for w in range(1, cw + 1)), [])
+    return {"name": which, "slices": [
+        {"preps": [new_inc, {"kind": "STD"}],
+         "iss": [{"words": ow(wr, 2), "mode": "EXTENDED", "weighting": {"kind": "Indices"}}],
+         "sieves": _SIEVES7, "fit_sample_size": 1.0},
+        {"preps": [new_inc],
+         "iss": [{"words": alt(na), "mode": "EXTENDED", "semiring": "Arctic"}],
+         "sieves": _SIEVES7, "fit_sample_size": 1.0}] + [
+        {"preps": [new_inc, {"kind": "STD"}],
+         "iss": [{"kind": "CosWISS", "words": cos_words,
+                  "freqs": [i / 20 for i in range(1, 11, 2)], "exponent": e,
+                  "total_weighting": True, "mode": "SINGLE"}],
+         "sieves": _SIEVES7, "fit_sample_size": 1.0} for e in (1, 2)]}
+
+
+@pytest.mark.parametrize("which,shape", [("reduced", (2048, 3, 1024)),
+                                         ("general", (8192, 3, 1024)),
+                                         ("twi", (2048, 6, 4096))],
+                         ids=["config3_fruit_reduced", "config4_fruit_general", "config5_fruit_twi"])
+def test_experiment_fruits_full_size(fr, which, shape):
+    """BASELINE configs[2], [3], [4] at their full batch sizes on one GPU (config 5
+    names no N: 2048).  Fitted on the first 24 series (device fit == oracle fit up to
+    threshold ties), transformed as ONE batch; checked (a) against the numpy oracle on
+    a handful of series spread over the batch (outside the fit sample) and (b) through batch independence: the
+    rows of the big transform equal the transform of those series alone."""
+    rng = np.random.default_rng(len(which))
+    X = rng.standard_normal(shape).cumsum(axis=2) / 8.0
+    spec = _experiment_spec(fr, which)
+    fruit = build_fruit(fr, spec)
+    n_fit = 24
+    np.random.seed(5)
+    fruit.fit(X[:n_fit])
+    T = shape[2]
+    for slc in fruit:
+        assert slc._fused(T) is not None          # every slice is ONE fused launch
+    feats = fruit.transform(X)
+    assert feats.shape == (shape[0], fruit.nfeatures())
+    assert np.isfinite(feats).all()
+    # series outside the fit sample: a fitted extreme quantile IS a data point of the
+    # sample, i.e. an exact threshold tie for the series that holds it
+    idx = np.array([n_fit, n_fit + 1, shape[0] // 2 + 3, shape[0] - 2, shape[0] - 1])
+    labels = [fruit.label(i) for i in range(fruit.nfeatures())]
+    # (b) batch independence (MPI band sums are accumulated with float atomics)
+    alone = fruit.transform(np.ascontiguousarray(X[idx]))
+    np.testing.assert_allclose(feats[idx], alone, rtol=1e-10, atol=1e-12)
+    # (a) the oracle, fitted on the same sample, on the selected series
+    np.random.seed(5)
+    ofit = orc.fruit_fit(spec, X[:n_fit])
+    ref = orc.fruit_transform(spec, ofit, np.ascontiguousarray(X[idx]))
+    compare_features(feats[idx], ref, labels, count_frac=0.02)
