@@ -162,7 +162,7 @@ __device__ __forceinline__ void coswiss_unit(WalkCtx &cx, const double *xrow, co
     cx.slot = kCosMaxLetters * (S + 1);
     if (total) prev_first_differences<C>(cx, res, resx);  // resx[t] = res[t-1]
     cx.slot += 3;
-    fused_all<C>(cx, nd, pre, res, resx, total ? nullptr : s);
+    fused_all<C>(cx, nd, pre, res, resx, s, !total);
   } else {
     emit_store<C>(cx, res, cx.out_base + (int64_t)k_out * a.out_k_stride);
   }

@@ -408,7 +408,7 @@ struct FusedScratch {
   bool have_dp = false;
 };
 
-// `s` is the scan input the values came from (c = cumsum(s)) or nullptr.  With it, a
+// `s` is the scan input the values came from (c = cumsum(s)) when seq_steps.  Then a
 // Reals first difference is formed as fl(x + s) - x, the step a SEQUENTIAL cumsum
 // takes from the same prefix (np.cumsum in the reference): a summand the running sum
 // absorbs gives an increment of exactly 0, as in the reference, where the difference of
@@ -417,7 +417,8 @@ struct FusedScratch {
 template <class C>
 __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w,
                                          const double (&c)[C::EP], const double (&x)[C::EP],
-                                         const double *s, FusedScratch<C::EP> &sc) {
+                                         const double (&s)[C::EP], bool seq_steps,
+                                         FusedScratch<C::EP> &sc) {
   constexpr int E = C::E, P = C::P, EP = C::EP;
   const int kind = w[0] & 0xff, inc = w[0] >> 8, col = w[1];
   if (kind == FR_SIEVE_END_K) {
@@ -454,7 +455,7 @@ __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w,
       for (int e = 0; e < E; ++e) {
         const int i = h * E + e;
         double step = c[i] - x[i];
-        if (C::SEMI == 0 && s != nullptr) step = (x[i] + s[i]) - x[i];
+        if (C::SEMI == 0 && seq_steps) step = (x[i] + s[i]) - x[i];
         d[i] = (t_first + h * C::PIECE + e == 0) ? 0.0 : step;
       }
     if (inc == 2) {
@@ -496,7 +497,7 @@ __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w,
 template <class C>
 __device__ __forceinline__ void fused_all(WalkCtx &cx, const Rec &nd, const Ops2 &pre,
                                           const double (&c)[C::EP], const double (&x)[C::EP],
-                                          const double *s) {
+                                          const double (&s)[C::EP], bool seq_steps) {
   const IssArgs &a = *cx.a;
   const int ne = nd.emit_count(), n = a.n_ops;
   int64_t k = nd.w[7];
@@ -504,8 +505,8 @@ __device__ __forceinline__ void fused_all(WalkCtx &cx, const Rec &nd, const Ops2
   FusedScratch<C::EP> sc;
   for (int j = 0;;) {
     for (int i = 0;;) {
-      fused_op<C>(cx, o.w, c, x, s, sc);
-      if (i + 1 < n) fused_op<C>(cx, o.w + 8, c, x, s, sc);
+      fused_op<C>(cx, o.w, c, x, s, seq_steps, sc);
+      if (i + 1 < n) fused_op<C>(cx, o.w + 8, c, x, s, seq_steps, sc);
       i += 2;
       if (i >= n) break;
       o = load_ops2(a, k, i);
@@ -569,7 +570,7 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd, int slo
       if (C::WEIGHTED && emit_mul >= 0)
         mul_row<C>(cx, C::SEMI == 0 ? emit_mul : fac_arctic(emit_mul, -1), c);
       if constexpr (C::MODE == 1)
-        fused_all<C>(cx, nd, pre, c, x, (C::WEIGHTED && emit_mul >= 0) ? nullptr : s);
+        fused_all<C>(cx, nd, pre, c, x, s, !(C::WEIGHTED && emit_mul >= 0));
       else
         emit_all<C>(cx, nd, c);
       STAMP(cx, 5);  // stores
@@ -655,8 +656,16 @@ __device__ __forceinline__ void walk(WalkCtx &cx, Rec &cur, int &pc,
   }
 }
 
+// The fused kernels for 1024-element chunks sit just above 128 VGPRs; at least 4 waves
+// per SIMD (<= 128 VGPRs) is worth the compiler's effort there.
+#if defined(WALK_MODE) && WALK_MODE == 1
+#define WALK_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(4)))
+#else
+#define WALK_KERNEL_ATTR
+#endif
+
 template <class C>
-__global__ __launch_bounds__(kWalkThreads) void iss_walk_kernel(const IssArgs a) {
+__global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel(const IssArgs a) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
   WalkCtx cx;
