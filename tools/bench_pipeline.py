@@ -70,7 +70,7 @@ def run(name, N, D, T, words, weighting, sieves):
            "max_feature_diff_fused_vs_unfused": float(diff.max()), "frac_diff": float((diff > 0).mean())}
     print(json.dumps(res))
 
-which = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+which = (sys.argv[1] if len(sys.argv) > 1 else "cfg3") if __name__ == "__main__" else "none"
 if which in ("cfg3", "all"):
     run("cfg3_indices", 2048, 3, 1024, fr.words.of_weight(4, dim=2), fr.iss.weighting.Indices(),
         [fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END()])
