@@ -1,6 +1,7 @@
 // Small HIP kernels around the trie walk (exp tables, INC, path-length lookups,
 // standalone sieves, STD) and the dispatcher over the walk-kernel instances.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "kernels.h"
 #include "walk_scan.h"
@@ -335,7 +336,15 @@ hipError_t launch_select_ranks(void *jobs, int n_jobs, int64_t N, int64_t T, uns
 }
 
 // ---------------------------------------------------------------- launchers
-int walk_chunk_elems(int64_t T) { return T <= 512 ? 512 : 1024; }
+int walk_chunk_elems(int64_t T) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char *v = getenv("FRUITS_HIP_CHUNK");
+    forced = v && *v ? atoi(v) : 0;
+  }
+  if (forced == 512 || forced == 1024) return forced;
+  return T <= 512 ? 512 : 1024;
+}
 
 // wave-per-row variant (TEAM = 1): single chunk, aligned 16-byte accesses,
 // shallow tries (register frames of 2 * E * P VGPRs per level)
