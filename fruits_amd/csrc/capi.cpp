@@ -733,38 +733,67 @@ int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32
     int inc, pad;
   };
   static_assert(sizeof(HostJob) == fr::kSelJobBytes, "job layout");
-  std::vector<HostJob> jobs(n_jobs);
-  for (int j = 0; j < n_jobs; ++j) {
+  for (int j = 0; j < n_jobs; ++j)
     if (job_row[j] < 0 || job_row[j] >= rows || job_inc[j] < 0 || job_inc[j] > 8 ||
         job_rank[j] < 0 || job_rank[j] >= N * T)
       return fail(FR_E_ARG, "fr_select_ranks: job " + std::to_string(j) + " out of range");
-    jobs[j] = HostJob{d_A + (int64_t)job_row[j] * N * T, 0ull, (long long)job_rank[j], job_inc[j], 0};
+  // jobs that read the same row block share their passes over it (sorted by row, then
+  // differencing order, so a group computes every difference once per element)
+  std::vector<int> order(n_jobs);
+  for (int j = 0; j < n_jobs; ++j) order[j] = j;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+    if (job_row[x] != job_row[y]) return job_row[x] < job_row[y];
+    return job_inc[x] < job_inc[y];
+  });
+  std::vector<HostJob> jobs(n_jobs);
+  std::vector<int32_t> groups;  // {first, count} pairs
+  for (int s = 0; s < n_jobs; ++s) {
+    const int j = order[s];
+    jobs[s] = HostJob{d_A + (int64_t)job_row[j] * N * T, 0ull, (long long)job_rank[j], job_inc[j], 0};
+    if (!groups.empty() && job_row[order[groups[groups.size() - 2]]] == job_row[j] &&
+        groups.back() < fr::kSelGroupMax)
+      ++groups.back();
+    else {
+      groups.push_back(s);
+      groups.push_back(1);
+    }
   }
+  const int n_groups = (int)groups.size() / 2;
+  std::vector<double> sorted_out(n_jobs);
   hipStream_t st = (hipStream_t)stream;
-  void *d_jobs = nullptr, *d_hist = nullptr, *d_out = nullptr;
+  void *d_jobs = nullptr, *d_hist = nullptr, *d_out = nullptr, *d_groups = nullptr;
   int rc = FR_OK;
   do {
     hipError_t e;
     if ((e = hipMalloc(&d_jobs, jobs.size() * sizeof(HostJob))) != hipSuccess ||
+        (e = hipMalloc(&d_groups, groups.size() * 4)) != hipSuccess ||
         (e = hipMalloc(&d_hist, (size_t)n_jobs * 256 * 4)) != hipSuccess ||
         (e = hipMalloc(&d_out, (size_t)n_jobs * 8)) != hipSuccess ||
         (e = hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(HostJob),
                             hipMemcpyHostToDevice, st)) != hipSuccess ||
+        (e = hipMemcpyAsync(d_groups, groups.data(), groups.size() * 4, hipMemcpyHostToDevice,
+                            st)) != hipSuccess ||
         (e = hipMemsetAsync(d_hist, 0, (size_t)n_jobs * 256 * 4, st)) != hipSuccess ||
-        (e = fr::launch_select_ranks(d_jobs, n_jobs, N, T, static_cast<unsigned int *>(d_hist),
+        (e = fr::launch_select_ranks(d_jobs, n_jobs, d_groups, n_groups, N, T,
+                                     static_cast<unsigned int *>(d_hist),
                                      static_cast<double *>(d_out), st)) != hipSuccess ||
-        (e = hipMemcpyAsync(h_out, d_out, (size_t)n_jobs * 8, hipMemcpyDeviceToHost, st)) !=
-            hipSuccess ||
+        (e = hipMemcpyAsync(sorted_out.data(), d_out, (size_t)n_jobs * 8, hipMemcpyDeviceToHost,
+                            st)) != hipSuccess ||
         (e = hipStreamSynchronize(st)) != hipSuccess) {
       rc = hip_fail(e, "fr_select_ranks");
     }
   } while (0);
   const std::string keep = g_err;
   if (d_jobs) (void)hipFree(d_jobs);
+  if (d_groups) (void)hipFree(d_groups);
   if (d_hist) (void)hipFree(d_hist);
   if (d_out) (void)hipFree(d_out);
-  if (rc != FR_OK) g_err = keep;
-  return rc;
+  if (rc != FR_OK) {
+    g_err = keep;
+    return rc;
+  }
+  for (int s = 0; s < n_jobs; ++s) h_out[order[s]] = sorted_out[s];
+  return FR_OK;
 }
 
 int fr_pre_transform(const double *d_A, int64_t N, int64_t T, int64_t a_stride, int32_t inc,

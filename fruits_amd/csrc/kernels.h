@@ -80,8 +80,11 @@ hipError_t launch_pathlen_lookup(const double *X, int64_t N, int64_t D, int64_t 
 hipError_t launch_sieve(int kind, const double *A, int64_t N, int64_t T, int64_t a_stride, int inc,
                         const int64_t *cuts, int64_t cut_rows, int C1, const double *q, int Q1,
                         double *out, int64_t out_stride, hipStream_t st);
-hipError_t launch_select_ranks(void *jobs, int n_jobs, int64_t N, int64_t T, unsigned int *hist,
-                               double *out, hipStream_t st);
+// jobs sorted so that the jobs of one group (<= kSelGroupMax, same row block) are adjacent;
+// groups = int2 {first job, count}
+constexpr int kSelGroupMax = 8;
+hipError_t launch_select_ranks(void *jobs, int n_jobs, const void *groups, int n_groups, int64_t N,
+                               int64_t T, unsigned int *hist, double *out, hipStream_t st);
 constexpr int kSelJobBytes = 32;
 hipError_t launch_pre_transform(const double *A, int64_t N, int64_t T, int64_t a_stride, int inc,
                                 double *out, hipStream_t st);

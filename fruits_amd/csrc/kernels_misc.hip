@@ -279,26 +279,52 @@ __device__ __forceinline__ double key_to_double(unsigned long long k) {
   return __longlong_as_double((long long)u);
 }
 
+// One block column per GROUP of jobs that read the same (N, T) row block (the ranks and
+// differencing orders one iterated sum is asked for): every element is loaded once per
+// pass for all of them.
+constexpr int kSelGroupJobs = 8;
 __global__ __launch_bounds__(256) void select_hist_kernel(const SelJob *__restrict__ jobs,
+                                                           const int2 *__restrict__ groups,
                                                            int64_t N, int64_t T, int shift,
                                                            unsigned int *__restrict__ hist) {
-  __shared__ unsigned int lh[256];
-  const int job = blockIdx.y;
-  lh[threadIdx.x] = 0;
+  __shared__ unsigned int lh[kSelGroupJobs][256];
+  const int jb = groups[blockIdx.y].x, nj = groups[blockIdx.y].y;
+  for (int j = 0; j < nj; ++j) lh[j][threadIdx.x] = 0;
   __syncthreads();
-  const double *base = jobs[job].base;
-  const unsigned long long prefix = jobs[job].prefix;
-  const int inc = jobs[job].inc;
+  const double *base = jobs[jb].base;
   const int64_t total = N * T;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t n = i / T, t = i - n * T;
-    const unsigned long long key = order_key(diff_at(base + n * T, t, inc));
-    const bool match = shift == 56 || (key >> (shift + 8)) == (prefix >> (shift + 8));
-    if (match) atomicAdd(&lh[(key >> shift) & 255], 1u);
+    unsigned long long key = 0;
+    int key_inc = -1;
+    for (int j = 0; j < nj; ++j) {
+      const int inc = jobs[jb + j].inc;
+      if (inc != key_inc) {  // jobs are sorted by differencing order
+        key = order_key(diff_at(base + n * T, t, inc));
+        key_inc = inc;
+      }
+      const unsigned long long prefix = jobs[jb + j].prefix;
+      const bool match = shift == 56 || (key >> (shift + 8)) == (prefix >> (shift + 8));
+      const unsigned int bin = (unsigned int)(key >> shift) & 255u;
+      // The leading digits (sign, exponent, high mantissa bits) are shared by almost all
+      // elements: 64 lanes adding to ONE LDS counter serialise.  When every matching lane
+      // of the wave holds the same digit, one lane adds the population count instead.
+      const unsigned long long m = __ballot(match);
+      if (m == 0) continue;
+      const int leader = __ffsll((long long)m) - 1;
+      const unsigned int lead_bin = (unsigned int)__builtin_amdgcn_readlane((int)bin, leader);
+      if (__ballot(match && bin == lead_bin) == m) {
+        if ((int)(threadIdx.x & 63) == leader)
+          atomicAdd(&lh[j][lead_bin], (unsigned int)__popcll(m));
+      } else if (match) {
+        atomicAdd(&lh[j][bin], 1u);
+      }
+    }
   }
   __syncthreads();
-  if (lh[threadIdx.x]) atomicAdd(&hist[job * 256 + threadIdx.x], lh[threadIdx.x]);
+  for (int j = 0; j < nj; ++j)
+    if (lh[j][threadIdx.x]) atomicAdd(&hist[(jb + j) * 256 + threadIdx.x], lh[j][threadIdx.x]);
 }
 
 __global__ void select_pick_kernel(SelJob *__restrict__ jobs, int shift,
@@ -320,15 +346,16 @@ __global__ void select_pick_kernel(SelJob *__restrict__ jobs, int shift,
   for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[job * 256 + i] = 0;
 }
 
-hipError_t launch_select_ranks(void *jobs, int n_jobs, int64_t N, int64_t T, unsigned int *hist,
-                               double *out, hipStream_t st) {
-  if (n_jobs <= 0 || N * T <= 0) return hipSuccess;
+hipError_t launch_select_ranks(void *jobs, int n_jobs, const void *groups, int n_groups, int64_t N,
+                               int64_t T, unsigned int *hist, double *out, hipStream_t st) {
+  if (n_jobs <= 0 || n_groups <= 0 || N * T <= 0) return hipSuccess;
   int64_t bpj = (N * T + 256 * 16 - 1) / (256 * 16);
   if (bpj > 512) bpj = 512;
   if (bpj < 1) bpj = 1;
   for (int shift = 56; shift >= 0; shift -= 8) {
-    hipLaunchKernelGGL(select_hist_kernel, dim3((unsigned)bpj, (unsigned)n_jobs), dim3(256), 0, st,
-                       static_cast<const SelJob *>(jobs), N, T, shift, hist);
+    hipLaunchKernelGGL(select_hist_kernel, dim3((unsigned)bpj, (unsigned)n_groups), dim3(256), 0,
+                       st, static_cast<const SelJob *>(jobs), static_cast<const int2 *>(groups), N,
+                       T, shift, hist);
     hipLaunchKernelGGL(select_pick_kernel, dim3((unsigned)n_jobs), dim3(64), 0, st,
                        static_cast<SelJob *>(jobs), shift, hist, out);
   }
