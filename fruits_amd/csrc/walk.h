@@ -691,6 +691,7 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
   for (int i = 0; i < 8; ++i) cx.seg[i] = 0;
   cx.last = stamp_now();
   const unsigned long long t_begin = cx.last;
+  const unsigned long long real_begin = __builtin_amdgcn_s_memrealtime();  // 100 MHz, global
 #endif
   // Persistent workgroups: the grid holds one resident round of workgroups and
   // each walks units b, b + grid, ...  A unit is (series n, group g of sub-tries).
@@ -781,10 +782,12 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
   }
 #ifdef FRUITS_HIP_TIMING_BUILD
   if ((a.debug & 16) && a.dbg != nullptr && cx.lane == 0) {
-    unsigned long long *o = a.dbg + ((int64_t)blockIdx.x * 4 + cx.team * C::TEAM + cx.wave) * 10;
+    unsigned long long *o = a.dbg + ((int64_t)blockIdx.x * 4 + cx.team * C::TEAM + cx.wave) * 12;
     for (int i = 0; i < 8; ++i) o[i] = cx.seg[i];
     o[8] = stamp_now() - t_begin;
     o[9] = t_begin;
+    o[10] = real_begin;
+    o[11] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
 }

@@ -22,11 +22,22 @@ work.zero_()
 plan.run(Xd, None, out=out, work=work); torch.cuda.synchronize()
 raw = work[:].cpu().numpy().view(np.uint64)
 nwaves = min(N, 1536) * 4 if os.environ.get("FRUITS_HIP_PERSIST", "1") != "0" else N * 4
-st = raw[: nwaves * 10].reshape(nwaves, 10).astype(np.float64)
+st = raw[: nwaves * 12].reshape(nwaves, 12).astype(np.float64)
 names = ["interp", "factors", "scan-local", "lds+barrier", "prefix+final", "stores", "staging", "-"]
 tot = st[:, 8]
-print(f"waves {nwaves}  lifetime cycles: median {np.median(tot):.0f}  min {tot.min():.0f}  max {tot.max():.0f}")
+ok = tot > 0
+print(f"waves reporting {int(ok.sum())} of {nwaves}; lifetime cycles: median {np.median(tot[ok]):.0f}  "
+      f"min {tot[ok].min():.0f}  max {tot[ok].max():.0f}")
 for i, nm in enumerate(names[:7]):
-    print(f"  {nm:14s} median {np.median(st[:, i]):9.0f}  share {np.median(st[:, i]) / np.median(tot) * 100:5.1f}%")
-t0 = raw[: nwaves * 10].reshape(nwaves, 10)[:, 9].astype(np.int64)
-print("start spread (cycles):", int(t0.max() - t0.min()))
+    print(f"  {nm:14s} median {np.median(st[ok, i]):9.0f}  share {np.median(st[ok, i]) / np.median(tot[ok]) * 100:5.1f}%")
+rb = raw[: nwaves * 12].reshape(nwaves, 12)[:, 10].astype(np.int64)[ok]
+re = raw[: nwaves * 12].reshape(nwaves, 12)[:, 11].astype(np.int64)[ok]
+g0 = rb.min()
+start, end = (rb - g0) / 100.0, (re - g0) / 100.0        # microseconds (100 MHz)
+span = end.max()
+print(f"kernel span {span:.1f} us; wave start: median {np.median(start):.1f} p90 {np.percentile(start, 90):.1f} max {start.max():.1f} us")
+print("wave END deciles (us):", [round(float(np.percentile(end, q)), 1) for q in range(10, 101, 10)])
+print("wave lifetime deciles (us):", [round(float(np.percentile(end - start, q)), 1) for q in range(10, 101, 10)])
+edges = np.linspace(0, span, 21)
+alive = [int(((start < b) & (end > a)).sum()) for a, b in zip(edges[:-1], edges[1:])]
+print("waves alive per 5% slice:", alive)
