@@ -31,7 +31,7 @@ EXPORTS = [
     "fr_pathlen_lookup", "fr_sieve", "fr_pre_transform", "fr_standardize",
     "fr_pipeline_create", "fr_pipeline_destroy", "fr_pipeline_info",
     "fr_pipeline_workspace_bytes", "fr_pipeline_run", "fr_pipeline_set_quantiles",
-    "fr_select_ranks", "fr_coswiss_combine", "fr_plan_create_coswiss",
+    "fr_select_ranks", "fr_coswiss_combine", "fr_plan_create_coswiss", "fr_nan_to_num",
 ]
 
 _lib = None
@@ -475,3 +475,11 @@ def coswiss_combine(terms_d, begin_d, coeff_d, desc_d, trig_d, out, out_row_stri
                                   stream_ptr())
     check(rc, "fr_coswiss_combine")
     return out
+
+
+def nan_to_num(xd):
+    """In place np.nan_to_num(x, nan=0.0) of a contiguous float64 device tensor."""
+    if not xd.is_contiguous():
+        raise TypeError("nan_to_num needs a contiguous tensor")
+    check(lib().fr_nan_to_num(dptr(xd), C.c_int64(xd.numel()), stream_ptr()), "fr_nan_to_num")
+    return xd

@@ -816,6 +816,15 @@ int fr_standardize(const double *d_X, int64_t rows, int64_t T, int32_t div_std, 
   return FR_OK;
 }
 
+int fr_nan_to_num(double *d_x, int64_t count, void *stream) {
+  if (count < 0) return fail(FR_E_ARG, "fr_nan_to_num: bad count");
+  if (count == 0) return FR_OK;
+  if (!d_x) return fail(FR_E_ARG, "fr_nan_to_num: null device pointer");
+  hipError_t e = fr::launch_nan_to_num(d_x, count, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "nan_to_num launch");
+  return FR_OK;
+}
+
 int fr_coswiss_combine(const double *d_terms, int64_t n_terms, int64_t N, int64_t T,
                        int32_t n_out, const int32_t *d_begin, const double *d_coeff,
                        const int32_t *d_desc, const double *d_trig, double *d_out,

@@ -95,6 +95,7 @@ hipError_t launch_coswiss_combine(const double *A, int64_t N, int64_t T, int n_o
                                   const int32_t *begin, const double *coeff, const int32_t *desc,
                                   const double *trig, double *out, int64_t out_row_stride,
                                   hipStream_t st);
+hipError_t launch_nan_to_num(double *x, int64_t count, hipStream_t st);
 hipError_t launch_standardize(const double *X, int64_t rows, int64_t T, int div_std, double eps,
                               double *out, hipStream_t st);
 

@@ -556,6 +556,26 @@ hipError_t launch_coswiss_combine(const double *A, int64_t N, int64_t T, int n_o
   return hipGetLastError();
 }
 
+// np.nan_to_num(features, nan=0.0) of Fruit.transform (fruits/fruit.py:172): NaN -> 0,
+// +-inf -> the largest / lowest finite double
+__global__ void nan_to_num_kernel(double *__restrict__ x, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = x[i];
+    if (v != v) x[i] = 0.0;
+    else if (v == __builtin_inf()) x[i] = 1.7976931348623157e308;
+    else if (v == -__builtin_inf()) x[i] = -1.7976931348623157e308;
+  }
+}
+
+hipError_t launch_nan_to_num(double *x, int64_t count, hipStream_t st) {
+  if (count <= 0) return hipSuccess;
+  int64_t blocks = (count + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(nan_to_num_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, count);
+  return hipGetLastError();
+}
+
 hipError_t launch_standardize(const double *X, int64_t rows, int64_t T, int div_std, double eps,
                               double *out, hipStream_t st) {
   if (rows <= 0 || T <= 0) return hipSuccess;

@@ -113,7 +113,7 @@ class Fruit:
             blocks.append(slc.transform_device(X, callbacks, cache_))
         # assembled on the device: one download instead of a strided host copy per slice
         result = blocks[0] if len(blocks) == 1 else t.cat(blocks, dim=1)
-        return nat.to_host(t.nan_to_num(result, nan=0.0))
+        return nat.to_host(nat.nan_to_num(result.contiguous()))
 
     def fit_transform(self, X: np.ndarray,
                       callbacks: Optional[list[AbstractCallback]] = None) -> np.ndarray:

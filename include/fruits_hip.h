@@ -271,6 +271,12 @@ int fr_coswiss_combine(const double *d_terms, int64_t n_terms, int64_t N, int64_
                        const int32_t *d_desc, const double *d_trig, double *d_out,
                        int64_t out_row_stride, void *stream);
 
+/* ------------------------------------------------------------------ Fruit.transform epilogue
+ * np.nan_to_num(result, copy=False, nan=0.0) of Fruit.transform (fruits/fruit.py:172) on the
+ * device-resident feature matrix, in place: NaN -> 0, +inf / -inf -> the largest / lowest
+ * finite double (numpy's defaults).  d_x: `count` contiguous doubles. */
+int fr_nan_to_num(double *d_x, int64_t count, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

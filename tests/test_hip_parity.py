@@ -406,6 +406,25 @@ def test_coswiss_fused_pipeline(fr, monkeypatch, T, total):
     compare_features(fused, ref, labels, count_frac=0.05)
 
 
+def test_nan_to_num_epilogue(fr):
+    # Fruit.transform ends with np.nan_to_num(result, nan=0.0) (fruits/fruit.py:172)
+    from fruits_amd import _native as nat
+    x = np.array([[0.0, np.nan, np.inf], [-np.inf, 1.5, -0.0]])
+    got = nat.to_host(nat.nan_to_num(nat.to_device(x)))
+    np.testing.assert_array_equal(got, np.nan_to_num(x, nan=0.0))
+    # through a fruit: 1/x on a series with zeros gives inf / nan iterated sums
+    X = np.zeros((3, 1, 16))
+    X[1] = 1.0
+    fruit = fr.Fruit()
+    fruit.add(fr.ISS([fr.words.SimpleWord("[-1]"), fr.words.SimpleWord("[1][-1]")]),
+              fr.sieving.END)
+    feats = fruit.fit_transform(X)
+    with np.errstate(all="ignore"):
+        its = orc.iss_transform(X, ["[-1]", "[1][-1]"], "SINGLE")
+    want = np.nan_to_num(np.stack([its[0][:, -1], its[1][:, -1]], axis=1), nan=0.0)
+    np.testing.assert_array_equal(feats, want)
+
+
 def test_coswiss_unsupported(fr):
     cw = fr.CosWISS([fr.words.SimpleWord("[1]")], [0.5], dropout=0.5)
     with pytest.raises(NotImplementedError):
