@@ -413,6 +413,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   }
   a.persistent = env_int("FRUITS_HIP_PERSIST", 1);
   a.wave_rows = wave_rows ? 1 : 0;
+  a.prefetch_next = env_int("FRUITS_HIP_PREFETCH", 24);  // longest unit (nodes) that prefetches; 0: off
   a.semiring = p.semiring;
   {
     int max_nodes = 0;

@@ -698,6 +698,16 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
   // Workgroups are dealt round-robin over the 8 XCDs and the grid is a multiple
   // of 8, so with the mapping below all groups of one series meet in one XCD's
   // L2 (speed only, never correctness).
+  int sink = 0;  // next-unit prefetch (see below): one word per 128-byte line of the rows
+  int pf_val = 0, pf_off = -1;
+  if constexpr (C::TEAM != 1 && C::MODE == 0) {
+    const int lines = (int)((a.T * 8 + 127) >> 7);
+    if (a.prefetch_next && a.nchunks == 1 && a.D * a.T < (1 << 30) && tid < a.R * lines) {
+      const int r = tid / lines, line = tid - r * lines;
+      const int src = a.row_src[r];
+      if (src >= 0) pf_off = src * (int)a.T + line * 16;
+    }
+  }
   for (int64_t u = blockIdx.x; u < units; u += gridDim.x) {
     int64_t n;
     int g;
@@ -770,6 +780,31 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
         }
       }
       __syncthreads();
+      if constexpr (C::TEAM != 1 && C::MODE == 0) {
+        if (a.prefetch_next && a.nchunks == 1) {
+          // Touch one word per 128-byte line of the rows of this workgroup's NEXT unit, so
+          // that its staging - issued when the memory system is full of this kernel's
+          // stores - finds them in the L2 / Infinity Cache.  The loaded value is only
+          // consumed behind the next staging wait (no extra stall).
+          sink += pf_val;
+          pf_val = 0;
+          const int64_t un = u + gridDim.x;
+          // (lines touched a whole long unit ahead are evicted before they are used:
+          // units of more than prefetch_next nodes do not prefetch)
+          const int n_rec = as_const(a.group_begin)[g + 1] - node_begin;
+          if (un < units && n_rec <= a.prefetch_next) {
+            int64_t n2;
+            if (a.xcd_map) {
+              const int64_t q = un >> 3, r = un & 7;
+              n2 = (q / a.G) * 8 + r;
+            } else {
+              n2 = un / a.G;
+            }
+            if (pf_off >= 0)
+              pf_val = *reinterpret_cast<const int *>(a.X + n2 * a.D * a.T + pf_off);
+          }
+        }
+      }
       STAMP(cx, 6);  // staging
       double ones[C::EP];  // identity of the semiring's product: 1 (Reals), 0 (Arctic)
 #pragma unroll
@@ -780,6 +815,7 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
     }
     first_unit = false;
   }
+  if (sink + pf_val == 0x7fffffff) a.out[0] = (double)sink;  // keeps the prefetch loads alive
 #ifdef FRUITS_HIP_TIMING_BUILD
   if ((a.debug & 16) && a.dbg != nullptr && cx.lane == 0) {
     unsigned long long *o = a.dbg + ((int64_t)blockIdx.x * 4 + cx.team * C::TEAM + cx.wave) * 12;
