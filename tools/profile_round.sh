@@ -5,9 +5,10 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r01}
 O=$R/gpurun_out/prof_$TAG
+rm -rf $O
 mkdir -p $O
 cd $R
-CMD="python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline"
+CMD="python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $CMD > $O/trace.log 2>&1 || echo "trace failed"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $CMD > $O/fetch.log 2>&1 || echo "fetch failed"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $CMD > $O/write.log 2>&1 || echo "write failed"

@@ -9,10 +9,12 @@ if stats:
     rows = list(csv.DictReader(open(stats[0])))
     with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as f:
         w = csv.DictWriter(f, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(rows)
-    for r in rows:
-        if "iss_walk" in r["Name"]:
-            summary["iss_walk_calls"] = int(r["Calls"])
-            summary["iss_walk_avg_ns"] = float(r["AverageNs"])
+    walk = [r for r in rows if "iss_walk" in r["Name"]]
+    if walk:
+        r = max(walk, key=lambda r: int(r["Calls"]))
+        summary["iss_walk_kernel"] = r["Name"]
+        summary["iss_walk_calls"] = int(r["Calls"])
+        summary["iss_walk_avg_ns"] = float(r["AverageNs"])
 def pmc(sub, name):
     vals = []
     for f in glob.glob(root + f"/{sub}/**/*counter_collection.csv", recursive=True):
