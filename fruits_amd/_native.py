@@ -146,7 +146,7 @@ class Plan:
 
     def __init__(self, words: Sequence[np.ndarray], depths: Sequence[int],
                  alphas: Optional[Sequence[np.ndarray]] = None, weighting: int = FR_W_NONE,
-                 share_prefixes: bool = True, arctic: bool = False):
+                 share_prefixes: bool = True, arctic: bool = False, bayesian: bool = False):
         L = lib()
         self._h = None
         mats = [np.ascontiguousarray(w, dtype=np.int32) for w in words]
@@ -175,7 +175,8 @@ class Plan:
             Dws.ctypes.data_as(ip),
             al.ctypes.data_as(C.POINTER(C.c_float)) if al is not None else None,
             dep.ctypes.data_as(ip), C.c_int32(weighting),
-            C.c_int32((1 if share_prefixes else 0) | (2 if arctic else 0)))
+            C.c_int32((1 if share_prefixes else 0) | (2 if arctic else 0)
+                      | (4 if bayesian else 0)))
         if not h:
             raise ValueError(last_error())
         self._h = C.c_void_p(h)
@@ -360,7 +361,8 @@ class Pipeline:
 
 
 # ----------------------------------------------------------------------- kernels
-def iterated_sum_fast_host(Z, word, alpha, lookup, extended, total_weighting, arctic=False):
+def iterated_sum_fast_host(Z, word, alpha, lookup, extended, total_weighting, arctic=False,
+                           bayesian=False):
     """fr_iterated_sum_fast_host: host arrays in / out (the literal drop-in of
     Semiring.iterated_sum_fast, fruits/iss/semiring.py:43-52)."""
     require_device()
@@ -377,7 +379,8 @@ def iterated_sum_fast_host(Z, word, alpha, lookup, extended, total_weighting, ar
         word.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(Lw), C.c_int32(Dw),
         al.ctypes.data_as(C.POINTER(C.c_float)) if al is not None else None,
         lk.ctypes.data_as(dp) if lk is not None else None, C.c_int64(int(extended)),
-        C.c_int32((1 if total_weighting else 0) | (2 if arctic else 0)), out.ctypes.data_as(dp))
+        C.c_int32((1 if total_weighting else 0) | (2 if arctic else 0) | (4 if bayesian else 0)),
+        out.ctypes.data_as(dp))
     check(rc, "fr_iterated_sum_fast_host")
     return out
 

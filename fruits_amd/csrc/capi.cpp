@@ -646,7 +646,8 @@ int fr_iterated_sum_fast_host(const double *h_Z, int64_t N, int64_t D, int64_t T
   if (extended < 1 || extended > L)
     return fail(FR_E_ARG, "fr_iterated_sum_fast_host: extended must be in [1, L]");
   const int weighting = h_lookup ? ((total_weighting & 1) ? FR_W_TOTAL : FR_W_NONTOTAL) : FR_W_NONE;
-  const int plan_flags = (total_weighting & 2) ? FR_PLAN_ARCTIC : 0;
+  const int plan_flags = (total_weighting & 2) ? FR_PLAN_ARCTIC
+                                               : ((total_weighting & 4) ? FR_PLAN_BAYESIAN : 0);
   if (weighting != FR_W_NONE && !alpha)
     return fail(FR_E_ARG, "fr_iterated_sum_fast_host: weighted call needs alpha");
   const int32_t depth = (int32_t)extended;

@@ -206,7 +206,7 @@ Plan *build_plan(int W, const int32_t *exps, const int32_t *L, const int32_t *Dw
     Plan *p = new Plan();
     p->W = W;
     p->weighting = weighting;
-    p->semiring = (flags & 2) ? kSemiArctic : kSemiReals;
+    p->semiring = (flags & 2) ? kSemiArctic : ((flags & 4) ? kSemiBayesian : kSemiReals);
     p->shared = share;
     Builder b;
     b.p = p;
@@ -333,11 +333,11 @@ GroupedProgram &grouped(Plan &p, int G) {
         NodeRec r{};
         bool slow = nd.fac_count > kRecInlineFactors;
         for (int j = 0; j < nd.fac_count; ++j)
-          if (p.semiring == kSemiReals && (p.factors[nd.fac_begin + j] & FAC_DIV)) slow = true;
+          if (p.multiplicative() && (p.factors[nd.fac_begin + j] & FAC_DIV)) slow = true;
         r.w[0] = (nd.level & 0xff) | (((nd.flags | (slow ? F_SLOW : 0)) & 0xff) << 8);
         r.w[1] = nd.fac_count;
         for (int j = 0; j < kRecInlineFactors && j < nd.fac_count; ++j)
-          r.w[2 + j] = p.semiring == kSemiReals ? (p.factors[nd.fac_begin + j] & FAC_ROW_MASK)
+          r.w[2 + j] = p.multiplicative() ? (p.factors[nd.fac_begin + j] & FAC_ROW_MASK)
                                                 : p.factors[nd.fac_begin + j];
         r.w[6] = nd.emit_count;
         for (int j = 0; j < kRecInlineEmits && j < nd.emit_count; ++j)

@@ -22,7 +22,7 @@ constexpr int32_t F_CHILDREN = 2;  // the exclusive prefix of this node is consu
 // the ADDED term el * row (one code per dimension of the extended letter).
 constexpr int32_t FAC_DIV = 0x80;
 constexpr int32_t FAC_ROW_MASK = 0x7f;
-constexpr int kSemiReals = 0, kSemiArctic = 1;
+constexpr int kSemiReals = 0, kSemiArctic = 1, kSemiBayesian = 2;
 constexpr int32_t fac_arctic(int row, int el) { return row | ((el & 0xff) << 8); }
 
 constexpr int kMaxLevels = 8;   // deepest register-frame stack a kernel variant supports
@@ -105,6 +105,8 @@ struct Plan {
   // Arctic: aux table a = g*alpha_a
   std::vector<float> alphas;
   int aux_tables() const { return (int)alphas.size() * (semiring == kSemiArctic ? 1 : 2); }
+  // Bayesian (max, x) shares the Reals encoding of letters and exp weights
+  bool multiplicative() const { return semiring != kSemiArctic; }
   int dims_used = 0;
   std::map<int, GroupedProgram> programs;  // per G
   int device = -1;

@@ -30,7 +30,8 @@ template <int E_, int P_, int MAXLV_, int MULTI_, bool VEC_, bool WEIGHTED_, int
           int MODE_ = 0, int SEMI_ = 0>
 struct WalkCfg {
   // SEMI 0: Reals (+, x) with an exclusive shift between letters; SEMI 1: Arctic
-  // (max, +), letters add el * x and children continue from the INCLUSIVE maximum
+  // (max, +), letters add el * x and children continue from the INCLUSIVE maximum;
+  // SEMI 2: Bayesian (max, x): the letters and weights of Reals, the scan of Arctic
   static constexpr int SEMI = SEMI_;
   // MODE 0: write the (K,N,T) tensor.  MODE 1: fused sieve epilogue - the values of
   // a node go straight into NPI / MPI / END features, no tensor is written.
@@ -281,7 +282,7 @@ template <class C>
 __device__ __forceinline__ void mul_row(const WalkCtx &cx, int code, double (&s)[C::EP]) {
   double v[C::EP];
   read_row<C>(cx, code & FAC_ROW_MASK, v);
-  if constexpr (C::SEMI == 0) {
+  if constexpr (C::SEMI != 1) {
 #pragma unroll
     for (int i = 0; i < C::EP; ++i) s[i] = s[i] * v[i];
   } else {
@@ -302,7 +303,7 @@ __device__ __forceinline__ void slow_factors(const WalkCtx &cx, int fac_begin, i
                                           double (&s)[C::EP]) {
   for (int f = 0; f < nf; ++f) {
     const int code = as_const(cx.a->factors)[fac_begin + f];
-    if constexpr (C::SEMI != 0) {
+    if constexpr (C::SEMI == 1) {
       mul_row<C>(cx, code, s);
       continue;
     }
@@ -568,7 +569,7 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd, int slo
     if (nd.emit_count() > 0) {
       // total weighting: Reals emit c * exp(-g alpha_k), Arctic emit c - g alpha_k
       if (C::WEIGHTED && emit_mul >= 0)
-        mul_row<C>(cx, C::SEMI == 0 ? emit_mul : fac_arctic(emit_mul, -1), c);
+        mul_row<C>(cx, C::SEMI != 1 ? emit_mul : fac_arctic(emit_mul, -1), c);
       if constexpr (C::MODE == 1)
         fused_all<C>(cx, nd, pre, c, x, s, !(C::WEIGHTED && emit_mul >= 0));
       else
@@ -581,7 +582,7 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd, int slo
       double s2[EP], c[EP], x[EP];
 #pragma unroll
       for (int i = 0; i < EP; ++i) s2[i] = s[i];
-      mul_row<C>(cx, C::SEMI == 0 ? z_mul : fac_arctic(z_mul, 1), s2);
+      mul_row<C>(cx, C::SEMI != 1 ? z_mul : fac_arctic(z_mul, 1), s2);
       block_scan<C>(cx, s2, c, x, slot + 1);
 #pragma unroll
       for (int i = 0; i < EP; ++i) pout[i] = C::SEMI == 0 ? x[i] : c[i];
@@ -806,9 +807,9 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
         }
       }
       STAMP(cx, 6);  // staging
-      double ones[C::EP];  // identity of the semiring's product: 1 (Reals), 0 (Arctic)
+      double ones[C::EP];  // identity of the semiring's product: 1 (Reals, Bayesian), 0 (Arctic)
 #pragma unroll
-      for (int i = 0; i < C::EP; ++i) ones[i] = C::SEMI == 0 ? 1.0 : 0.0;
+      for (int i = 0; i < C::EP; ++i) ones[i] = C::SEMI != 1 ? 1.0 : 0.0;
       int pc = node_begin;
       Rec cur = load_rec(a.recs, pc);
       walk<C, 0>(cx, cur, pc, ones);

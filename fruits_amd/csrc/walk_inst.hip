@@ -24,6 +24,9 @@ static hipError_t inst_w(const IssArgs &a, hipStream_t st) {
   if (a.semiring == kSemiArctic)
     return a.aux ? launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, true, 4, WALK_MODE, 1>(a, st)
                  : launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, false, 4, WALK_MODE, 1>(a, st);
+  if (a.semiring == kSemiBayesian)
+    return a.aux ? launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, true, 4, WALK_MODE, 2>(a, st)
+                 : launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, false, 4, WALK_MODE, 2>(a, st);
   return a.aux ? launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, true, 4, WALK_MODE>(a, st)
                : launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, false, 4, WALK_MODE>(a, st);
 }

@@ -20,7 +20,7 @@ __device__ __forceinline__ cptr<T> as_const(const T *p) {
 
 // ---------------------------------------------------------------- wave scan
 // The scan is written for both semirings: SEMI 0 = Reals (the "sum" is +, identity
-// 0.0), SEMI 1 = Arctic (the "sum" is max, identity -inf).
+// 0.0), SEMI 1 = Arctic and SEMI 2 = Bayesian (the "sum" is max, identity -inf).
 template <int SEMI>
 __device__ __forceinline__ double semi_add(double a, double b) {
   if constexpr (SEMI == 0) return a + b;

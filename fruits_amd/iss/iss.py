@@ -19,7 +19,7 @@ from .. import _native as nat
 from ..cache import SharedSeedCache
 from ..seed import Seed
 from .cache import CachePlan
-from .semiring import Arctic, Reals, Semiring
+from .semiring import Arctic, Bayesian, Reals, Semiring
 from .weighting import Weighting
 from .words.word import SimpleWord, Word
 
@@ -69,7 +69,7 @@ class ISS(Seed):
         if isinstance(self.semiring, Arctic):
             if self.semiring._argmax:
                 raise NotImplementedError("Arctic argmax is not on the MI355X path")
-        elif not isinstance(self.semiring, Reals):
+        elif not isinstance(self.semiring, (Reals, Bayesian)):
             raise NotImplementedError(
                 f"semiring {type(self.semiring).__name__} is not on the MI355X hot path")
         for w in self.words:
@@ -92,12 +92,14 @@ class ISS(Seed):
             wmode = nat.FR_W_TOTAL if self.weighting.total else nat.FR_W_NONTOTAL
             alphas = [np.asarray(self.words[i].alpha, dtype=np.float32) for i in indices]
         arctic = isinstance(self.semiring, Arctic)
-        key = (indices, self.mode, wmode, arctic,
+        bayesian = isinstance(self.semiring, Bayesian)
+        key = (indices, self.mode, wmode, arctic, bayesian,
                None if alphas is None else tuple(a.tobytes() for a in alphas))
         plan = self._plans.get(key)
         if plan is None:
             plan = nat.Plan([self.words[i].table() for i in indices],
-                            [self._depth(i) for i in indices], alphas, wmode, arctic=arctic)
+                            [self._depth(i) for i in indices], alphas, wmode, arctic=arctic,
+                            bayesian=bayesian)
             self._plans[key] = plan
         return plan
 

@@ -5,7 +5,7 @@ is the reference's per-word operator; :class:`Reals` implements it with the HIP
 trie-walk kernel through the C ABI (``fr_iterated_sum_fast_host``).  The batched
 device path used by :class:`fruits_amd.ISS` goes through the same kernel for all
 words at once.  Arctic (a "next" row of the scope table) runs on the same kernel;
-Bayesian is outside the MI355X path.
+Bayesian (max, x) runs on the same kernel as well.
 """
 from __future__ import annotations
 
@@ -84,5 +84,15 @@ class Arctic(Semiring):
 
 
 class Bayesian(Semiring):
-    def iterated_sum_fast(self, *args, **kwargs):
-        raise NotImplementedError("the Bayesian semiring is not on the MI355X hot path")
+    """([0, 1], max, x): the letters and exponential weights of Reals, a running
+    maximum instead of the cumulative sum and no shift between letters
+    (fruits/iss/semiring.py:461-571).  Same HIP kernel (scan operator exchanged);
+    the maximum is exact, the products round like the reference's."""
+
+    def iterated_sum_fast(self, Z, word, alpha, lookup, extended, total_weighting):
+        Z = _check_input(Z)
+        word = np.asarray(word, dtype=np.int32)
+        if lookup is not None and not np.any(lookup) and (alpha is None or not np.any(alpha)):
+            lookup = None
+        return nat.iterated_sum_fast_host(Z, word, alpha, lookup, extended, total_weighting,
+                                          bayesian=True)

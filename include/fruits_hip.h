@@ -47,6 +47,9 @@ extern "C" {
 #define FR_PLAN_ARCTIC 2         /* (max, +) semiring instead of (+, x):
                                     Arctic._iterated_sum_fast, fruits/iss/semiring.py:282-400
                                     (argmax=False); "next" row of SURVEY.md 8f */
+#define FR_PLAN_BAYESIAN 4       /* (max, x) semiring: Bayesian._iterated_sum_fast,
+                                    fruits/iss/semiring.py:461-571 - the letters and exp
+                                    weights of Reals, a running maximum, no shift */
 
 /* fr_plan_info selectors */
 #define FR_INFO_ROWS 0       /* K = number of output rows (iterated sums)        */
@@ -134,7 +137,8 @@ int fr_iss_run(fr_plan_t *plan, const double *d_X, int64_t N, int64_t D, int64_t
  * host arrays in, host array out, synchronous:
  *   Z (N,D,T) f64, word (L,Dw) i32, alpha (L) f32, lookup (N,T) f64 or NULL
  *   (NULL = the unweighted call of semiring.py:27-28), extended in [1,L],
- *   total_weighting (bit 0; bit 1 set = Arctic semiring, semiring.py:354-400)
+ *   total_weighting (bit 0; bit 1 set = Arctic semiring, semiring.py:354-400; bit 2 set =
+ *   Bayesian semiring, semiring.py:530-571)
  *   -> out (N, extended, T) f64 (caller allocated). */
 int fr_iterated_sum_fast_host(const double *h_Z, int64_t N, int64_t D, int64_t T,
                               const int32_t *word, int32_t L, int32_t Dw,

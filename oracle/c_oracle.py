@@ -66,7 +66,7 @@ def iterated_sum_fast(Z, word, alpha, lookup, extended, total, nthreads=0, semir
         _p(Z, _dp), C.c_int64(N), C.c_int64(D), C.c_int64(T), _p(word, _ip),
         C.c_int(L), C.c_int(Dw), _p(alpha, _fp),
         _p(lk, _dp) if lk is not None else None, C.c_int64(extended),
-        C.c_int((1 if total else 0) | (2 if semiring == "Arctic" else 0)), _p(out, _dp),
+        C.c_int((1 if total else 0) | (2 if semiring == "Arctic" else 0) | (4 if semiring == "Bayesian" else 0)), _p(out, _dp),
         C.c_int(nthreads))
     if rc != 0:
         raise ValueError("orc_iterated_sum_fast: bad arguments")
@@ -112,7 +112,7 @@ def iss_transform(X, word_strings, mode="SINGLE", alphas=None, lookup=None,
         _p(exps, _ip), _p(word_off, _lp), _p(Ls, _ip), _p(Dws, _ip),
         _p(alpha, _fp) if alpha is not None else None, _p(alpha_off, _lp),
         _p(depth, _ip), _p(lk, _dp) if lk is not None else None,
-        C.c_int((1 if total else 0) | (2 if semiring == "Arctic" else 0)), _p(out, _dp),
+        C.c_int((1 if total else 0) | (2 if semiring == "Arctic" else 0) | (4 if semiring == "Bayesian" else 0)), _p(out, _dp),
         C.c_int(nthreads))
     if rc != 0:
         raise ValueError("orc_iss_batch: word dimension exceeds input dimension")

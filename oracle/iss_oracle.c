@@ -166,6 +166,42 @@ static void single_arctic(const double *Z, int64_t T, const int32_t *word, int L
     }
 }
 
+/* Bayesian semiring (max, x): fruits/iss/semiring.py:461-493 (_bayesian_single) and
+ * :496-527 (_total_weighted_bayesian_single): the letters and exp weights of the Reals
+ * kernels, a running maximum instead of the cumulative sum, no shift.  w == NULL:
+ * unweighted call (total branch with exp(0) = 1 factors, skipped). */
+static void single_bayesian(const double *Z, int64_t T, const int32_t *word, int L, int Dw,
+                            const float *alpha, const double *w, int total, int E,
+                            double *out, double *tmp)
+{
+    for (int64_t t = 0; t < T; ++t) tmp[t] = 1.0;
+    for (int k = 0; k < L; ++k) {
+        letters(tmp, Z, T, word + k * Dw, Dw);
+        double *o = (L - k <= E) ? out + (int64_t)(E - (L - k)) * T : NULL;
+        if (w == NULL || total) {
+            double a = w ? (double)alpha[k] : 0.0;
+            if (w) for (int64_t t = 0; t < T; ++t) tmp[t] = tmp[t] * exp(w[t] * a);
+            cummax(tmp, T);
+            if (o) for (int64_t t = 0; t < T; ++t) o[t] = w ? tmp[t] * exp(-w[t] * a) : tmp[t];
+            if (k < L - 1 && w) for (int64_t t = 0; t < T; ++t) tmp[t] = tmp[t] * exp(-w[t] * a);
+        } else {
+            if (k > 0) {
+                double a = (double)alpha[k - 1];
+                for (int64_t t = 0; t < T; ++t) tmp[t] = tmp[t] * exp(-w[t] * a);
+            }
+            if (o) {
+                o[0] = tmp[0];
+                for (int64_t t = 1; t < T; ++t) o[t] = o[t - 1] > tmp[t] ? o[t - 1] : tmp[t];
+            }
+            if (k < L - 1) {
+                double a = (double)alpha[k];
+                for (int64_t t = 0; t < T; ++t) tmp[t] = tmp[t] * exp(w[t] * a);
+                cummax(tmp, T);
+            }
+        }
+    }
+}
+
 /* Z (N,D,T); word (L,Dw); alpha (L); lookup (N,T) or NULL (= unweighted);
  * out (N,E,T) with arbitrary strides so the batch entry can write (K,N,T). */
 static void iterated_sum_fast_strided(const double *Z, int64_t N, int64_t D, int64_t T,
@@ -175,7 +211,8 @@ static void iterated_sum_fast_strided(const double *Z, int64_t N, int64_t D, int
                                       int64_t out_n_stride, int64_t out_e_stride,
                                       int nthreads)
 {
-    const int arctic = total & 2; /* bit 1 selects the Arctic semiring */
+    const int arctic = total & 2;   /* bit 1 selects the Arctic semiring */
+    const int bayesian = total & 4; /* bit 2 the Bayesian one */
     total &= 1;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -191,6 +228,9 @@ static void iterated_sum_fast_strided(const double *Z, int64_t N, int64_t D, int
             if (arctic)
                 single_arctic(Zj, T, word, L, Dw, alpha, lookup ? lookup + j * T : NULL, total,
                               E, res, tmp);
+            else if (bayesian)
+                single_bayesian(Zj, T, word, L, Dw, alpha, lookup ? lookup + j * T : NULL,
+                                total, E, res, tmp);
             else if (lookup == NULL)
                 single_unweighted(Zj, T, word, L, Dw, E, res, tmp);
             else if (total)

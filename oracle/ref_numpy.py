@@ -195,6 +195,12 @@ def l1_sum(X: np.ndarray) -> np.ndarray:
     return np.cumsum(np.abs(Y), axis=1)
 
 
+def l2_sum(X: np.ndarray) -> np.ndarray:
+    """fruits/cache.py:34-40 (_L2_sum): cumsum of squared increments of DIMENSION 0."""
+    Y = increments(X, 1)[:, 0, :]
+    return np.cumsum(Y * Y, axis=1)
+
+
 def lookup_indices(N, T, relative=True, scale=50.0):
     """fruits/iss/weighting.py:100-110 (Indices.get_lookup, no transform)."""
     r = np.arange(1, T + 1)
@@ -312,6 +318,38 @@ def arctic_iterated_sum_fast(Z, word, alpha, lookup, extended, total_weighting):
     return out
 
 
+def bayesian_iterated_sum_fast(Z, word, alpha, lookup, extended, total_weighting):
+    """fruits/iss/semiring.py:530-571 (Bayesian._iterated_sum_fast) with its bodies
+    ``_bayesian_single`` (:461-493) and ``_total_weighted_bayesian_single`` (:496-527),
+    vectorised over N.  (max, x): the letters and exp weights of the Reals kernels, a
+    running maximum instead of the cumulative sum, no shift between letters."""
+    N, _, T = Z.shape
+    L = len(word)
+    word = np.asarray(word, dtype=np.int32).reshape(L, -1)
+    alpha = np.asarray(alpha, dtype=np.float32)
+    lookup = lookup[:N]
+    out = np.zeros((N, extended, T))
+    tmp = np.ones((N, T))
+    for k in range(L):
+        tmp = _letters(tmp, Z, word[k])
+        if total_weighting:
+            tmp = tmp * np.exp(lookup * alpha[k])
+            tmp = np.maximum.accumulate(tmp, axis=1)
+            if L - k <= extended:
+                out[:, extended - (L - k), :] = tmp * np.exp(-lookup * alpha[k])
+            if k < L - 1:
+                tmp = tmp * np.exp(-lookup * alpha[k])
+        else:
+            if k > 0:
+                tmp = tmp * np.exp(-lookup * alpha[k - 1])
+            if L - k <= extended:
+                out[:, extended - (L - k), :] = np.maximum.accumulate(tmp, axis=1)
+            if k < L - 1:
+                tmp = tmp * np.exp(lookup * alpha[k])
+                tmp = np.maximum.accumulate(tmp, axis=1)
+    return out
+
+
 def iterated_sums(Z, word_rows, alpha=None, lookup=None, extended=1, total=False,
                   semiring="Reals"):
     """fruits/iss/semiring.py:14-41 (Semiring.iterated_sums) for a SimpleWord:
@@ -326,7 +364,8 @@ def iterated_sums(Z, word_rows, alpha=None, lookup=None, extended=1, total=False
                   else np.asarray(alpha, dtype=np.float32))
         lookup_ = lookup
         total_ = total
-    fn = iterated_sum_fast if semiring == "Reals" else arctic_iterated_sum_fast
+    fn = {"Reals": iterated_sum_fast, "Arctic": arctic_iterated_sum_fast,
+          "Bayesian": bayesian_iterated_sum_fast}[semiring]
     return fn(Z, np.array(word_rows, dtype=np.int32), alpha_, lookup_, extended, total_)
 
 
@@ -577,6 +616,14 @@ def _apply_preps(X, preps):
     return X
 
 
+def lookup_l2(X_for_l2, relative=False, scale=50.0):
+    """fruits/iss/weighting.py:198-210 (L2.get_lookup, no transform)."""
+    r = l2_sum(X_for_l2)
+    if relative:
+        r = r / (r[:, -1:] + 1e-5)
+    return nrm_rows(r) * scale
+
+
 def _weight_lookup(spec, X_prepared, X_raw):
     if spec is None:
         return None, False
@@ -589,6 +636,9 @@ def _weight_lookup(spec, X_prepared, X_raw):
     if kind == "L1":
         src = X_prepared if spec.get("on_prepared", False) else X_raw
         return lookup_l1(src, spec.get("relative", False), scale), total
+    if kind == "L2":
+        src = X_prepared if spec.get("on_prepared", False) else X_raw
+        return lookup_l2(src, spec.get("relative", False), scale), total
     raise NotImplementedError(kind)
 
 

@@ -301,6 +301,20 @@ iss_case("arctic_config2_ext", ("gen", gen(c2a)), W23, "EXTENDED", store_slice=[
          semiring="Arctic")
 manifest["iss"][-1]["x_gen"] = c2a
 
+# Bayesian semiring (max, x): reference tests/signature/test_weighting.py:220-278 word sets + random
+iss_case("bayes_w23_ext_U", "U_6_3_40", W23, "EXTENDED", semiring="Bayesian")
+iss_case("bayes_w32_single_U", "U_7_2_129", W32, "SINGLE", semiring="Bayesian")
+iss_case("bayes_neg_words", "P_4_2_33", ["[-1][-2]", "[-12][-2-21]", "[1][-1]", "[-1-1][22]",
+                                          "[111][-2-2-2]"], "EXTENDED", semiring="Bayesian")
+iss_case("bayes_l2_nontotal", "U_6_3_40", ["[12][3][2213]", "[1][3]"], "EXTENDED",
+         alphas=[[.6, .2, .3], None], weighting={"kind": "L2", "scale": 1.0},
+         semiring="Bayesian")
+iss_case("bayes_l2_total", "U_6_3_40", ["[12][3][2213]", "[1][3]"], "EXTENDED",
+         alphas=[[.6, .2, .3], None], weighting={"kind": "L2", "scale": 1.0, "total": True},
+         semiring="Bayesian")
+iss_case("bayes_idx_G", "G_5_3_37", ["[1][2]", "[1][2][3]", "[3]"], "EXTENDED",
+         weighting={"kind": "Indices", "scale": 3.0}, semiring="Bayesian")
+
 # CosWISS ("next" row): frequencies exactly representable in float32 AND with an exact
 # float32 product freq*(T-1), so the un-jitted run agrees with numba's f4->f8 promotion
 manifest["coswiss"] = []

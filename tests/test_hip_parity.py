@@ -128,6 +128,53 @@ def test_arctic_ragged_and_long_chains(fr, T):
         np.testing.assert_array_equal(iss.fit_transform(X), ref)
 
 
+@pytest.mark.parametrize("T", [5, 511, 1024, 1025, 3000])
+def test_bayesian_semiring(fr, T):
+    # (max, x), fruits/iss/semiring.py:461-571; reference tests/signature/test_weighting.py:220-278
+    rng = np.random.default_rng(T)
+    X = rng.random((4, 3, T)) * 0.9 + 0.05            # the semiring lives on [0, 1]
+    words = ["[1]", "[12][3][2213]", "[1][-2]", "[3][1][2][1]", "[12][3]"]
+    for weighting in (None, {"kind": "Indices", "scale": 3.0},
+                      {"kind": "L2", "scale": 1.0, "total": True}):
+        iss = fr.ISS([fr.words.SimpleWord(s) for s in words], mode=fr.ISSMode.EXTENDED,
+                     semiring=fr.semiring.Bayesian(), weighting=make_weighting(fr, weighting))
+        lookup, total = orc._weight_lookup(weighting, X, X)
+        ref = corc.iss_transform(X, words, "EXTENDED", None, lookup, total, semiring="Bayesian")
+        out = iss.fit_transform(X)
+        if weighting is None:
+            np.testing.assert_array_equal(out, ref)    # products in order, max is exact
+        else:
+            np.testing.assert_allclose(out, ref, rtol=1e-9)
+    # the operator entry
+    B = fr.semiring.Bayesian()
+    word = fr.words.SimpleWord("[12][3][2213]").table()
+    alpha = np.array([.6, .2, .3], dtype=np.float32)
+    lk = orc.lookup_l2(X, False, 1.0)
+    for total in (False, True):
+        np.testing.assert_allclose(
+            B.iterated_sum_fast(X, word, alpha, lk, 2, total),
+            orc.bayesian_iterated_sum_fast(X, word, alpha, lk, 2, total), rtol=1e-9)
+
+
+def test_bayesian_fused_pipeline(fr):
+    rng = np.random.default_rng(8)
+    X = rng.random((16, 2, 300)) * 0.9 + 0.05
+    spec = {"slices": [{"iss": [{"words": G.manifest["words"]["3,2"]["words"], "mode": "EXTENDED",
+                                 "semiring": "Bayesian"}],
+                        "sieves": [{"kind": "NPI", "q": [0.5, 1.0]}, {"kind": "MPI", "inc": 0},
+                                   {"kind": "END"}],
+                        "fit_sample_size": 1.0}]}
+    fruit = build_fruit(fr, spec)
+    np.random.seed(4)
+    fruit.fit(X)
+    assert fruit.get_slice()._fused(300) is not None
+    got = fruit.transform(X)
+    np.random.seed(4)
+    ref = orc.fruit_transform(spec, orc.fruit_fit(spec, X), X)
+    labels = [fruit.label(i) for i in range(fruit.nfeatures())]
+    compare_features(got, ref, labels, count_frac=0.05)
+
+
 def test_theoretical_identity(fr):
     # reference tests/signature/test_simple.py:44-51: standardised x => <[1][1]>_T = -T/2
     X = np.random.default_rng(5).random((25, 1, 100))

@@ -212,8 +212,11 @@ def test_iss_bookkeeping():
     with pytest.raises(TypeError):
         fr.ISS(words).fit_transform(np.zeros((1, 3, 4), dtype=np.float32))
     fr.ISS(words, semiring=fr.semiring.Arctic())._check_supported()
+    fr.ISS(words, semiring=fr.semiring.Bayesian())._check_supported()
+    assert fr.ISS(words, semiring=fr.semiring.Bayesian()).label(0) == "[11] : Bayesian"
     with pytest.raises(NotImplementedError):
-        fr.ISS(words, semiring=fr.semiring.Bayesian())._check_supported()
+        fr.ISS(words, semiring=fr.semiring.Arctic(argmax=True),
+               mode=fr.ISSMode.EXTENDED)._check_supported()
     assert fr.ISS(words, semiring=fr.semiring.Arctic()).label(0) == "[11] : Arctic"
     assert ext.word_batches(4, 8, 1) == [(i, i + 1) for i in range(15)]
     assert ext.word_batches(4, 8) == [(0, 15)]
