@@ -324,3 +324,57 @@ def test_coswiss_host_tables(case):
         np.testing.assert_array_equal(trig[f, 1], cs)
     c2 = cw._copy()
     assert c2._freqs == cw._freqs and c2._exponent == cw._exponent
+
+
+def test_plan_compiler_sanitized(tmp_path):
+    """The host plan compiler under AddressSanitizer + UBSan (CPU build; the GPU pool has
+    no sanitizer runs): word lists of the BASELINE configs, long chains, duplicated and
+    invalid words, weighted / Arctic / Bayesian / unshared plans, CosWISS programs."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("g++ not available")
+    exe = str(tmp_path / "plan_sanitize")
+    cmd = [gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined",
+           "-fno-sanitize-recover=undefined", os.path.join(ROOT, "tests", "native", "plan_sanitize.cpp"),
+           os.path.join(ROOT, "fruits_amd", "csrc", "plan.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("sanitizer runtime not available: " + r.stderr[-200:])
+    assert r.returncode == 0, r.stderr
+
+    def case(words, mode="EXTENDED", weighting=0, flags=1, kind=0, depths=None, alphas=None):
+        ws = [fr.words.SimpleWord(s) for s in words]
+        if depths is None:
+            depths = orc.cache_plan(words) if mode == "EXTENDED" else [1] * len(words)
+        lines = [f"{kind} {len(ws)} {weighting} {flags}"]
+        for i, w in enumerate(ws):
+            t = w.table()
+            a = alphas[i] if alphas else [1.0] * t.shape[0]
+            lines.append(f"{t.shape[0]} {t.shape[1]} {depths[i]} "
+                         + " ".join(str(int(v)) for v in t.ravel()) + " "
+                         + " ".join(str(float(v)) for v in a))
+        return "\n".join(lines)
+
+    alt = [str(w) for w in fr.words.alternate_sign([fr.words.SimpleWord(48 * "[1]"),
+                                                    fr.words.SimpleWord(24 * "[1][2]")])]
+    cases = [
+        case(M["words"]["2,3"]["words"]),
+        case(M["words"]["4,2"]["words"], weighting=1),
+        case(M["words"]["6,2"]["words"], weighting=2),
+        case(M["words"]["9,1"]["words"], weighting=1, flags=0),
+        case(alt, flags=1 | 2),                                  # Arctic, 48 levels -> unshared
+        case(M["words"]["3,2"]["words"], flags=1 | 4, weighting=2),   # Bayesian
+        case(["[12]", "[1]", "[12]", "[21]", "[1][-2]"], mode="SINGLE"),
+        case(["[1][2]", "[1][3]"], weighting=1, alphas=[[1.0, 1.0], [0.5, 1.0]]),
+        case(["[1][2][3]"], depths=[0]),                         # nothing to output
+        case(["[1][2]"], depths=[5]),                            # invalid depth: rejected
+        case(M["words"]["3,2"]["words"], kind=1, flags=1),       # CosWISS program
+    ]
+    text = f"{len(cases)}\n" + "\n".join(cases) + "\n"
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe], input=text, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "checksum" in r.stdout and "rejected" in r.stdout
+    assert "K=18 nodes=18" in r.stdout.splitlines()[0]
