@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libfruits_hip.so")
-HEADERS = ["kernels.h", "plan.h", "walk.h", "walk_scan.h", "coswiss.h",
+HEADERS = ["kernels.h", "plan.h", "walk.h", "walk_scan.h", "coswiss.h", "walk_packed.h",
            os.path.join("..", "..", "include", "fruits_hip.h")]
 
 
@@ -29,6 +29,8 @@ def units():
         for lv in (2, 4, 8):
             out.append((f"walk_m{mode}_l{lv}", "walk_inst.hip",
                         [f"-DWALK_MODE={mode}", f"-DWALK_LV={lv}"]))
+    for mode in (0, 1):
+        out.append((f"walk_packed_m{mode}", "walk_packed_inst.hip", [f"-DWALK_MODE={mode}"]))
     for s in (1, 2, 3, 4):
         out.append((f"coswiss_s{s}", "coswiss_inst.hip", [f"-DCOS_S={s}"]))
     return out

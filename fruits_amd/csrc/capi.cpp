@@ -368,7 +368,11 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   const bool wave_rows = !fu && team_env == 1 && groups <= 0 && p.units() >= 4 &&
                          p.semiring == fr::kSemiReals &&
                          fr::wave_rows_supported(T, p.levels, vec_ok_pre);
-  const int G = wave_rows ? 4 : choose_groups(p, N, groups);
+  // short series: four series per workgroup, one wave each
+  const bool packed = !wave_rows && env_int("FRUITS_HIP_PACKED", 1) != 0 &&
+                      fr::packed_supported(T, p.levels, p.semiring);
+  // (a packed workgroup holds four units: ask for four times the units)
+  const int G = wave_rows ? 4 : choose_groups(p, packed ? (N + 3) / 4 : N, groups);
   fr::GroupedProgram &gp = fr::grouped(p, G);
   int rc = ensure_device_program(p, gp);
   if (rc != FR_OK) return rc;
@@ -413,6 +417,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   }
   a.persistent = env_int("FRUITS_HIP_PERSIST", 1);
   a.wave_rows = wave_rows ? 1 : 0;
+  a.packed = packed ? 1 : 0;
   a.prefetch_next = env_int("FRUITS_HIP_PREFETCH", 24);  // longest unit (nodes) that prefetches; 0: off
   a.semiring = p.semiring;
   {

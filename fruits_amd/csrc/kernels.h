@@ -49,6 +49,7 @@ struct IssArgs {
   int32_t carry_in_lds;     // multi-chunk carries fit in LDS
   int32_t semiring;         // kSemiReals / kSemiArctic
   int32_t prefetch_next;    // units of at most this many nodes touch the next unit's rows (0: off)
+  int32_t packed;           // short series: wave-per-series kernel (walk_packed.h)
   int32_t wave_rows;        // TEAM = 1 kernel: one wave per row, 4 groups per workgroup
   // fused sieve epilogue (MODE 1 kernels): features instead of the (K,N,T) tensor
   const FeatOp *ops;        // (K, n_ops_padded) feature ops per output row, 64-byte aligned rows
@@ -68,6 +69,7 @@ struct IssArgs {
 
 int walk_chunk_elems(int64_t T);
 bool wave_rows_supported(int64_t T, int levels, bool vec_ok);
+bool packed_supported(int64_t T, int levels, int semiring);
 hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st);
 hipError_t launch_mpi_finalize(double *feats, const double *cnt, int64_t N, int64_t stride,
                                const int32_t *cols, int n_cols, int per_sum, int K,

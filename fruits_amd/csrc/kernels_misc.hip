@@ -383,6 +383,13 @@ bool wave_rows_supported(int64_t T, int levels, bool vec_ok) {
 DECL_INST(0, 2) DECL_INST(0, 4) DECL_INST(0, 8)
 DECL_INST(1, 2) DECL_INST(1, 4) DECL_INST(1, 8)
 hipError_t walk_inst_team1(const IssArgs &, int, int, hipStream_t);
+hipError_t walk_packed_inst_m0(const IssArgs &, int, hipStream_t);
+hipError_t walk_packed_inst_m1(const IssArgs &, int, hipStream_t);
+
+// short series: four series per workgroup, one wave each (walk_packed.h)
+bool packed_supported(int64_t T, int levels, int semiring) {
+  return T <= 256 && levels <= 8 && semiring == kSemiReals;
+}
 
 hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st) {
   const int chunk = walk_chunk_elems(a.T);
@@ -393,6 +400,10 @@ hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st) {
     if (a.G != 4 || a.feats || !wave_rows_supported(a.T, levels, a.vec_ok != 0))
       return hipErrorInvalidValue;
     return walk_inst_team1(a, levels, chunk, st);
+  }
+  if (a.packed) {
+    if (!packed_supported(a.T, levels, a.semiring)) return hipErrorInvalidValue;
+    return a.feats ? walk_packed_inst_m1(a, levels, st) : walk_packed_inst_m0(a, levels, st);
   }
   if (a.feats) {
     if (levels <= 2) return walk_inst_m1_l2(a, chunk, st);

@@ -175,6 +175,26 @@ def test_bayesian_fused_pipeline(fr):
     compare_features(got, ref, labels, count_frac=0.05)
 
 
+@pytest.mark.parametrize("packed", ["0", "1"])
+@pytest.mark.parametrize("T", [1, 2, 7, 64, 100, 128, 129, 255, 256])
+def test_short_series_kernels(fr, monkeypatch, packed, T):
+    """T <= 256 runs on the wave-per-series kernel (four series per workgroup) by default;
+    FRUITS_HIP_PACKED=0 keeps the cooperative kernel.  Both against the C oracle, with a
+    series count that leaves waves without work, deep words (8 register levels), a
+    per-series (L1) and a broadcast (Indices) lookup."""
+    monkeypatch.setenv("FRUITS_HIP_PACKED", packed)
+    rng = np.random.default_rng(T)
+    X = rng.standard_normal((13, 2, T)) / 2
+    words = G.manifest["words"]["4,2"]["words"][:40] + ["[1][2][1][2][1][2][1][2]", "[2][-1]"]
+    for weighting in (None, {"kind": "Indices", "scale": 2.0},
+                      {"kind": "L1", "scale": 3.0, "total": True}):
+        iss = fr.ISS([fr.words.SimpleWord(s) for s in words], mode=fr.ISSMode.EXTENDED,
+                     weighting=make_weighting(fr, weighting))
+        lookup, total = orc._weight_lookup(weighting, X, X)
+        ref = corc.iss_transform(X, words, "EXTENDED", None, lookup, total)
+        rowwise_close(iss.fit_transform(X), ref)
+
+
 def test_theoretical_identity(fr):
     # reference tests/signature/test_simple.py:44-51: standardised x => <[1][1]>_T = -T/2
     X = np.random.default_rng(5).random((25, 1, 100))
