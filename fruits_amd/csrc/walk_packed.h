@@ -69,16 +69,16 @@ __global__ __launch_bounds__(kWalkThreads) void iss_walk_packed_kernel(const Iss
     }
     double ones[EP];
 #pragma unroll
-    for (int i = 0; i < EP; ++i) ones[i] = 1.0;
+    for (int i = 0; i < EP; ++i) ones[i] = C::SEMI != 1 ? 1.0 : 0.0;
     int pc = node_begin;
     Rec cur = load_rec(a.recs, pc);
     walk<C, 0>(cx, cur, pc, ones);
   }
 }
 
-template <int P, int LV, bool VEC, bool W, int MODE>
+template <int P, int LV, bool VEC, bool W, int MODE, int SEMI>
 static hipError_t launch_walk_packed_cfg(const IssArgs &a, hipStream_t st) {
-  using C = WalkCfg<2, P, LV, 0, VEC, W, 1, MODE, 0>;
+  using C = WalkCfg<2, P, LV, 0, VEC, W, 1, MODE, SEMI>;
   const size_t lds = (size_t)C::TEAMS * a.R * C::CHUNK * sizeof(double);
   if (lds > 64 * 1024) return hipErrorInvalidValue;
   const int64_t units = a.N * a.G;

@@ -4,18 +4,25 @@
 
 namespace fr {
 
-template <int P, int LV>
-static hipError_t packed_pl(const IssArgs &a, hipStream_t st) {
+template <int P, int LV, int SEMI>
+static hipError_t packed_pls(const IssArgs &a, hipStream_t st) {
 #if WALK_MODE == 1
-  return a.aux ? launch_walk_packed_cfg<P, LV, true, true, 1>(a, st)
-               : launch_walk_packed_cfg<P, LV, true, false, 1>(a, st);
+  return a.aux ? launch_walk_packed_cfg<P, LV, true, true, 1, SEMI>(a, st)
+               : launch_walk_packed_cfg<P, LV, true, false, 1, SEMI>(a, st);
 #else
   if (a.vec_ok)
-    return a.aux ? launch_walk_packed_cfg<P, LV, true, true, 0>(a, st)
-                 : launch_walk_packed_cfg<P, LV, true, false, 0>(a, st);
-  return a.aux ? launch_walk_packed_cfg<P, LV, false, true, 0>(a, st)
-               : launch_walk_packed_cfg<P, LV, false, false, 0>(a, st);
+    return a.aux ? launch_walk_packed_cfg<P, LV, true, true, 0, SEMI>(a, st)
+                 : launch_walk_packed_cfg<P, LV, true, false, 0, SEMI>(a, st);
+  return a.aux ? launch_walk_packed_cfg<P, LV, false, true, 0, SEMI>(a, st)
+               : launch_walk_packed_cfg<P, LV, false, false, 0, SEMI>(a, st);
 #endif
+}
+
+template <int P, int LV>
+static hipError_t packed_pl(const IssArgs &a, hipStream_t st) {
+  if (a.semiring == kSemiArctic) return packed_pls<P, LV, 1>(a, st);
+  if (a.semiring == kSemiBayesian) return packed_pls<P, LV, 2>(a, st);
+  return packed_pls<P, LV, 0>(a, st);
 }
 
 #define PACK_CAT2(a, b) a##b

@@ -193,6 +193,13 @@ def test_short_series_kernels(fr, monkeypatch, packed, T):
         lookup, total = orc._weight_lookup(weighting, X, X)
         ref = corc.iss_transform(X, words, "EXTENDED", None, lookup, total)
         rowwise_close(iss.fit_transform(X), ref)
+    # the other semirings share the kernel: Arctic bit-exact, Bayesian bit-exact unweighted
+    Xp = np.abs(X) + 0.1
+    for name in ("Arctic", "Bayesian"):
+        iss = fr.ISS([fr.words.SimpleWord(s) for s in words], mode=fr.ISSMode.EXTENDED,
+                     semiring=getattr(fr.semiring, name)())
+        np.testing.assert_array_equal(iss.fit_transform(Xp),
+                                      corc.iss_transform(Xp, words, "EXTENDED", semiring=name))
 
 
 def test_theoretical_identity(fr):
