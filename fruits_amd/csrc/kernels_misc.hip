@@ -389,7 +389,9 @@ hipError_t walk_packed_inst_m1(const IssArgs &, int, hipStream_t);
 // short series: four series per workgroup, one wave each (walk_packed.h)
 bool packed_supported(int64_t T, int levels, int semiring) {
   (void)semiring;  // all three semirings are instantiated
-  return T <= 256 && levels <= 8;
+  // measured against the cooperative kernel: T = 300 138 -> 88 us, T = 384 143 -> 100 us;
+  // beyond (4 pieces per wave, 8 elements per lane) it is no faster (T = 512: 73 vs 79 us)
+  return (T <= 256 && levels <= 8) || (T <= 384 && levels <= 4);
 }
 
 hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st) {

@@ -1,4 +1,4 @@
-// Short series (T <= 256): four series per workgroup, one wave each.
+// Short series (T <= 256, T <= 384 for shallow tries): four series per workgroup, one wave each.
 //
 // The cooperative kernel (walk.h) spreads ONE series over the 256 threads of a
 // workgroup in chunks of >= 512 elements: with T = 256 half of the lanes hold

@@ -1,5 +1,6 @@
 // Instances of the wave-per-series kernel (walk_packed.h), one translation unit per
-// WALK_MODE: chunk 128 / 256, <= 4 / <= 8 register levels, weighted or not, aligned or not.
+// WALK_MODE: chunk 128 / 256 (<= 4 / <= 8 register levels) and 384 (<= 4 levels), weighted or
+// not, aligned or not, the three semirings.
 #include "walk_packed.h"
 
 namespace fr {
@@ -29,7 +30,9 @@ static hipError_t packed_pl(const IssArgs &a, hipStream_t st) {
 #define PACK_CAT(a, b) PACK_CAT2(a, b)
 hipError_t PACK_CAT(walk_packed_inst_m, WALK_MODE)(const IssArgs &a, int levels, hipStream_t st) {
   if (a.T <= 128) return levels <= 4 ? packed_pl<1, 4>(a, st) : packed_pl<1, 8>(a, st);
-  return levels <= 4 ? packed_pl<2, 4>(a, st) : packed_pl<2, 8>(a, st);
+  if (a.T <= 256) return levels <= 4 ? packed_pl<2, 4>(a, st) : packed_pl<2, 8>(a, st);
+  if (levels > 4 || a.T > 384) return hipErrorInvalidValue;
+  return packed_pl<3, 4>(a, st);
 }
 
 }  // namespace fr
