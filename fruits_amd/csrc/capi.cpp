@@ -335,6 +335,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     a.cw_W = c.W;
     a.cw_F = c.F;
     a.cw_total = c.total ? 1 : 0;
+    a.packed = (T <= 384 && env_int("FRUITS_HIP_PACKED", 1) != 0) ? 1 : 0;
     a.vec_ok = (T % 2 == 0) && aligned16(d_X) && aligned16(trig) &&
                (fu || (aligned16(d_out) && (out_k_stride % 2 == 0) && (out_n_stride % 2 == 0)));
     if (fu) {

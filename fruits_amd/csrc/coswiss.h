@@ -208,6 +208,67 @@ __global__ __launch_bounds__(kWalkThreads) void coswiss_kernel(const IssArgs a) 
   }
 }
 
+// Short series (T <= 384): four units per workgroup, one wave each - the scans are
+// wave-local (no barrier, no LDS), like iss_walk_packed_kernel (walk_packed.h).
+template <class C, int S>
+__global__ __launch_bounds__(kWalkThreads) void coswiss_packed_kernel(const IssArgs a) {
+  static_assert(C::TEAM == 1 && C::MULTI == 0, "wave-per-unit configuration");
+  const int tid = threadIdx.x;
+  WalkCtx cx;
+  cx.a = &a;
+  cx.rows = nullptr;
+  cx.tot = nullptr;
+  cx.tail = nullptr;
+  cx.carry = nullptr;
+  cx.tid = tid;
+  cx.lane = tid & 63;
+  cx.wave = 0;
+  cx.team = __builtin_amdgcn_readfirstlane(tid >> 6);
+  cx.buf = 0;
+  cx.tail_buf = 0;
+  cx.pc_begin = 0;
+  cx.t0 = 0;
+  cx.first_chunk = true;
+  cx.full_chunk = C::CHUNK <= a.T;
+  const int64_t per_series = (int64_t)a.cw_W * a.cw_F;
+  const int64_t units = a.N * per_series;
+  for (int64_t u = (int64_t)blockIdx.x * C::TEAMS + cx.team; u < units;
+       u += (int64_t)gridDim.x * C::TEAMS) {
+    const int64_t n = u / per_series;
+    const int j = (int)(u % per_series);
+    const int w = j / a.cw_F, f = j % a.cw_F;
+    const int lb = as_const(a.cw_letter_begin)[w], le = as_const(a.cw_letter_begin)[w + 1];
+    cx.out_base = a.out + n * a.out_n_stride;
+    if constexpr (C::MODE == 1) {
+      cx.feat_row = a.feats + n * a.feat_stride;
+      cx.cnt_row = a.cnt + n * a.feat_stride;
+    }
+    coswiss_unit<C, S>(cx, a.X + n * a.D * a.T, a.aux + (int64_t)f * 2 * a.T, lb, le,
+                       a.cw_total != 0, j);
+  }
+}
+
+template <int P, bool VEC, int MODE, int S>
+static hipError_t launch_coswiss_packed_cfg(const IssArgs &a, hipStream_t st) {
+  using C = WalkCfg<2, P, 1, 0, VEC, false, 1, MODE, 0>;
+  const int64_t units = a.N * a.cw_W * a.cw_F;
+  static int per_cu = 0;
+  if (per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, coswiss_packed_kernel<C, S>,
+                                                     kWalkThreads, 0) != hipSuccess || nb < 1)
+      nb = 1;
+    per_cu = nb;
+  }
+  int64_t blocks = (units + C::TEAMS - 1) / C::TEAMS;
+  const int64_t resident = (int64_t)per_cu * device_cu_count();
+  if (blocks > resident) blocks = resident;
+  if (blocks < 1) return hipSuccess;
+  hipLaunchKernelGGL((coswiss_packed_kernel<C, S>), dim3((unsigned)blocks), dim3(kWalkThreads), 0,
+                     st, a);
+  return hipGetLastError();
+}
+
 template <int P, int MULTI, bool VEC, int MODE, int S>
 static hipError_t launch_coswiss_cfg(const IssArgs &a, hipStream_t st) {
   using C = WalkCfg<2, P, 1, MULTI, VEC, false, 4, MODE, 0>;

@@ -411,7 +411,7 @@ def test_coswiss_vs_oracle(fr, words, exponent, total):
     assert np.all(np.abs(out - ref) <= RTOL * np.maximum(np.abs(ref), 1e-3 * scale))
 
 
-@pytest.mark.parametrize("T", [700, 1024, 1030, 2051])
+@pytest.mark.parametrize("T", [130, 300, 450, 700, 1024, 1030, 2051])
 @pytest.mark.parametrize("total", [False, True])
 def test_coswiss_long_series(fr, T, total):
     # chunk sizes 512 / 1024, several chunks (carries), odd lengths (scalar accesses)
@@ -426,6 +426,20 @@ def test_coswiss_long_series(fr, T, total):
         out = cw.fit_transform(X)
         ref = orc.coswiss_transform(X, words, freqs, exponent, total)
         scale = np.abs(ref).max(axis=2, keepdims=True)
+        assert np.all(np.abs(out - ref) <= RTOL * np.maximum(np.abs(ref), 1e-3 * scale))
+
+
+def test_coswiss_short_series_cooperative(fr, monkeypatch):
+    # T <= 384 runs one wave per (series, word, frequency) unit; FRUITS_HIP_PACKED=0 keeps the
+    # cooperative kernel - both against the oracle
+    X = np.random.default_rng(9).random((7, 2, 100)) + 0.25
+    words, freqs = ["[1]", "[2][1]", "[1][2][2]"], [0.15, 0.5]
+    ref = orc.coswiss_transform(X, words, freqs, 2, True)
+    scale = np.abs(ref).max(axis=2, keepdims=True)
+    for packed in ("1", "0"):
+        monkeypatch.setenv("FRUITS_HIP_PACKED", packed)
+        out = fr.CosWISS([fr.words.SimpleWord(s) for s in words], freqs, exponent=2,
+                         total_weighting=True).fit_transform(X)
         assert np.all(np.abs(out - ref) <= RTOL * np.maximum(np.abs(ref), 1e-3 * scale))
 
 
