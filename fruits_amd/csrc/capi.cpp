@@ -149,7 +149,7 @@ extern "C" {
 
 const char *fr_last_error(void) { return g_err.c_str(); }
 
-int fr_version(void) { return 100; }
+int fr_version(void) { return 110; }
 
 int fr_device_count(void) {
   int n = 0;
