@@ -370,31 +370,41 @@ class FruitSlice:
                 return False
         return True
 
-    def _fused(self, T: int):
+    def _fused(self, T: int, indices=None):
         """The fused pipeline for series length T (thresholds of the fitted sieve
         copies already resolved), or None when a sieve or the weighting is outside
-        the fused set; cached until the next fit."""
+        the fused set; cached until the next fit.  ``indices``: only these words
+        (a rank's share of a word-sharded slice, fruits_amd.parallel); the pipeline
+        then produces the feature columns of their iterated sums, in that order."""
         if not hasattr(self, "_fused_cache"):
             self._fused_cache = {}
-        if T in self._fused_cache:
-            return self._fused_cache[T]
+        key = T if indices is None else (T, tuple(indices))
+        if key in self._fused_cache:
+            return self._fused_cache[key]
         entry = None
         if self._fusable():
             from .sieving.segment import END
             iss = self._iss[0]
             iss._check_supported()
-            plan = iss._plan(0, len(iss.words))
+            if indices is None:
+                plan = iss._plan(0, len(iss.words))
+                rows = range(plan.rows)
+            else:
+                plan = iss._plan_indices(indices)
+                first = np.concatenate([[0], np.cumsum(
+                    [iss._depth(i) for i in range(len(iss.words))])]).astype(int)
+                rows = [r for i in indices for r in range(first[i], first[i + 1])]
             specs = [(sv._kind, 0 if type(sv) is END else sv._inc, sv._int_cut_row(T),
                       len(sv._q)) for sv in self._sieves]
             try:
-                pipe = nat.Pipeline(plan, specs, T)
+                pipe = nat.Pipeline(plan, specs, T) if len(rows) else None
             except ValueError:
                 pipe = None
             if pipe is not None:
-                K = plan.rows
-                quant = np.zeros((K, pipe.q_stride))
-                for k in range(K):
-                    sieves = self._sieves_extended[k] if self._sieves_extended else self._sieves
+                assert plan.rows == len(rows)
+                quant = np.zeros((len(rows), pipe.q_stride))
+                for k, row in enumerate(rows):
+                    sieves = self._sieves_extended[row] if self._sieves_extended else self._sieves
                     off = 0
                     for sv in sieves:
                         if type(sv) is END:
@@ -405,7 +415,7 @@ class FruitSlice:
                         off += len(sv._q)
                 pipe.set_quantiles(quant)
                 entry = pipe
-        self._fused_cache[T] = entry
+        self._fused_cache[key] = entry
         return entry
 
     def _attach(self, cache) -> None:

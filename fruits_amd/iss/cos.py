@@ -137,6 +137,18 @@ class CosWISS(ISS):
             self._plans[key] = plan
         return plan
 
+    def _plan_indices(self, indices) -> nat.Plan:
+        """Program of an arbitrary subset of the words (a rank's share of a word-sharded
+        slice): rows word-major in the given order, F rows per word."""
+        indices = tuple(indices)
+        key = ("cos", indices)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = nat.CosPlan([self.words[i].table() for i in indices], self._freqs,
+                               self._exponent, self._total_weighting)
+            self._plans[key] = plan
+        return plan
+
     def _n_terms(self, w: int) -> int:
         p = len(self.words[w]) + 1 if self._total_weighting else len(self.words[w])
         return (self._exponent + 1) ** (p - 1)
@@ -171,18 +183,22 @@ class CosWISS(ISS):
                          lookup_d=None, out=None, groups: int = 0, indices=None):
         """Rows [start*F, stop*F) of the result, a ((stop-start)*F, N, T) device tensor."""
         self._check_supported()
-        if indices is not None:
-            raise NotImplementedError("CosWISS has no word-subset programs")
         t = nat.torch()
         stop = len(self.words) if stop is None else stop
         N, D, T = (int(v) for v in Xd.shape)
         F = len(self._freqs)
+        if indices is not None:
+            if not self._native():
+                raise NotImplementedError("word subsets need the factorised CosWISS kernels")
+            n_words = len(indices)
+        else:
+            n_words = stop - start
         if out is None:
-            out = t.empty(((stop - start) * F, N, T), dtype=t.float64, device=Xd.device)
-        if out.numel() == 0 or stop == start:
+            out = t.empty((n_words * F, N, T), dtype=t.float64, device=Xd.device)
+        if out.numel() == 0 or n_words == 0:
             return out
         if self._native():
-            plan = self._plan(start, stop)
+            plan = self._plan(start, stop) if indices is None else self._plan_indices(indices)
             if plan.max_dim > D:
                 raise IndexError(
                     f"a word references dimension {plan.max_dim} but the input has only {D}")

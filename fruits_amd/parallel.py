@@ -161,6 +161,9 @@ def _device_block(slc, iss, X, cache, indices, depths, per_sum):
     feats = t.zeros((X.shape[0], n_rows * per_sum), dtype=t.float64, device=Pd.device)
     if not indices:
         return feats
+    fused = slc._fused(int(Pd.shape[2]), indices=indices)
+    if fused is not None:      # the rank's share in ONE launch, no (K_r, N, T) tensor
+        return fused.run(Pd, iss.lookup_device(Pd))
     block = iss.transform_device(Pd, indices=indices)
     col = k = 0
     for i in indices:
