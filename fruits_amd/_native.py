@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libfruits_hip.so")
 FR_W_NONE, FR_W_NONTOTAL, FR_W_TOTAL = 0, 1, 2
 FR_SIEVE_NPI, FR_SIEVE_MPI, FR_SIEVE_END = 0, 1, 2
 (FR_INFO_ROWS, FR_INFO_NODES, FR_INFO_LEVELS, FR_INFO_DIMS_USED, FR_INFO_MAX_DIM,
- FR_INFO_ALPHAS, FR_INFO_GROUPS, FR_INFO_SHARED) = range(8)
+ FR_INFO_ALPHAS, FR_INFO_GROUPS, FR_INFO_SHARED, FR_INFO_STAGED_ROWS) = range(9)
 FR_E_ARG, FR_E_DIM, FR_E_HIP, FR_E_NOMEM, FR_E_LIMIT = -1, -2, -3, -4, -5
 
 EXPORTS = [
@@ -205,6 +205,16 @@ class Plan:
     @property
     def max_dim(self) -> int:
         return self.info(FR_INFO_MAX_DIM)
+
+    @property
+    def staged_rows(self) -> int:
+        return self.info(FR_INFO_STAGED_ROWS)
+
+    def fits(self, T: int) -> bool:
+        """Whether a workgroup can stage the plan's rows (input dimensions + exp
+        tables) of one time chunk in LDS."""
+        chunk = 512 if T <= 512 else 1024
+        return self.staged_rows * chunk * 8 <= 150 * 1024
 
     @property
     def dims_used(self) -> int:

@@ -253,6 +253,7 @@ int64_t fr_plan_info(const fr_plan_t *plan, int32_t what) {
     case FR_INFO_ALPHAS: return (int64_t)p.alphas.size();
     case FR_INFO_GROUPS: return p.units();
     case FR_INFO_SHARED: return p.shared ? 1 : 0;
+    case FR_INFO_STAGED_ROWS: return p.cos ? 0 : p.rows_staged();
     default: return fail(FR_E_ARG, "fr_plan_info: unknown selector");
   }
 }
@@ -369,9 +370,20 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   const bool wave_rows = !fu && team_env == 1 && groups <= 0 && p.units() >= 4 &&
                          p.semiring == fr::kSemiReals &&
                          fr::wave_rows_supported(T, p.levels, vec_ok_pre);
-  // short series: four series per workgroup, one wave each
+  // the staged rows (input dimensions + exp tables) of one time chunk must fit the LDS
+  {
+    const size_t rows_bytes = (size_t)p.rows_staged() * fr::walk_chunk_elems(T) * 8;
+    if (rows_bytes > 150 * 1024)
+      return fail(FR_E_LIMIT, w + ": the plan stages " + std::to_string(p.rows_staged()) +
+                                  " rows per time chunk (input dimensions + exp tables of " +
+                                  std::to_string(p.alphas.size()) +
+                                  " distinct alphas), more than the LDS holds - split the word list");
+  }
+  // short series: four series per workgroup, one wave each (their rows side by side in LDS)
+  const int64_t packed_chunk = T <= 128 ? 128 : (T <= 256 ? 256 : 384);
   const bool packed = !wave_rows && env_int("FRUITS_HIP_PACKED", 1) != 0 &&
-                      fr::packed_supported(T, p.levels, p.semiring);
+                      fr::packed_supported(T, p.levels, p.semiring) &&
+                      (size_t)4 * p.rows_staged() * packed_chunk * 8 <= 64 * 1024;
   // (a packed workgroup holds four units: ask for four times the units)
   const int G = wave_rows ? 4 : choose_groups(p, packed ? (N + 3) / 4 : N, groups);
   fr::GroupedProgram &gp = fr::grouped(p, G);

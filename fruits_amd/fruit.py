@@ -397,7 +397,7 @@ class FruitSlice:
             specs = [(sv._kind, 0 if type(sv) is END else sv._inc, sv._int_cut_row(T),
                       len(sv._q)) for sv in self._sieves]
             try:
-                pipe = nat.Pipeline(plan, specs, T) if len(rows) else None
+                pipe = nat.Pipeline(plan, specs, T) if len(rows) and plan.fits(T) else None
             except ValueError:
                 pipe = None
             if pipe is not None:

@@ -157,6 +157,26 @@ class ISS(Seed):
                 f"only {Xd.shape[1]}")
         if isinstance(lookup_d, str):
             lookup_d = self.lookup_device(Xd)
+        T = int(Xd.shape[2])
+        if not plan.fits(T):
+            # many distinct alphas -> more exp tables than a workgroup can stage: halves
+            if indices is None:
+                indices = tuple(range(start, stop))
+            if len(indices) == 1:
+                raise NotImplementedError(
+                    f"word {self.words[indices[0]]} alone needs {plan.staged_rows} staged rows "
+                    "(input dimensions + exp tables of its distinct alphas): more than the "
+                    "LDS of a workgroup holds")
+            if out is None:
+                out = nat.torch().empty((plan.rows, int(Xd.shape[0]), T),
+                                        dtype=nat.torch().float64, device=Xd.device)
+            half = len(indices) // 2
+            k0 = sum(self._depth(i) for i in indices[:half])
+            self.transform_device(Xd, lookup_d=lookup_d, out=out[:k0], groups=groups,
+                                  indices=indices[:half])
+            self.transform_device(Xd, lookup_d=lookup_d, out=out[k0:], groups=groups,
+                                  indices=indices[half:])
+            return out
         return plan.run(Xd, lookup_d, out=out, layout="KNT", groups=groups)
 
     # ------------------------------------------------------------------ reference API

@@ -60,6 +60,9 @@ extern "C" {
 #define FR_INFO_ALPHAS 5     /* distinct alpha values (exp tables = 2 per alpha) */
 #define FR_INFO_GROUPS 6     /* independent sub-tries (upper bound of `groups`)  */
 #define FR_INFO_SHARED 7     /* 1 if prefixes are shared                         */
+#define FR_INFO_STAGED_ROWS 8 /* rows a workgroup stages in LDS per time chunk (input dimensions +
+                                exp tables); fr_iss_run returns FR_E_LIMIT when they do not fit -
+                                the caller then splits the word list */
 
 /* sieve kinds of fr_sieve_* and the fused pipeline */
 #define FR_SIEVE_NPI 0 /* fruits/sieving/increment.py:101-129 */

@@ -8,6 +8,7 @@ U[0,1) inputs the reference's own tests use it is also element-wise rtol=1e-6.
 Observed differences are ~1e-13.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -202,6 +203,100 @@ def test_short_series_kernels(fr, monkeypatch, packed, T):
                      semiring=getattr(fr.semiring, name)())
         np.testing.assert_array_equal(iss.fit_transform(Xp),
                                       corc.iss_transform(Xp, words, "EXTENDED", semiring=name))
+
+
+def _random_word(rng, D):
+    L = int(rng.integers(1, 6))
+    letters = []
+    for _ in range(L):
+        el = ""
+        for _ in range(int(rng.integers(1, 4))):
+            d = int(rng.integers(1, D + 1))
+            el += (f"(-{d})" if d > 9 else f"-{d}") if rng.random() < 0.2 else (f"({d})" if d > 9 else str(d))
+        letters.append("[" + el + "]")
+    return "".join(letters)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FRUITS_TEST_RANDOM_CASES", "60"))))
+def test_random_differential(fr, seed):
+    """Random word lists (duplicates, negative exponents, shared prefixes), shapes, modes,
+    semirings and weightings against the C oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    D = int(rng.integers(1, 5))
+    N = int(rng.integers(1, 10))
+    T = int(rng.choice([1, 2, 3, 17, 64, 129, 256, 300, 385, 513, 700, 1025, 1500]))
+    words = [_random_word(rng, D) for _ in range(int(rng.integers(1, 13)))]
+    if rng.random() < 0.5:
+        words += [words[0], words[-1]]                       # duplicates
+    mode = "EXTENDED" if rng.random() < 0.6 else "SINGLE"
+    semiring = str(rng.choice(["Reals", "Reals", "Arctic", "Bayesian"]))
+    weighting = [None, {"kind": "Indices", "scale": 2.0},
+                 {"kind": "Indices", "scale": 2.0, "total": True},
+                 {"kind": "L1", "scale": 3.0}, {"kind": "L1", "scale": 3.0, "total": True}][
+        int(rng.integers(0, 5))]
+    X = rng.random((N, D, T)) * 0.9 + 0.3                     # away from 0: 1/x letters
+    ws = [fr.words.SimpleWord(s) for s in words]
+    alphas = None
+    if weighting is not None and rng.random() < 0.5:
+        alphas = [rng.random(len(w)).round(2).tolist() for w in ws]
+        for w, a in zip(ws, alphas):
+            w.alpha = a
+    iss = fr.ISS(ws, mode=getattr(fr.ISSMode, mode), semiring=getattr(fr.semiring, semiring)(),
+                 weighting=make_weighting(fr, weighting))
+    out = iss.fit_transform(X)
+    lookup, total = orc._weight_lookup(weighting, X, X)
+    ref = corc.iss_transform(X, words, mode, alphas, lookup, total, semiring=semiring)
+    assert out.shape == ref.shape
+    if semiring == "Reals":
+        rowwise_close(out, ref)
+    elif weighting is None:
+        np.testing.assert_array_equal(out, ref)               # max is exact
+    else:
+        np.testing.assert_allclose(out, ref, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FRUITS_TEST_RANDOM_CASES", "40"))))
+def test_random_fruit_differential(fr, seed):
+    """Random single-slice fruits (preparateurs, word lists, weightings, sieves with cuts,
+    bands and differencing orders) through Fruit.fit / transform - the fused launch where
+    the sieves allow it - against the numpy oracle."""
+    rng = np.random.default_rng(5000 + seed)
+    D = int(rng.integers(1, 4))
+    N = int(rng.integers(6, 20))
+    T = int(rng.choice([24, 65, 128, 200, 300, 400, 513, 600, 1030]))
+    Dp = 2 * D if rng.random() < 0.3 else D
+    preps = [[{"kind": "INC"}], [], [{"kind": "STD"}],
+             [{"kind": "NEW", "inner": {"kind": "INC"}}, {"kind": "STD"}]][
+        3 if Dp != D else int(rng.integers(0, 3))]
+    words = sorted({_random_word(rng, Dp).replace("-", "") for _ in range(int(rng.integers(1, 10)))})
+    semiring = str(rng.choice(["Reals", "Reals", "Arctic"]))
+    weighting = [None, None, {"kind": "Indices", "scale": 2.0}, {"kind": "L1", "scale": 2.0}][
+        int(rng.integers(0, 4))]
+    sieves = []
+    for _ in range(int(rng.integers(1, 5))):
+        kind = str(rng.choice(["NPI", "MPI", "END"]))
+        cut = sorted({int(c) for c in rng.integers(1, T, size=int(rng.integers(0, 3)))}) + [-1]
+        if kind == "END":
+            sieves.append({"kind": "END", "cut": cut})
+        else:
+            q = [[0.0, 1.0], [-1.0, 1.0], [0.5, 1.0], [0.25, 0.5, 1.0], [-1.0, 0.3, 0.7, 1.0]][
+                int(rng.integers(0, 5))]
+            sieves.append({"kind": kind, "cut": cut, "q": q, "inc": int(rng.integers(0, 3))})
+    spec = {"slices": [{"preps": preps,
+                        "iss": [{"words": words, "mode": str(rng.choice(["EXTENDED", "SINGLE"])),
+                                 "semiring": semiring, "weighting": weighting}],
+                        "sieves": sieves, "fit_sample_size": 1.0}]}
+    X = rng.standard_normal((N, D, T)).cumsum(axis=2) / np.sqrt(T)
+    fruit = build_fruit(fr, spec)
+    np.random.seed(seed)
+    fruit.fit(X)
+    got = fruit.transform(X)
+    np.random.seed(seed)
+    ref = orc.fruit_transform(spec, orc.fruit_fit(spec, X), X)
+    labels = [fruit.label(i) for i in range(fruit.nfeatures())]
+    assert got.shape == ref.shape
+    # fitted quantiles are data points of the (small) fit sample: exact ties are legitimate
+    compare_features(got, ref, labels, count_frac=0.08)
 
 
 def test_theoretical_identity(fr):
