@@ -610,6 +610,27 @@ def test_nan_to_num_epilogue(fr):
     np.testing.assert_array_equal(feats, want)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FRUITS_TEST_RANDOM_CASES", "30"))))
+def test_random_coswiss_differential(fr, seed):
+    rng = np.random.default_rng(9000 + seed)
+    D = int(rng.integers(1, 4))
+    N = int(rng.integers(1, 7))
+    T = int(rng.choice([2, 5, 33, 128, 129, 300, 385, 600, 1100]))
+    words = [_random_word(rng, D) for _ in range(int(rng.integers(1, 6)))]
+    words = [w for w in words if len(orc.parse_word(w)) <= 4] or ["[1]"]
+    freqs = [float(f) for f in rng.choice([0.05, 0.15, 0.25, 0.5, 0.75, 1.0, 2.0],
+                                          size=int(rng.integers(1, 4)), replace=False)]
+    exponent = int(rng.integers(1, 5))
+    total = bool(rng.random() < 0.5)
+    X = rng.random((N, D, T)) * 0.9 + 0.3
+    out = fr.CosWISS([fr.words.SimpleWord(s) for s in words], freqs, exponent=exponent,
+                     total_weighting=total).fit_transform(X)
+    ref = orc.coswiss_transform(X, words, freqs, exponent, total)
+    assert out.shape == ref.shape
+    scale = np.abs(ref).max(axis=2, keepdims=True)
+    assert np.all(np.abs(out - ref) <= RTOL * np.maximum(np.abs(ref), 1e-3 * scale))
+
+
 def test_coswiss_unsupported(fr):
     cw = fr.CosWISS([fr.words.SimpleWord("[1]")], [0.5], dropout=0.5)
     with pytest.raises(NotImplementedError):
