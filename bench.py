@@ -92,6 +92,18 @@ def extras(torch, fr, nat, dev):
     out["words48_single"] = {"kernel_us": t, "elements_per_s": N_SERIES * 48 * N_STEPS_T / (t * 1e-6),
                              "GBs": b_alg / (t * 1e-6) / 1e9, "frac": b_alg / (t * 1e-6) / 1e9 / HBM_PEAK_GBS}
     del buf
+    # (a') what this box sustains (SURVEY.md 8d asks for an on-box peak next to the 8 TB/s
+    # spec): a device fill and a device-to-device copy of the size of the output tensor
+    big = torch.empty((18, N_SERIES, N_STEPS_T), dtype=torch.float64, device=dev)
+    big2 = torch.empty_like(big)
+    t_fill = _event_time_us(torch, lambda: big.fill_(1.0))
+    t_copy = _event_time_us(torch, lambda: big2.copy_(big))
+    nbytes = big.numel() * 8
+    out["on_box_stream"] = {"fill_GBs": nbytes / (t_fill * 1e-6) / 1e9,
+                            "copy_read_plus_write_GBs": 2 * nbytes / (t_copy * 1e-6) / 1e9,
+                            "bytes": nbytes,
+                            "note": "torch fill_ / copy_ of a buffer of the (K,N,T) tensor's size"}
+    del big, big2
     # (b) config 3 shape: INC -> ISS(of_weight(4,2) EXTENDED, Indices) -> NPI(q=(.5,1)), END, fused
     fruit = fr.Fruit("cfg3")
     fruit.add(fr.preparation.INC)
