@@ -26,7 +26,7 @@ def units():
     out = [("kernels_misc", "kernels_misc.hip", []), ("plan", "plan.cpp", []),
            ("capi", "capi.cpp", []), ("walk_team1", "walk_inst.hip", ["-DWALK_TEAM1"])]
     for mode in (0, 1):
-        for lv in (2, 4, 8):
+        for lv in (2, 4, 6, 8):
             out.append((f"walk_m{mode}_l{lv}", "walk_inst.hip",
                         [f"-DWALK_MODE={mode}", f"-DWALK_LV={lv}"]))
     for mode in (0, 1):

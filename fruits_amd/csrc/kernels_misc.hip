@@ -380,8 +380,8 @@ bool wave_rows_supported(int64_t T, int levels, bool vec_ok) {
 }
 
 #define DECL_INST(m, l) hipError_t walk_inst_m##m##_l##l(const IssArgs &, int, hipStream_t);
-DECL_INST(0, 2) DECL_INST(0, 4) DECL_INST(0, 8)
-DECL_INST(1, 2) DECL_INST(1, 4) DECL_INST(1, 8)
+DECL_INST(0, 2) DECL_INST(0, 4) DECL_INST(0, 6) DECL_INST(0, 8)
+DECL_INST(1, 2) DECL_INST(1, 4) DECL_INST(1, 6) DECL_INST(1, 8)
 hipError_t walk_inst_team1(const IssArgs &, int, int, hipStream_t);
 hipError_t walk_packed_inst_m0(const IssArgs &, int, hipStream_t);
 hipError_t walk_packed_inst_m1(const IssArgs &, int, hipStream_t);
@@ -411,10 +411,12 @@ hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st) {
   if (a.feats) {
     if (levels <= 2) return walk_inst_m1_l2(a, chunk, st);
     if (levels <= 4) return walk_inst_m1_l4(a, chunk, st);
+    if (levels <= 6) return walk_inst_m1_l6(a, chunk, st);
     return walk_inst_m1_l8(a, chunk, st);
   }
   if (levels <= 2) return walk_inst_m0_l2(a, chunk, st);
   if (levels <= 4) return walk_inst_m0_l4(a, chunk, st);
+  if (levels <= 6) return walk_inst_m0_l6(a, chunk, st);
   return walk_inst_m0_l8(a, chunk, st);
 }
 
