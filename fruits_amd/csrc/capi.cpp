@@ -469,6 +469,9 @@ struct fr_pipeline {
   fr_plan_t *plan = nullptr;
   int64_t T = 0;
   int32_t per_sum = 0, q_stride = 0, n_ops = 0, n_ops_padded = 0;
+  int32_t n_ops_eff = 0;           // ops per row after dropping NPI ops an MPI op covers
+  std::vector<int32_t> npi_pairs;  // (npi column, mpi column) inside one iterated sum's block
+  void *d_npi_pairs = nullptr;
   std::vector<PipeSieve> sieves;
   std::vector<int32_t> mpi_cols;   // columns inside one iterated sum's block
   void *d_ops = nullptr;           // (K, n_ops_padded) FeatOp
@@ -548,6 +551,7 @@ void fr_pipeline_destroy(fr_pipeline_t *pl) {
   if (!pl) return;
   if (pl->d_ops) (void)hipFree(pl->d_ops);
   if (pl->d_mpi_cols) (void)hipFree(pl->d_mpi_cols);
+  if (pl->d_npi_pairs) (void)hipFree(pl->d_npi_pairs);
   delete pl;
 }
 
@@ -566,28 +570,75 @@ int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
   const fr::Plan &p = *pl->plan->p;
   const int K = p.K;
   std::vector<fr::FeatOp> ops((size_t)K * pl->n_ops_padded);
-  for (int k = 0; k < K; ++k) {
-    fr::FeatOp *o = ops.data() + (size_t)k * pl->n_ops_padded;
-    int i = 0;
-    for (const PipeSieve &sv : pl->sieves) {
-      const int C = (int)sv.cuts.size() - 1;
-      if (sv.kind == FR_SIEVE_END) {
-        for (int j = 0; j < C; ++j, ++i) {
-          int idx = sv.cuts[j + 1] - 1;
-          if (idx < 0) idx += (int)pl->T;  // numpy's wrap of index -1 (segment.py:213-218)
-          o[i] = fr::FeatOp{FR_SIEVE_END, k * pl->per_sum + sv.col + j, idx, 0, 0.0, 0.0};
+  // An NPI feature whose band, cut and differencing order equal an MPI feature's is that
+  // MPI op's population (experiments/fruit_reduced.py pairs NPI and MPI sieves with the
+  // same arguments, fitted on the same values): such NPI ops are dropped from the walk
+  // and filled in from the population table by mpi_finalize_kernel.  Only when the same
+  // pairs match in every row (the finalize kernel works on column patterns).
+  std::vector<int32_t> pairs;
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool merge = pass == 0;
+    bool uniform = true;
+    int n_ops_eff = 0;
+    for (int k = 0; k < K && uniform; ++k) {
+      std::vector<fr::FeatOp> row;
+      for (const PipeSieve &sv : pl->sieves) {
+        const int C = (int)sv.cuts.size() - 1;
+        if (sv.kind == FR_SIEVE_END) {
+          for (int j = 0; j < C; ++j) {
+            int idx = sv.cuts[j + 1] - 1;
+            if (idx < 0) idx += (int)pl->T;  // numpy's wrap of index -1 (segment.py:213-218)
+            row.push_back(fr::FeatOp{FR_SIEVE_END, k * pl->per_sum + sv.col + j, idx, 0, 0.0, 0.0});
+          }
+          continue;
         }
-        continue;
+        const double *q = h_quant + (size_t)k * pl->q_stride + sv.q_off;
+        for (int j = 0; j < C; ++j)
+          for (int b = 0; b + 1 < sv.Q1; ++b)
+            row.push_back(fr::FeatOp{sv.kind | (sv.inc << 8),
+                                     k * pl->per_sum + sv.col + j * (sv.Q1 - 1) + b, sv.cuts[j],
+                                     sv.cuts[j + 1], q[b], q[b + 1]});
       }
-      const double *q = h_quant + (size_t)k * pl->q_stride + sv.q_off;
-      for (int j = 0; j < C; ++j)
-        for (int b = 0; b + 1 < sv.Q1; ++b, ++i)
-          o[i] = fr::FeatOp{sv.kind | (sv.inc << 8),
-                            k * pl->per_sum + sv.col + j * (sv.Q1 - 1) + b, sv.cuts[j],
-                            sv.cuts[j + 1], q[b], q[b + 1]};
+      std::vector<int32_t> row_pairs;
+      std::vector<char> drop(row.size(), 0), used(row.size(), 0);
+      if (merge && !pl->mpi_cols.empty()) {
+        for (size_t i = 0; i < row.size(); ++i) {
+          if ((row[i].kind_inc & 0xff) != FR_SIEVE_NPI) continue;
+          for (size_t m = 0; m < row.size(); ++m) {
+            if ((row[m].kind_inc & 0xff) != FR_SIEVE_MPI || used[m]) continue;
+            if ((row[m].kind_inc >> 8) == (row[i].kind_inc >> 8) && row[m].lo == row[i].lo &&
+                row[m].hi == row[i].hi && std::memcmp(&row[m].qlo, &row[i].qlo, 8) == 0 &&
+                std::memcmp(&row[m].qhi, &row[i].qhi, 8) == 0) {
+              drop[i] = used[m] = 1;
+              row_pairs.push_back(row[i].col - k * pl->per_sum);
+              row_pairs.push_back(row[m].col - k * pl->per_sum);
+              break;
+            }
+          }
+        }
+      }
+      if (k == 0) pairs = row_pairs;
+      else if (row_pairs != pairs) uniform = false;
+      fr::FeatOp *o = ops.data() + (size_t)k * pl->n_ops_padded;
+      int i = 0;
+      for (size_t j = 0; j < row.size(); ++j)
+        if (!drop[j]) o[i++] = row[j];
+      n_ops_eff = std::max(n_ops_eff, i);
+      for (; i < pl->n_ops_padded; ++i)  // padding op: an END that never matches a chunk
+        o[i] = fr::FeatOp{FR_SIEVE_END, 0, -(1 << 30), 0, 0.0, 0.0};
     }
-    for (; i < pl->n_ops_padded; ++i)  // padding op: an END that never matches a chunk
-      o[i] = fr::FeatOp{FR_SIEVE_END, 0, -(1 << 30), 0, 0.0, 0.0};
+    pl->n_ops_eff = n_ops_eff;
+    if (uniform) break;
+    pairs.clear();  // rows disagree: second pass without merging
+  }
+  if (pairs != pl->npi_pairs || (!pairs.empty() && !pl->d_npi_pairs)) {
+    if (pl->d_npi_pairs) (void)hipFree(pl->d_npi_pairs);
+    pl->d_npi_pairs = nullptr;
+    pl->npi_pairs = pairs;
+    if (!pairs.empty()) {
+      HIP_TRY(hipMalloc(&pl->d_npi_pairs, pairs.size() * 4));
+      HIP_TRY(hipMemcpy(pl->d_npi_pairs, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
+    }
   }
   const size_t bytes = ops.size() * sizeof(fr::FeatOp);
   if (!pl->d_ops && bytes) HIP_TRY(hipMalloc(&pl->d_ops, bytes));
@@ -631,7 +682,7 @@ int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, 
   fu.ops = static_cast<const fr::FeatOp *>(pl->d_ops);
   fu.feats = d_feats;
   fu.feat_stride = feat_stride;
-  fu.n_ops = pl->n_ops;
+  fu.n_ops = pl->n_ops_eff;
   fu.n_ops_padded = pl->n_ops_padded;
   // features accumulate with atomics: clear them (memset nodes, graph-capturable)
   HIP_TRY(hipMemset2DAsync(d_feats, (size_t)feat_stride * 8, 0, (size_t)F * 8, (size_t)N, st));
@@ -649,7 +700,9 @@ int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, 
   if (!pl->mpi_cols.empty()) {
     hipError_t e = fr::launch_mpi_finalize(d_feats, fu.cnt, N, feat_stride,
                                            static_cast<const int32_t *>(pl->d_mpi_cols),
-                                           (int)pl->mpi_cols.size(), pl->per_sum, p.K, st);
+                                           (int)pl->mpi_cols.size(),
+                                           static_cast<const int32_t *>(pl->d_npi_pairs),
+                                           (int)pl->npi_pairs.size() / 2, pl->per_sum, p.K, st);
     if (e != hipSuccess) return hip_fail(e, "mpi_finalize launch");
   }
   return FR_OK;

@@ -72,8 +72,8 @@ bool wave_rows_supported(int64_t T, int levels, bool vec_ok);
 bool packed_supported(int64_t T, int levels, int semiring);
 hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st);
 hipError_t launch_mpi_finalize(double *feats, const double *cnt, int64_t N, int64_t stride,
-                               const int32_t *cols, int n_cols, int per_sum, int K,
-                               hipStream_t st);
+                               const int32_t *cols, int n_cols, const int32_t *pairs, int n_pairs,
+                               int per_sum, int K, hipStream_t st);
 hipError_t launch_exp_tables(const double *g, int64_t count, const float *alphas, int n_alpha,
                              double *aux, bool linear, hipStream_t st);
 hipError_t launch_increments(const double *X, int64_t rows, int64_t T, int64_t shift, double *out,

@@ -463,30 +463,42 @@ hipError_t launch_trig_tables(const float *freqs, int F, int64_t T, double *out,
   return hipGetLastError();
 }
 
-// MPI features: mean = sum / population (0 for an empty band, increment.py:158-161)
+// MPI features: mean = sum / population (0 for an empty band, increment.py:158-161).
+// `pairs` (npi column, mpi column inside one iterated sum's block): NPI features whose
+// band, cut and differencing order equal an MPI feature's ARE that population - the walk
+// kernel skipped them (fr_pipeline_set_quantiles) and they are filled in here.
 __global__ void mpi_finalize_kernel(double *__restrict__ feats, const double *__restrict__ cnt,
                                     int64_t N, int64_t stride, const int32_t *__restrict__ cols,
-                                    int n_cols, int per_sum, int K) {
-  const int64_t total = N * (int64_t)K * n_cols;
+                                    int n_cols, const int32_t *__restrict__ pairs, int n_pairs,
+                                    int per_sum, int K) {
+  const int64_t per_n = (int64_t)K * (n_cols + n_pairs);
+  const int64_t total = N * per_n;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t n = i / ((int64_t)K * n_cols);
-    const int64_t r = i % ((int64_t)K * n_cols);
-    const int64_t f = (r / n_cols) * per_sum + cols[r % n_cols];
-    const double c = cnt[n * stride + f];
-    feats[n * stride + f] = c > 0.0 ? feats[n * stride + f] / c : 0.0;
+    const int64_t n = i / per_n;
+    const int64_t r = i % per_n;
+    const int64_t k = r / (n_cols + n_pairs);
+    const int j = (int)(r % (n_cols + n_pairs));
+    if (j < n_cols) {
+      const int64_t f = k * per_sum + cols[j];
+      const double c = cnt[n * stride + f];
+      feats[n * stride + f] = c > 0.0 ? feats[n * stride + f] / c : 0.0;
+    } else {
+      const int p = j - n_cols;
+      feats[n * stride + k * per_sum + pairs[2 * p]] = cnt[n * stride + k * per_sum + pairs[2 * p + 1]];
+    }
   }
 }
 
 hipError_t launch_mpi_finalize(double *feats, const double *cnt, int64_t N, int64_t stride,
-                               const int32_t *cols, int n_cols, int per_sum, int K,
-                               hipStream_t st) {
-  const int64_t total = N * (int64_t)K * n_cols;
+                               const int32_t *cols, int n_cols, const int32_t *pairs, int n_pairs,
+                               int per_sum, int K, hipStream_t st) {
+  const int64_t total = N * (int64_t)K * (n_cols + n_pairs);
   if (total <= 0) return hipSuccess;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(mpi_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, st, feats, cnt, N,
-                     stride, cols, n_cols, per_sum, K);
+                     stride, cols, n_cols, pairs, n_pairs, per_sum, K);
   return hipGetLastError();
 }
 

@@ -485,7 +485,7 @@ __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w,
     }
   if (cnt == 0) return;
   if (kind == FR_SIEVE_MPI_K) {
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum = wave_last_lane(wave_inclusive_scan<0>(sum));  // wave total by DPP (no LDS permutes)
     if (cx.lane == 0) {
       unsafeAtomicAdd(&cx.feat_row[col], sum);
       unsafeAtomicAdd(&cx.cnt_row[col], (double)cnt);
