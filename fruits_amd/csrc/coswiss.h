@@ -28,24 +28,27 @@ constexpr int kCosMaxLetters = 16;  // carry slots reserved per unit (multi-chun
 template <class C>
 __device__ __forceinline__ void load_global_row(const WalkCtx &cx, const double *gp,
                                                 double (&v)[C::EP]) {
-  // gp = row + t0; the lane's elements in the layout of read_row / emit_store
+  // gp = row + t0; the lane's elements in the layout of emit_store (E consecutive
+  // elements per piece, 16-byte accesses)
   constexpr int E = C::E, P = C::P;
-  static_assert(E == 2, "written for E = 2");
+  static_assert(E % 2 == 0, "pairs of doubles");
   const int64_t T = cx.a->T;
 #pragma unroll
-  for (int h = 0; h < P; ++h) {
-    const int idx = cx.wave * C::SPAN + h * C::PIECE + cx.lane * E;
-    const int64_t t = cx.t0 + idx;
-    if (cx.a->vec_ok) {
-      vd2 q = {0.0, 0.0};
-      if (cx.full_chunk || t < T) q = *reinterpret_cast<const vd2 *>(gp + idx);
-      v[h * 2] = q.x;
-      v[h * 2 + 1] = q.y;
-    } else {
-      v[h * 2] = t < T ? gp[idx] : 0.0;
-      v[h * 2 + 1] = t + 1 < T ? gp[idx + 1] : 0.0;
+  for (int h = 0; h < P; ++h)
+#pragma unroll
+    for (int e = 0; e < E; e += 2) {
+      const int idx = cx.wave * C::SPAN + h * C::PIECE + cx.lane * E + e;
+      const int64_t t = cx.t0 + idx;
+      if (cx.a->vec_ok) {
+        vd2 q = {0.0, 0.0};
+        if (cx.full_chunk || t < T) q = *reinterpret_cast<const vd2 *>(gp + idx);
+        v[h * E + e] = q.x;
+        v[h * E + e + 1] = q.y;
+      } else {
+        v[h * E + e] = t < T ? gp[idx] : 0.0;
+        v[h * E + e + 1] = t + 1 < T ? gp[idx + 1] : 0.0;
+      }
     }
-  }
 }
 
 // v *= sin^(S-M) * cos^M by repeated multiplication, sines first (cos.py:37-40)
@@ -75,23 +78,118 @@ struct CosState {
   bool last;
 };
 
-// scan number M of one letter: A_M = cumsum(s * q_M)
+// local (per lane, per piece) inclusive sums of s * q_M for M, M+1, ... S
 template <class C, int S, int M>
-__device__ __forceinline__ void cos_scan(WalkCtx &cx, CosState<C, S> &st,
-                                         const double (&s)[C::EP], int slot,
-                                         double (&res)[C::EP]) {
-  constexpr int EP = C::EP;
-  double v[EP], c[EP];
+__device__ __forceinline__ void cos_local(const CosState<C, S> &st, const double (&s)[C::EP],
+                                          double (&l)[S + 1][C::EP]) {
+  constexpr int E = C::E, P = C::P, EP = C::EP;
+  double v[EP];
 #pragma unroll
   for (int i = 0; i < EP; ++i) v[i] = s[i];
   mul_trig<S, M, EP>(v, st.sn, st.cs);
-  block_scan<C>(cx, v, c, st.xa[M], slot + M);
-  if (st.last) {  // total weighting: result += C(S,M) * (A_M * q_M), cos.py:42-48
-    mul_trig<S, M, EP>(c, st.sn, st.cs);
 #pragma unroll
-    for (int i = 0; i < EP; ++i) res[i] += cos_binom(S, M) * c[i];
+  for (int h = 0; h < P; ++h) {
+    l[M][h * E] = v[h * E];
+#pragma unroll
+    for (int e = 1; e < E; ++e) l[M][h * E + e] = l[M][h * E + e - 1] + v[h * E + e];
   }
-  if constexpr (M < S) cos_scan<C, S, M + 1>(cx, st, s, slot, res);
+  if constexpr (M < S) cos_local<C, S, M + 1>(st, s, l);
+}
+
+// total weighting: result += C(S,m) * (A_m * q_m), cos.py:42-48 (m is an unrolled index)
+template <class C, int S, int M = 0>
+__device__ __forceinline__ void cos_add_result(const CosState<C, S> &st, int m,
+                                               double (&c)[C::EP], double (&res)[C::EP]) {
+  if (m == M) {
+    mul_trig<S, M, C::EP>(c, st.sn, st.cs);
+#pragma unroll
+    for (int i = 0; i < C::EP; ++i) res[i] += cos_binom(S, M) * c[i];
+  } else if constexpr (M < S) {
+    cos_add_result<C, S, M + 1>(st, m, c, res);
+  }
+}
+
+// The S+1 scans of one letter, A_m = cumsum(s * q_m), behind ONE workgroup barrier: local
+// sums of all of them, their wave scans interleaved (DPP latencies overlap), one LDS
+// exchange of S+1 totals per wave.  Values are formed exactly as in block_scan (walk.h).
+template <class C, int S>
+__device__ __forceinline__ void cos_scan_all(WalkCtx &cx, CosState<C, S> &st,
+                                             const double (&s)[C::EP], int slot,
+                                             double (&res)[C::EP], double *tot_all) {
+  constexpr int E = C::E, P = C::P, EP = C::EP, NW = C::NW, M = S + 1;
+  double l[M][EP];
+  double incl[M * P], excl[M * P], ptot[M * P];
+  cos_local<C, S, 0>(st, s, l);
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int h = 0; h < P; ++h) incl[m * P + h] = l[m][h * E + E - 1];
+  wave_inclusive_scan_multi<M * P, 0>(incl);
+#pragma unroll
+  for (int i = 0; i < M * P; ++i) {
+    excl[i] = wave_shift_right1<0>(incl[i]);
+    ptot[i] = wave_last_lane(incl[i]);
+  }
+  double carry_in[M], base[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    carry_in[m] = 0.0;
+    if constexpr (C::MULTI != 0) {
+      if (!cx.first_chunk) carry_in[m] = cx.carry[slot + m];
+    }
+  }
+  if constexpr (NW == 1) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      base[m] = carry_in[m];
+      if constexpr (C::MULTI != 0) {
+        double total = ptot[m * P];
+#pragma unroll
+        for (int h = 1; h < P; ++h) total += ptot[m * P + h];
+        if (cx.lane == 0) cx.carry[slot + m] = carry_in[m] + total;
+      }
+    }
+  } else {
+    static_assert(NW == 1 || NW == 4, "cross-wave prefix is written for 4 waves");
+    double *tot = tot_all + cx.buf * (NW * M);
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      double wave_total = ptot[m * P];
+#pragma unroll
+      for (int h = 1; h < P; ++h) wave_total += ptot[m * P + h];
+      if (cx.lane == 0) tot[cx.wave * M + m] = wave_total;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const double t0 = tot[m], t1 = tot[M + m], t2 = tot[2 * M + m], t3 = tot[3 * M + m];
+      const double p2 = t0 + t1, p3 = p2 + t2;
+      base[m] = cx.wave == 0 ? 0.0 : (cx.wave == 1 ? t0 : (cx.wave == 2 ? p2 : p3));
+      if constexpr (C::MULTI != 0) {
+        base[m] += carry_in[m];
+        if (cx.wave == 0 && cx.lane == 0) cx.carry[slot + m] = carry_in[m] + (p3 + t3);
+      }
+    }
+    cx.buf ^= 1;
+  }
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    double c[EP];
+    double b = base[m];
+#pragma unroll
+    for (int h = 0; h < P; ++h) {
+      const double off = b + excl[m * P + h];
+      st.xa[m][h * E] = off;
+#pragma unroll
+      for (int e = 0; e + 1 < E; ++e) {
+        c[h * E + e] = off + l[m][h * E + e];
+        st.xa[m][h * E + e + 1] = c[h * E + e];
+      }
+      c[h * E + E - 1] = b + incl[m * P + h];
+      b += ptot[m * P + h];
+    }
+    if (st.last) cos_add_result<C, S>(st, m, c, res);
+  }
 }
 
 template <class C, int S, int M>
@@ -109,7 +207,8 @@ __device__ __forceinline__ void cos_combine(const CosState<C, S> &st, double (&u
 // one (series, word, frequency) unit for one time chunk
 template <class C, int S>
 __device__ __forceinline__ void coswiss_unit(WalkCtx &cx, const double *xrow, const double *trig,
-                                             int lb, int le, bool total, int k_out) {
+                                             int lb, int le, bool total, int k_out,
+                                             double *tot_all) {
   constexpr int EP = C::EP;
   const IssArgs &a = *cx.a;
   CosState<C, S> st;
@@ -151,7 +250,7 @@ __device__ __forceinline__ void coswiss_unit(WalkCtx &cx, const double *xrow, co
       block_scan<C>(cx, s, res, resx, slot);
       break;
     }
-    cos_scan<C, S, 0>(cx, st, s, slot, res);
+    cos_scan_all<C, S>(cx, st, s, slot, res, tot_all);
   }
   if constexpr (C::MODE == 1) {
     Rec nd;
@@ -175,9 +274,10 @@ __global__ __launch_bounds__(kWalkThreads) void coswiss_kernel(const IssArgs a) 
   WalkCtx cx;
   cx.a = &a;
   cx.rows = nullptr;
-  cx.tot = lds;
-  cx.tail = lds + 2 * C::NW;
-  cx.carry = lds + 4 * C::NW;
+  double *tot_all = lds;  // [2][NW][S+1] wave totals of cos_scan_all
+  cx.tot = lds + 2 * C::NW * (S + 1);
+  cx.tail = cx.tot + 2 * C::NW;
+  cx.carry = cx.tail + 2 * C::NW;
   cx.tid = tid;
   cx.lane = tid & 63;
   cx.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -203,7 +303,7 @@ __global__ __launch_bounds__(kWalkThreads) void coswiss_kernel(const IssArgs a) 
         cx.cnt_row = a.cnt + n * a.feat_stride;
       }
       coswiss_unit<C, S>(cx, a.X + n * a.D * a.T + t0, a.aux + (int64_t)f * 2 * a.T + t0, lb, le,
-                         a.cw_total != 0, j);
+                         a.cw_total != 0, j, tot_all);
     }
   }
 }
@@ -244,13 +344,13 @@ __global__ __launch_bounds__(kWalkThreads) void coswiss_packed_kernel(const IssA
       cx.cnt_row = a.cnt + n * a.feat_stride;
     }
     coswiss_unit<C, S>(cx, a.X + n * a.D * a.T, a.aux + (int64_t)f * 2 * a.T, lb, le,
-                       a.cw_total != 0, j);
+                       a.cw_total != 0, j, nullptr);
   }
 }
 
 template <int P, bool VEC, int MODE, int S>
 static hipError_t launch_coswiss_packed_cfg(const IssArgs &a, hipStream_t st) {
-  using C = WalkCfg<2, P, 1, 0, VEC, false, 1, MODE, 0>;
+  using C = WalkCfg<(P == 2 ? 4 : 2), (P == 2 ? 1 : P), 1, 0, VEC, false, 1, MODE, 0>;
   const int64_t units = a.N * a.cw_W * a.cw_F;
   static int per_cu = 0;
   if (per_cu == 0) {
@@ -271,8 +371,12 @@ static hipError_t launch_coswiss_packed_cfg(const IssArgs &a, hipStream_t st) {
 
 template <int P, int MULTI, bool VEC, int MODE, int S>
 static hipError_t launch_coswiss_cfg(const IssArgs &a, hipStream_t st) {
-  using C = WalkCfg<2, P, 1, MULTI, VEC, false, 4, MODE, 0>;
-  const size_t lds = (4 * C::NW + (kCosMaxLetters * (S + 1) + 8)) * sizeof(double);
+  // 1024-element chunks: 4 consecutive elements per lane in ONE piece - half the wave-scan
+  // chains of the walk kernel's 2 x 2 layout (this kernel is bound by vector issue, and
+  // the S+1 scans of a letter already overlap their DPP latencies)
+  using C = WalkCfg<(P == 2 ? 4 : 2), (P == 2 ? 1 : P), 1, MULTI, VEC, false, 4, MODE, 0>;
+  const size_t lds = (2 * C::NW * (S + 1) + 4 * C::NW + (kCosMaxLetters * (S + 1) + 8)) *
+                     sizeof(double);
   const int64_t units = a.N * a.cw_W * a.cw_F;
   static int per_cu = 0;
   if (per_cu == 0) {

@@ -19,16 +19,27 @@ hipError_t walk_inst_team1(const IssArgs &a, int levels, int chunk, hipStream_t 
   return chunk == 512 ? team1_p<4>(a, levels, st) : team1_p<8>(a, levels, st);
 }
 #else
+// Fused kernels (vector-issue bound by the sieve epilogue) use 4 consecutive elements per
+// lane in one piece for 1024-element chunks: half the wave-scan chains of the 2 x 2 layout
+// the materialising kernels interleave to hide DPP latency.
+#if WALK_MODE == 1
+#define WALK_E(P) ((P) == 2 ? 4 : 2)
+#define WALK_P(P) ((P) == 2 ? 1 : (P))
+#else
+#define WALK_E(P) 2
+#define WALK_P(P) (P)
+#endif
 template <int P, int MULTI, bool VEC>
 static hipError_t inst_w(const IssArgs &a, hipStream_t st) {
+  constexpr int E = WALK_E(P), PP = WALK_P(P);
   if (a.semiring == kSemiArctic)
-    return a.aux ? launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, true, 4, WALK_MODE, 1>(a, st)
-                 : launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, false, 4, WALK_MODE, 1>(a, st);
+    return a.aux ? launch_walk_cfg<E, PP, WALK_LV, MULTI, VEC, true, 4, WALK_MODE, 1>(a, st)
+                 : launch_walk_cfg<E, PP, WALK_LV, MULTI, VEC, false, 4, WALK_MODE, 1>(a, st);
   if (a.semiring == kSemiBayesian)
-    return a.aux ? launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, true, 4, WALK_MODE, 2>(a, st)
-                 : launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, false, 4, WALK_MODE, 2>(a, st);
-  return a.aux ? launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, true, 4, WALK_MODE>(a, st)
-               : launch_walk_cfg<2, P, WALK_LV, MULTI, VEC, false, 4, WALK_MODE>(a, st);
+    return a.aux ? launch_walk_cfg<E, PP, WALK_LV, MULTI, VEC, true, 4, WALK_MODE, 2>(a, st)
+                 : launch_walk_cfg<E, PP, WALK_LV, MULTI, VEC, false, 4, WALK_MODE, 2>(a, st);
+  return a.aux ? launch_walk_cfg<E, PP, WALK_LV, MULTI, VEC, true, 4, WALK_MODE>(a, st)
+               : launch_walk_cfg<E, PP, WALK_LV, MULTI, VEC, false, 4, WALK_MODE>(a, st);
 }
 template <int P>
 static hipError_t inst_p(const IssArgs &a, hipStream_t st) {
