@@ -634,6 +634,53 @@ def test_random_coswiss_differential(fr, seed):
     assert np.all(np.abs(out - ref) <= RTOL * np.maximum(np.abs(ref), 1e-3 * scale))
 
 
+def test_entry_points_capture_into_a_hip_graph(fr):
+    """fr_iss_run and fr_pipeline_run only enqueue work: captured into a
+    HIP graph and replayed they reproduce the eager results - cooperative, wave-per-series
+    and CosWISS kernels, materialising and fused."""
+    import torch
+    from fruits_amd import _native as nat
+    rng = np.random.default_rng(12)
+    for T in (100, 1024):
+        X = rng.standard_normal((32, 2, T)).cumsum(axis=2) / np.sqrt(T)
+        Xd = nat.to_device(X)
+        iss = fr.ISS(fr.words.of_weight(3, 2), mode=fr.ISSMode.EXTENDED,
+                     weighting=fr.iss.weighting.Indices())
+        plan = iss._plan(0, len(iss.words))
+        lk = iss.lookup_device(Xd)
+        out = torch.empty((plan.rows, 32, T), dtype=torch.float64, device=Xd.device)
+        work = torch.empty(max(plan.workspace_bytes(32, T, 1), 1), dtype=torch.uint8, device=Xd.device)
+        eager = plan.run(Xd, lk, work=work).clone()
+        cw = fr.CosWISS(fr.words.of_weight(2, 2), [0.25, 0.5], exponent=2)
+        cplan = cw._plan(0, len(cw.words))
+        cout = torch.empty((cplan.rows, 32, T), dtype=torch.float64, device=Xd.device)
+        cwork = torch.empty(max(cplan.workspace_bytes(32, T, 0), 1), dtype=torch.uint8, device=Xd.device)
+        ceager = cplan.run(Xd, None, work=cwork).clone()
+        fruit = fr.Fruit()
+        fruit.add(iss.copy(), fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.MPI(q=(0.5, 1.0)), fr.sieving.END)
+        fruit.fit(X)
+        slc = fruit.get_slice()
+        pipe = slc._fused(T)
+        assert pipe is not None
+        feats = torch.empty((32, pipe.n_features), dtype=torch.float64, device=Xd.device)
+        pwork = torch.empty(int(nat.lib().fr_pipeline_workspace_bytes(pipe._h, 32, 1)) + 1,
+                            dtype=torch.uint8, device=Xd.device)
+        slc._attach(fr.cache.SharedSeedCache(X))
+        feager = pipe.run(Xd, lk, work=pwork).clone()
+        torch.cuda.synchronize()
+        g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                plan.run(Xd, lk, out=out, work=work)
+                cplan.run(Xd, None, out=cout, work=cwork)
+                pipe.run(Xd, lk, feats=feats, work=pwork)
+        out.zero_(); cout.zero_(); feats.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager) and torch.equal(cout, ceager)
+        np.testing.assert_allclose(feats.cpu().numpy(), feager.cpu().numpy(), rtol=1e-12)
+
+
 def test_coswiss_unsupported(fr):
     cw = fr.CosWISS([fr.words.SimpleWord("[1]")], [0.5], dropout=0.5)
     with pytest.raises(NotImplementedError):
