@@ -65,6 +65,15 @@ __device__ __forceinline__ void mul_trig(double (&v)[EP], const double (&sn)[EP]
     for (int i = 0; i < EP; ++i) v[i] = v[i] * cs[i];
 }
 
+template <int S, int M, int EP>
+__device__ __forceinline__ void build_q(double (&q)[S + 1][EP], const double (&sn)[EP],
+                                        const double (&cs)[EP]) {
+#pragma unroll
+  for (int i = 0; i < EP; ++i) q[M][i] = 1.0;
+  mul_trig<S, M, EP>(q[M], sn, cs);
+  if constexpr (M < S) build_q<S, M + 1, EP>(q, sn, cs);
+}
+
 constexpr double cos_binom(int s, int m) {
   double c = 1.0;
   for (int k = 0; k < m; ++k) c = c * (s - k) / (k + 1);
@@ -74,7 +83,7 @@ constexpr double cos_binom(int s, int m) {
 template <class C, int S>
 struct CosState {
   double xa[S + 1][C::EP];  // exclusive prefixes of the previous letter's S+1 scans
-  double sn[C::EP], cs[C::EP];
+  double q[S + 1][C::EP];   // q_m = sin^(S-m) cos^m, formed once per unit
   bool last;
 };
 
@@ -85,8 +94,7 @@ __device__ __forceinline__ void cos_local(const CosState<C, S> &st, const double
   constexpr int E = C::E, P = C::P, EP = C::EP;
   double v[EP];
 #pragma unroll
-  for (int i = 0; i < EP; ++i) v[i] = s[i];
-  mul_trig<S, M, EP>(v, st.sn, st.cs);
+  for (int i = 0; i < EP; ++i) v[i] = s[i] * st.q[M][i];
 #pragma unroll
   for (int h = 0; h < P; ++h) {
     l[M][h * E] = v[h * E];
@@ -101,9 +109,8 @@ template <class C, int S, int M = 0>
 __device__ __forceinline__ void cos_add_result(const CosState<C, S> &st, int m,
                                                double (&c)[C::EP], double (&res)[C::EP]) {
   if (m == M) {
-    mul_trig<S, M, C::EP>(c, st.sn, st.cs);
 #pragma unroll
-    for (int i = 0; i < C::EP; ++i) res[i] += cos_binom(S, M) * c[i];
+    for (int i = 0; i < C::EP; ++i) res[i] += cos_binom(S, M) * (c[i] * st.q[M][i]);
   } else if constexpr (M < S) {
     cos_add_result<C, S, M + 1>(st, m, c, res);
   }
@@ -197,8 +204,7 @@ __device__ __forceinline__ void cos_combine(const CosState<C, S> &st, double (&u
   constexpr int EP = C::EP;
   double v[EP];
 #pragma unroll
-  for (int i = 0; i < EP; ++i) v[i] = st.xa[M][i];
-  mul_trig<S, M, EP>(v, st.sn, st.cs);
+  for (int i = 0; i < EP; ++i) v[i] = st.xa[M][i] * st.q[M][i];
 #pragma unroll
   for (int i = 0; i < EP; ++i) u[i] += cos_binom(S, M) * v[i];
   if constexpr (M < S) cos_combine<C, S, M + 1>(st, u);
@@ -213,8 +219,12 @@ __device__ __forceinline__ void coswiss_unit(WalkCtx &cx, const double *xrow, co
   const IssArgs &a = *cx.a;
   CosState<C, S> st;
   double res[EP], resx[EP];
-  load_global_row<C>(cx, trig, st.sn);
-  load_global_row<C>(cx, trig + a.T, st.cs);
+  {
+    double sn[EP], cs[EP];
+    load_global_row<C>(cx, trig, sn);
+    load_global_row<C>(cx, trig + a.T, cs);
+    build_q<S, 0, EP>(st.q, sn, cs);
+  }
   Ops2 pre;
   if constexpr (C::MODE == 1) pre = load_ops2(a, k_out, 0);
 #pragma unroll
