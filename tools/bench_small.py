@@ -24,3 +24,16 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(20): fruit.transform(X)
 pr.disable()
 pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+
+# a whole experiment fruit on a UCR-sized problem
+sys.path.insert(0, "tools")
+import bench_pipeline as bp
+Xs = np.random.default_rng(1).standard_normal((300, 1, 150)).cumsum(axis=2)
+red = bp.build_reduced()
+np.random.seed(0)
+print("fruit_reduced (300,1,150) fit:", tm(lambda: red.fit(Xs), 5))
+print("fruit_reduced (300,1,150) transform:", tm(lambda: red.transform(Xs)))
+pr = cProfile.Profile(); pr.enable()
+for _ in range(10): red.transform(Xs)
+pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(12)
