@@ -302,6 +302,23 @@ def test_random_fruit_differential(fr, seed, monkeypatch):
     compare_features(got, ref, labels, count_frac=0.08)
 
 
+def test_plateaus_and_custom_weightings(fr):
+    # host-built lookups (fruits/iss/weighting.py:41-66,213-256) consumed by the same kernel
+    rng = np.random.default_rng(21)
+    X = rng.random((5, 2, 90))
+    words = ["[1][2]", "[12][2][1]", "[2]"]
+    for weighting in (fr.iss.weighting.Plateaus(4, scale=3.0),
+                      fr.iss.weighting.Plateaus(3, reverse=True, scale=2.0, total=True),
+                      fr.iss.weighting.Custom(lambda Z: np.cumsum(np.abs(Z[:, 0, :]), axis=1) / 30.0),
+                      fr.iss.weighting.Custom(lambda Z: Z[:, 1, :] * 2.0, total=True)):
+        iss = fr.ISS([fr.words.SimpleWord(s) for s in words], mode=fr.ISSMode.EXTENDED,
+                     weighting=weighting)
+        out = iss.fit_transform(X)
+        lookup = np.asarray(weighting.get_lookup(X), dtype=np.float64)
+        ref = corc.iss_transform(X, words, "EXTENDED", None, lookup, weighting.total)
+        rowwise_close(out, ref)
+
+
 def test_theoretical_identity(fr):
     # reference tests/signature/test_simple.py:44-51: standardised x => <[1][1]>_T = -T/2
     X = np.random.default_rng(5).random((25, 1, 100))
