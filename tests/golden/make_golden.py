@@ -377,6 +377,24 @@ put("U_4_1_64_const", Xc)
 l1_case("const_row", "U_4_1_64_const", scale=7.0)
 
 
+# L2 path length and Plateaus staircases (same kernel consumes them; host / device lookups)
+manifest["lookups"] = []
+
+
+def lookup_case(name, x_key, kind, **kw):
+    X = arrays[x_key]
+    wt = getattr(fruits.iss.weighting, kind)(**kw)
+    wt._cache = fruits.cache.SharedSeedCache(X)
+    manifest["lookups"].append({"name": name, "x": x_key, "kind": kind, "kw": kw,
+                                "out": put(f"lookup/{name}", wt.get_lookup(X))})
+
+
+lookup_case("l2_default", "U_6_3_40", "L2")
+lookup_case("l2_relative", "G_5_3_37", "L2", relative=True, scale=1)
+lookup_case("plateaus4", "U_6_3_40", "Plateaus", n=4)
+lookup_case("plateaus3_rev", "G_5_3_37", "Plateaus", n=3, reverse=True, scale=2.0)
+lookup_case("plateaus7", "U_7_2_129", "Plateaus", n=7, scale=1.0)
+
 # --------------------------------------------------------------------------
 # INC
 # --------------------------------------------------------------------------

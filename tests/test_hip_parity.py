@@ -442,6 +442,18 @@ def test_l1_lookup(fr, case):
     np.testing.assert_allclose(wt.get_lookup(X), G[case["out"]], rtol=RTOL, atol=1e-12)
 
 
+@pytest.mark.parametrize("case", G.manifest.get("lookups", []), ids=lambda c: c["name"])
+def test_other_lookups(fr, case):
+    wt = getattr(fr.iss.weighting, case["kind"])(**case["kw"])
+    X = G[case["x"]]
+    wt._cache = fr.cache.SharedSeedCache(X)
+    np.testing.assert_allclose(wt.get_lookup(X), G[case["out"]], rtol=RTOL, atol=1e-12)
+    from fruits_amd import _native as nat
+    dev = nat.to_host(wt.lookup_device(nat.to_device(X)))
+    np.testing.assert_allclose(np.broadcast_to(dev, G[case["out"]].shape), G[case["out"]],
+                               rtol=RTOL, atol=1e-12)
+
+
 @pytest.mark.parametrize("case", G.cases("inc"), ids=lambda c: c["name"])
 def test_inc(fr, case):
     inc = fr.preparation.INC(**case["kw"])

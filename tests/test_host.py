@@ -231,6 +231,10 @@ def test_weighting_rows_match_oracle():
         fr.iss.weighting.Plateaus(1)
     p = fr.iss.weighting.Plateaus(4, scale=1.0)._row(16)
     assert p[0] == 0 and p[-1] == 1 and len(set(np.round(p, 12))) == 4
+    for case in M.get("lookups", []):
+        if case["kind"] == "Plateaus":         # pinned against the reference's staircases
+            row = fr.iss.weighting.Plateaus(**case["kw"])._row(G[case["x"]].shape[2])
+            np.testing.assert_allclose(row, G[case["out"]][0], rtol=1e-15, atol=0)
 
 
 def test_preparateurs_and_sieves_bookkeeping():

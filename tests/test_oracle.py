@@ -125,3 +125,11 @@ def test_coswiss(case):
         got = orc.coswiss_weightings(len(orc.parse_word(s)), kw.get("exponent", 2),
                                      kw.get("total_weighting", False))
         assert got.tolist() == w
+
+
+@pytest.mark.parametrize("case", [c for c in G.manifest.get("lookups", []) if c["kind"] == "L2"],
+                         ids=lambda c: c["name"])
+def test_l2_lookup(case):
+    kw = case["kw"]
+    out = orc.lookup_l2(G[case["x"]], kw.get("relative", False), kw.get("scale", 50))
+    np.testing.assert_allclose(out, G[case["out"]], rtol=1e-12, atol=1e-14)
