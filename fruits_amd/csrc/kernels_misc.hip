@@ -65,45 +65,30 @@ __global__ __launch_bounds__(256) void pathlen_lookup_kernel(const double *__res
                                                               int64_t D, int64_t T, int norm,
                                                               int relative, double scale,
                                                               double *__restrict__ out) {
-  __shared__ double sm_tot[2][4];
   __shared__ double sm_red[4];
+  __shared__ double sm_last;
   const int64_t n = blockIdx.x;
   const double *x = X + n * D * T;  // dimension 0 only
   double *o = out + n * T;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double carry = 0.0;
-  int buf = 0;
-  for (int64_t t0 = 0; t0 < T; t0 += 512) {
-    double s[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int64_t t = t0 + tid * 2 + e;
-      double d = 0.0;
-      if (t < T && t >= 1) d = x[t] - x[t - 1];
-      s[e] = (norm == 1) ? fabs(d) : d * d;
-      if (t >= T) s[e] = 0.0;
+  const int tid = threadIdx.x;
+  // The cumulative path length is summed SEQUENTIALLY (one lane per series) like
+  // np.cumsum in the reference (fruits/cache.py:25-40): the lookup is then bit-identical
+  // to the reference's, and with it every max-plus (Arctic) result - a running maximum
+  // has long plateaus, and a fitted quantile that equals a plateau value is an exact tie
+  // for all of its elements (a 1-ulp difference in g would move the whole plateau to the
+  // other band).  O(T) dependent adds per series, all series in parallel: ~20 us at T = 4096.
+  if (tid == 0) {
+    double acc = 0.0;
+    for (int64_t t = 0; t < T; ++t) {
+      const double d = t >= 1 ? x[t] - x[t - 1] : 0.0;
+      acc += (norm == 1) ? fabs(d) : d * d;
+      o[t] = acc;
     }
-    const double l1 = s[0] + s[1];
-    const double incl = wave_inclusive_scan(l1);
-    const double excl = wave_shift_right1(incl);
-    if (lane == 63) sm_tot[buf][wave] = incl;
-    __syncthreads();
-    double run = carry, base = 0.0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      if (w == wave) base = run;
-      run += sm_tot[buf][w];
-    }
-    carry = run;
-    buf ^= 1;
-    const double off = base + excl;
-    const int64_t t = t0 + tid * 2;
-    if (t < T) o[t] = off + s[0];
-    if (t + 1 < T) o[t + 1] = off + l1;
+    sm_last = acc;
   }
-  if (relative == 2) return;  // raw cumulative path length (SharedSeedCache entry)
   __syncthreads();
-  // every thread re-reads only elements it wrote itself (same t -> same thread)
+  const double carry = sm_last;
+  if (relative == 2) return;  // raw cumulative path length (SharedSeedCache entry)
   const double last = carry;
   double mn = INFINITY, mx = -INFINITY;
   for (int64_t t0 = 0; t0 < T; t0 += 512)
