@@ -407,15 +407,19 @@ def increments(Xd, shift: int, head_src=None, head: int = 0, out=None):
     return out
 
 
-def pathlen_lookup(Xd, norm: int = 1, relative: int = 0, scale: float = 50.0):
+FR_LOOKUP_FAST = 16
+
+
+def pathlen_lookup(Xd, norm: int = 1, relative: int = 0, scale: float = 50.0,
+                   exact: bool = True):
     """relative: 0 plain, 1 divide by (last + 1e-5) first, 2 = raw cumulative
     path length without normalisation (the SharedSeedCache entry)."""
     t = torch()
     N, D, T = Xd.shape
     out = t.empty((N, T), dtype=t.float64, device=Xd.device)
     rc = lib().fr_pathlen_lookup(dptr(Xd), C.c_int64(N), C.c_int64(D), C.c_int64(T),
-                                 C.c_int32(norm), C.c_int32(relative), C.c_double(scale),
-                                 dptr(out), stream_ptr())
+                                 C.c_int32(norm | (0 if exact else FR_LOOKUP_FAST)),
+                                 C.c_int32(relative), C.c_double(scale), dptr(out), stream_ptr())
     check(rc, "fr_pathlen_lookup")
     return out
 

@@ -765,11 +765,13 @@ int fr_increments(const double *d_X, int64_t rows, int64_t T, int64_t shift, dou
 
 int fr_pathlen_lookup(const double *d_X, int64_t N, int64_t D, int64_t T, int32_t norm,
                       int32_t relative, double scale, double *d_out, void *stream) {
+  const int exact = (norm & FR_LOOKUP_FAST) ? 0 : 1;
+  norm &= ~FR_LOOKUP_FAST;
   if (N < 0 || D < 1 || T < 0 || (norm != 1 && norm != 2))
     return fail(FR_E_ARG, "fr_pathlen_lookup: bad argument");
   if (N == 0 || T == 0) return FR_OK;
   if (!d_X || !d_out) return fail(FR_E_ARG, "fr_pathlen_lookup: null device pointer");
-  hipError_t e = fr::launch_pathlen_lookup(d_X, N, D, T, norm, relative, scale, d_out,
+  hipError_t e = fr::launch_pathlen_lookup(d_X, N, D, T, norm, relative, scale, exact, d_out,
                                            (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "pathlen_lookup launch");
   return FR_OK;

@@ -79,7 +79,8 @@ hipError_t launch_exp_tables(const double *g, int64_t count, const float *alphas
 hipError_t launch_increments(const double *X, int64_t rows, int64_t T, int64_t shift, double *out,
                              const double *head_src, int64_t head, hipStream_t st);
 hipError_t launch_pathlen_lookup(const double *X, int64_t N, int64_t D, int64_t T, int norm,
-                                 int relative, double scale, double *out, hipStream_t st);
+                                 int relative, double scale, int exact, double *out,
+                                 hipStream_t st);
 hipError_t launch_sieve(int kind, const double *A, int64_t N, int64_t T, int64_t a_stride, int inc,
                         const int64_t *cuts, int64_t cut_rows, int C1, const double *q, int Q1,
                         double *out, int64_t out_stride, hipStream_t st);

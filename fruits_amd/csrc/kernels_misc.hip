@@ -64,9 +64,11 @@ __device__ __forceinline__ double block_reduce_minmax(double v, bool is_max, dou
 __global__ __launch_bounds__(256) void pathlen_lookup_kernel(const double *__restrict__ X,
                                                               int64_t D, int64_t T, int norm,
                                                               int relative, double scale,
+                                                              int exact,
                                                               double *__restrict__ out) {
   __shared__ double sm_red[4];
   __shared__ double sm_last;
+  __shared__ double sm_tot[2][4];
   const int64_t n = blockIdx.x;
   const double *x = X + n * D * T;  // dimension 0 only
   double *o = out + n * T;
@@ -77,16 +79,79 @@ __global__ __launch_bounds__(256) void pathlen_lookup_kernel(const double *__res
   // has long plateaus, and a fitted quantile that equals a plateau value is an exact tie
   // for all of its elements (a 1-ulp difference in g would move the whole plateau to the
   // other band).  O(T) dependent adds per series, all series in parallel: ~20 us at T = 4096.
-  if (tid == 0) {
-    double acc = 0.0;
-    for (int64_t t = 0; t < T; ++t) {
-      const double d = t >= 1 ? x[t] - x[t - 1] : 0.0;
-      acc += (norm == 1) ? fabs(d) : d * d;
-      o[t] = acc;
+  // (the summands are formed and the results stored by the whole workgroup through LDS;
+  // only the adds themselves are serial)
+  // exact == 0 (Reals plans, whose sums are re-associated anyway): a parallel scan.
+  constexpr int kSeg = 4096;
+  __shared__ double seg[kSeg];
+  double acc = 0.0;  // meaningful in thread 0 only
+  if (!exact) {
+    const int lane = tid & 63, wave = tid >> 6;
+    double run_carry = 0.0;
+    int buf = 0;
+    for (int64_t t0 = 0; t0 < T; t0 += 512) {
+      double s2[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int64_t t = t0 + tid * 2 + e;
+        double d = 0.0;
+        if (t < T && t >= 1) d = x[t] - x[t - 1];
+        s2[e] = (norm == 1) ? fabs(d) : d * d;
+        if (t >= T) s2[e] = 0.0;
+      }
+      const double l1 = s2[0] + s2[1];
+      const double incl = wave_inclusive_scan(l1);
+      const double excl = wave_shift_right1(incl);
+      if (lane == 63) sm_tot[buf][wave] = incl;
+      __syncthreads();
+      double run = run_carry, base = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        if (w == wave) base = run;
+        run += sm_tot[buf][w];
+      }
+      run_carry = run;
+      buf ^= 1;
+      const double off = base + excl;
+      const int64_t t = t0 + tid * 2;
+      if (t < T) o[t] = off + s2[0];
+      if (t + 1 < T) o[t + 1] = off + l1;
     }
-    sm_last = acc;
+    acc = run_carry;  // the same value in every thread
   }
-  __syncthreads();
+  for (int64_t c0 = 0; exact && c0 < T; c0 += kSeg) {
+    const int len = (int)((T - c0) < kSeg ? (T - c0) : kSeg);
+    for (int i = tid; i < len; i += blockDim.x) {
+      const int64_t t = c0 + i;
+      const double d = t >= 1 ? x[t] - x[t - 1] : 0.0;
+      seg[i] = (norm == 1) ? fabs(d) : d * d;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int i = 0;
+      for (; i + 8 <= len; i += 8) {  // 8 LDS reads in flight, then the 8 dependent adds
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = seg[i + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          acc += v[j];
+          v[j] = acc;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) seg[i + j] = v[j];
+      }
+      for (; i < len; ++i) {
+        acc += seg[i];
+        seg[i] = acc;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < len; i += blockDim.x) o[c0 + i] = seg[i];
+    __syncthreads();
+  }
+  if (tid == 0) sm_last = acc;
+  __syncthreads();  // (also: every thread re-reads elements other threads wrote)
   const double carry = sm_last;
   if (relative == 2) return;  // raw cumulative path length (SharedSeedCache entry)
   const double last = carry;
@@ -509,10 +574,11 @@ hipError_t launch_increments(const double *X, int64_t rows, int64_t T, int64_t s
 }
 
 hipError_t launch_pathlen_lookup(const double *X, int64_t N, int64_t D, int64_t T, int norm,
-                                 int relative, double scale, double *out, hipStream_t st) {
+                                 int relative, double scale, int exact, double *out,
+                                 hipStream_t st) {
   if (N <= 0 || T <= 0) return hipSuccess;
   hipLaunchKernelGGL(pathlen_lookup_kernel, dim3((unsigned)N), dim3(256), 0, st, X, D, T, norm,
-                     relative, scale, out);
+                     relative, scale, exact, out);
   return hipGetLastError();
 }
 

@@ -119,7 +119,8 @@ class ISS(Seed):
         (fruits/iss/semiring.py:185-199)."""
         if self.weighting is None:
             return None
-        lk = self.weighting.lookup_device(Xd)
+        # (max-plus results meet fitted quantiles in exact ties: bit-exact lookup there)
+        lk = self.weighting.lookup_device(Xd, exact=not isinstance(self.semiring, Reals))
         n = int(Xd.shape[0])
         if lk.shape[0] != 1:
             if lk.shape[0] < n:

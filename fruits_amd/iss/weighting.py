@@ -44,8 +44,10 @@ class Weighting(ABC):
     def get_lookup(self, X: np.ndarray) -> np.ndarray:
         ...
 
-    def lookup_device(self, Xd):
-        """Device lookup for the prepared device input ``Xd`` (N, D, T)."""
+    def lookup_device(self, Xd, exact: bool = True):
+        """Device lookup for the prepared device input ``Xd`` (N, D, T).  ``exact``:
+        bit-identical to the reference (needed where exact ties matter: max-plus
+        results); False allows re-associated sums."""
         host = self.get_lookup(nat.to_host(Xd))
         return nat.to_device(np.asarray(host, dtype=np.float64))
 
@@ -58,7 +60,7 @@ class _SeriesIndependent(Weighting):
         n, _, T = X.shape
         return np.ones((n, T)) * self._row(T)
 
-    def lookup_device(self, Xd):
+    def lookup_device(self, Xd, exact: bool = True):
         row = np.asarray(self._row(int(Xd.shape[2])), dtype=np.float64)
         return nat.to_device(row[np.newaxis, :])
 
@@ -120,7 +122,7 @@ class _PathLength(Weighting):
         self._transform = transform
         self._scale = scale
 
-    def lookup_device(self, Xd):
+    def lookup_device(self, Xd, exact: bool = True):
         if self._transform is not None:
             # an arbitrary Python callable cannot run on the device: apply it on
             # the host to the raw path length, then normalise
@@ -131,7 +133,7 @@ class _PathLength(Weighting):
             return nat.to_device(np.asarray(_minmax_rows(r) * self._scale, dtype=np.float64))
         src = Xd if self._on_prepared else self._cache.input_device()
         return nat.pathlen_lookup(src, self._norm, 1 if self._relative else 0,
-                                  float(self._scale))
+                                  float(self._scale), exact=exact)
 
     def get_lookup(self, X: np.ndarray) -> np.ndarray:
         return nat.to_host(self.lookup_device(nat.to_device(X)))

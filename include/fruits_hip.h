@@ -165,7 +165,11 @@ int fr_increments(const double *d_X, int64_t rows, int64_t T, int64_t shift,
  * (last + 1e-5) first (relative = 1); constant rows give 0.  relative = 2 returns
  * the raw cumulative path length (the SharedSeedCache entry, cache.py:108-112).
  * d_X is (N, D, T), only dimension 0 is read (cache.py:27).
- * norm: 1 = L1 (abs), 2 = L2 (square). */
+ * norm: 1 = L1 (abs), 2 = L2 (square).  The path length is summed sequentially like
+ * np.cumsum, so the lookup is bit-identical to the reference's (it decides exact ties of
+ * max-plus results against fitted quantiles); norm | FR_LOOKUP_FAST uses a parallel scan
+ * instead (re-associated sums, ~1e-16 relative) - enough for Reals plans. */
+#define FR_LOOKUP_FAST 16
 int fr_pathlen_lookup(const double *d_X, int64_t N, int64_t D, int64_t T,
                       int32_t norm, int32_t relative, double scale,
                       double *d_out /* (N,T) */, void *stream);
