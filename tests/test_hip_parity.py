@@ -221,6 +221,9 @@ def test_random_differential(fr, seed):
     D = int(rng.integers(1, 5))
     N = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 16, 24, 40]))   # multiples of 8: XCD mapping
     T = int(rng.choice([1, 2, 3, 17, 64, 129, 256, 300, 385, 513, 700, 1025, 1500]))
+    if os.environ.get("FRUITS_TEST_RANDOM_BIG"):          # soak runs: long series, many of them
+        T = int(rng.choice([2049, 3000, 4097, 5000, 1024, 384]))
+        N = int(rng.choice([33, 100, 257, 300]))
     words = [_random_word(rng, D) for _ in range(int(rng.integers(1, 13)))]
     if rng.random() < 0.5:
         words += [words[0], words[-1]]                       # duplicates
