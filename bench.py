@@ -9,10 +9,23 @@ line (rank 0).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N > 1 is launched by the driver through torch.distributed.run, one rank per GPU;
-every rank processes its own batch (the path is independent per series, so it
-shards with no data-path collective: weak scaling), the timed region is
-bracketed by barrier + synchronize and the slowest rank's time counts.
+N > 1 is launched by the driver through torch.distributed.run, one rank per GPU.
+Two things are then measured:
+
+* the headline ``value``: every rank processes its own batch of the workload above
+  (the path is independent per series: weak scaling, no data-path collective), the
+  timed region is bracketed by barrier + synchronize, the slowest rank counts;
+* ``word_sharded_config4``: north_star's multi-GPU split - BASELINE configs[3], the
+  ``fruit_general`` word set ``of_weight(6, 2)`` + ``Indices`` on ``(8192, 3, 1024)``
+  with the WORD LIST sharded over the ranks (``fruits_amd.parallel``): every rank
+  holds the whole batch, computes the feature columns of its sub-tries in one fused
+  launch, and one RCCL all-gather (+ a column permutation) assembles the reference's
+  ``(N, F)`` feature matrix on every rank.  Reported: slowest rank's launch, the
+  all-gather, bytes gathered, end to end, and a check against the unsharded
+  transform on rank 0.
+
+``FRUITS_BENCH_BACKEND=gloo`` rehearses the N > 1 path on a box with fewer GPUs than
+ranks (ranks share devices, the collective is staged through the host).
 """
 from __future__ import annotations
 
@@ -32,10 +45,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_SERIES, N_DIMS, N_STEPS_T = 2048, 3, 1024
 
 
-def cpu_baseline(words, seconds_budget: float = 15.0):
+# --------------------------------------------------------------------------- CPU baselines
+def cpu_baseline(words, seconds_budget: float = 12.0):
     """The C oracle (oracle/iss_oracle.c, the reference algorithm restated) on
-    the host cores, on a bounded sample of the same workload."""
+    the host cores, on a bounded sample of the same workload; plus the literal
+    single-process numpy path (oracle/ref_numpy.py, SURVEY.md 8d form 1)."""
     from oracle import c_oracle as corc
+    from oracle import ref_numpy as norc
     # the GPU box gives one GPU a 16-core share; never oversubscribe it
     try:
         avail = len(os.sched_getaffinity(0))
@@ -47,7 +63,7 @@ def cpu_baseline(words, seconds_budget: float = 15.0):
     X = rng.standard_normal((n_sample, N_DIMS, N_STEPS_T))
     strs = [str(w) for w in words]
     corc.iss_transform(X[:8], strs, "EXTENDED", nthreads=threads)  # warm up / build
-    reps, t_total, K = 0, 0.0, 18
+    reps, t_total = 0, 0.0
     out = None
     while t_total < seconds_budget and reps < 50:
         t0 = time.perf_counter()
@@ -56,13 +72,28 @@ def cpu_baseline(words, seconds_budget: float = 15.0):
         reps += 1
     K = out.shape[0]
     value = n_sample * K * N_STEPS_T * reps / t_total
+    # single-process numpy (vectorised over the series, one thread)
+    n_np = 128
+    norc.iss_transform(X[:8], strs, "EXTENDED")
+    reps_np, t_np = 0, 0.0
+    while t_np < 5.0 and reps_np < 20:
+        t0 = time.perf_counter()
+        norc.iss_transform(X[:n_np], strs, "EXTENDED")
+        t_np += time.perf_counter() - t0
+        reps_np += 1
     return {
         "value": value, "unit": "iterated-sum elements/s", "cores": threads, "kind": "port",
         "sample": f"{n_sample} of {N_SERIES} series x {reps} reps, oracle/iss_oracle.c "
                   f"(OpenMP over series, {threads} threads)",
+        "numpy_single_process": {
+            "value": n_np * K * N_STEPS_T * reps_np / t_np, "unit": "iterated-sum elements/s",
+            "cores": 1, "kind": "port",
+            "sample": f"{n_np} of {N_SERIES} series x {reps_np} reps, oracle/ref_numpy.py "
+                      f"(numpy {np.__version__}, vectorised over series, 1 process)"},
     }
 
 
+# --------------------------------------------------------------------------- timing helpers
 def _event_time_us(torch, fn, reps=20):
     fn()
     torch.cuda.synchronize()
@@ -75,9 +106,94 @@ def _event_time_us(torch, fn, reps=20):
     return a.elapsed_time(b) / reps * 1e3
 
 
-def extras(torch, fr, nat, dev):
+def _batch_stats_us(torch, fn, batch=10, batches=50):
+    """Per-launch time of `batches` batches of `batch` back-to-back launches, each batch
+    between one HIP event pair on the launch stream (an event pair per launch would put
+    two barrier packets between consecutive kernels and inflate them by ~10 %)."""
+    ts = []
+    for _ in range(batches):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(batch):
+            fn()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b) / batch * 1e3)
+    ts = np.asarray(ts)
+    return {"median_us": float(np.median(ts)), "min_us": float(ts.min()), "max_us": float(ts.max()),
+            "batches": int(batches), "launches_per_batch": int(batch)}
+
+
+# --------------------------------------------------------------------------- pipelines
+def _device_batch(torch, shape, seed):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    return torch.randn(shape, dtype=torch.float64, device="cuda", generator=g)
+
+
+class _Pipeline:
+    """INC -> ISS(words, EXTENDED, weighting) -> sieves on a device-resident batch, fitted on
+    the first `n_fit` series: the fused launch (all words, or a rank's share of them)."""
+
+    def __init__(self, torch, fr, nat, shape, words, weighting, sieves, n_fit, seed=0):
+        self.torch, self.fr, self.nat = torch, fr, nat
+        self.N, self.D, self.T = shape
+        self.Xd = _device_batch(torch, shape, seed)
+        fruit = fr.Fruit("bench")
+        fruit.add(fr.preparation.INC)
+        self.iss = fr.ISS(words, mode=fr.ISSMode.EXTENDED, weighting=weighting)
+        fruit.add(self.iss)
+        fruit.add(*sieves)
+        self.slc = fruit.get_slice()
+        self.slc.fit_sample_size = 1.0
+        np.random.seed(0)
+        fruit.fit(self.Xd[:n_fit].cpu().numpy())
+        self.fruit = fruit
+        self.cache = fr.cache.SharedSeedCache(None)
+        self.cache.adopt_device_input(self.Xd)
+        self.Pd = self.slc._prepare_device(self.Xd, self.cache)
+        self.slc._attach(self.cache)
+        self.lk = self.iss.lookup_device(self.Pd)
+        self.strings = [str(w) for w in self.iss.words]
+        self.depths = [self.iss._depth(i) for i in range(len(self.strings))]
+        self.per_sum = sum(s.nfeatures() for s in self.slc.get_sieves())
+
+    def launch(self, indices=None):
+        """(fn, feats, pipe): fn enqueues the fused launch of the given words."""
+        torch, nat = self.torch, self.nat
+        pipe = self.slc._fused(self.T, indices=indices)
+        assert pipe is not None, "the bench pipelines are inside the fused set"
+        feats = torch.empty((self.N, pipe.n_features), dtype=torch.float64, device="cuda")
+        rows = 0 if self.lk is None else int(self.lk.shape[0])
+        wb = int(nat.lib().fr_pipeline_workspace_bytes(pipe._h, self.N, rows))
+        work = torch.empty(max(wb, 1), dtype=torch.uint8, device="cuda")
+        pipe.prepare(self.N)
+        return (lambda: pipe.run(self.Pd, self.lk, feats=feats, work=work)), feats, pipe
+
+    def figures(self, pipe, t_us):
+        N, T = self.N, self.T
+        K, d_used = pipe.plan.rows, pipe.plan.dims_used
+        lookup_b = 0 if self.lk is None else 8.0 * self.lk.numel()
+        return {
+            "launch_us": t_us, "K": K, "features": pipe.n_features, "nodes": pipe.plan.nodes,
+            "elements_per_s": N * K * T / (t_us * 1e-6),
+            "algorithmic_bytes": 8.0 * N * T * d_used + lookup_b + 8.0 * N * pipe.n_features,
+            "equivalent_materialised_GBs": (8.0 * N * T * (d_used + K) + lookup_b) / (t_us * 1e-6) / 1e9,
+            "note": "no (K,N,T) tensor is written; the GB/s figure is what a materialising run "
+                    "of the same work would have needed, not achieved bandwidth",
+        }
+
+
+def _config4(torch, fr, nat):
+    return _Pipeline(torch, fr, nat, (8192, 3, 1024), fr.words.of_weight(6, dim=2),
+                     fr.iss.weighting.Indices(), [fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END],
+                     n_fit=128)
+
+
+def extras(torch, fr, nat, dev, quick=False):
     """Secondary measurements on the same GPU (not the headline value): the metric's
-    "48 words" reading, and the fused INC->ISS->NPI,END pipeline of BASELINE configs[2]."""
+    "48 words" reading, what the box streams, and the fused pipelines of BASELINE
+    configs[2], [3] and [4] on ONE GPU."""
     out = {}
     rng = np.random.default_rng(0)
     X = rng.standard_normal((N_SERIES, N_DIMS, N_STEPS_T))
@@ -137,16 +253,125 @@ def extras(torch, fr, nat, dev):
         "note": "no (K,N,T) tensor is written; the GB/s figure is what a materialising run "
                 "of the same work would have needed, not achieved bandwidth",
     }
+    del Xd, Pd, feats
+    if quick:
+        return out
+    # (c) config 4 on ONE GPU: fruit_general's of_weight(6,2) + Indices, (8192,3,1024),
+    # INC -> ISS -> NPI(q=(.5,1)), END; K = 1351 (the reference's tensor would be 90 GB)
+    p4 = _config4(torch, fr, nat)
+    fn, _, pipe4 = p4.launch()
+    out["config4_single_gpu"] = dict(
+        p4.figures(pipe4, _event_time_us(torch, fn, reps=5)),
+        workload="BASELINE configs[3] on one GPU: of_weight(6,2) EXTENDED + Indices, "
+                 "(8192,3,1024), INC -> ISS -> NPI(q=(0.5,1)), END, one fused launch")
+    del p4, fn, pipe4
+    torch.cuda.empty_cache()
+    # (d) config 5 on ONE GPU: fruit_twi slice 1, of_weight(9,1) + L1, (8192,6,4096)
+    p5 = _Pipeline(torch, fr, nat, (8192, 6, 4096), fr.words.of_weight(9, dim=1),
+                   fr.iss.weighting.L1(), [fr.sieving.NPI, fr.sieving.END], n_fit=32)
+    fn, _, pipe5 = p5.launch()
+    out["config5_single_gpu"] = dict(
+        p5.figures(pipe5, _event_time_us(torch, fn, reps=3)),
+        workload="BASELINE configs[4] on one GPU: of_weight(9,1) EXTENDED + L1, (8192,6,4096) "
+                 "(N chosen: SURVEY.md 0.3), INC -> ISS -> NPI, END, one fused launch over 4 "
+                 "time chunks")
+    del p5, fn, pipe5
+    torch.cuda.empty_cache()
     return out
 
 
+# --------------------------------------------------------------------------- word-sharded config 4
+def word_sharded_config4(torch, fr, nat, dist, rank, world, backend):
+    """BASELINE configs[3]: the word list of fruit_general's first slice sharded over the
+    ranks, features all-gathered (fruits_amd.parallel).  Every rank holds the same batch."""
+    from fruits_amd import parallel as par
+    p = _config4(torch, fr, nat)
+    N, T = p.N, p.T
+    parts = par.shard_words(p.strings, p.depths, world)
+    maps = par.column_map(parts, p.depths, p.per_sum)
+    n_features = p.slc.nfeatures()
+    fn, local, pipe = p.launch(indices=parts[rank])
+    # (1) the rank's fused launch alone
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b))
+    my_ms = float(np.median(ts))
+    # (2) the all-gather alone and (3) launch + gather + permutation, device resident
+    par.gather_features(local, maps, n_features, rank, world)   # warm-up (RCCL channel set-up)
+    gather_ms, e2e_ms = [], []
+    full = None
+    for _ in range(5):
+        dist.barrier()
+        torch.cuda.synchronize()
+        tm = {}
+        par.gather_features(local, maps, n_features, rank, world, timings=tm)
+        gather_ms.append(tm.get("allgather_s", 0.0) * 1e3)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        full = par.gather_features(local, maps, n_features, rank, world)
+        torch.cuda.synchronize()
+        e2e_ms.append((time.perf_counter() - t0) * 1e3)
+    mine = {"rank": rank, "launch_ms": my_ms, "allgather_ms": float(np.median(gather_ms)),
+            "end_to_end_ms": float(np.median(e2e_ms)), "K": pipe.plan.rows,
+            "features": pipe.n_features, "nodes": pipe.plan.nodes}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    if rank != 0:
+        return None
+    # (4) rank 0: the unsharded transform of the same batch, every column compared
+    fn1, feats1, pipe1 = p.launch()
+    t_one = _event_time_us(torch, fn1, reps=3) / 1e3
+    fn1()
+    torch.cuda.synchronize()
+    diff = (full - feats1).abs()
+    cols_ok = int((diff.max(dim=0).values == 0).sum().item())
+    launches = [e["launch_ms"] for e in everyone]
+    e2e = max(e["end_to_end_ms"] for e in everyone)
+    width = max(len(m) for m in maps)
+    K_total = pipe1.plan.rows
+    return {
+        "workload": "BASELINE configs[3]: fruit_general slice-1 word set of_weight(6,2) EXTENDED + "
+                    "Indices, (8192,3,1024) float64 on EVERY rank, INC -> ISS -> NPI(q=(0.5,1)), END; "
+                    "word list sharded over the ranks by sub-trie, one fused launch per rank, one "
+                    "padded all_gather_into_tensor of the (N, F_r) blocks + column permutation",
+        "backend": backend + (" (RCCL over xGMI)" if backend == "nccl" else " (host-staged rehearsal)"),
+        "world_size": dist.get_world_size(), "N": N, "D": p.D, "T": T, "words": len(p.strings),
+        "K": K_total, "features": n_features,
+        "rank_launch_ms": launches, "slowest_launch_ms": max(launches),
+        "balance": float(np.mean(launches) / max(launches)),
+        "K_per_rank": [e["K"] for e in everyone], "nodes_per_rank": [e["nodes"] for e in everyone],
+        "allgather_ms": max(e["allgather_ms"] for e in everyone),
+        "gathered_bytes_per_rank": int(N * width * 8),
+        "gathered_bytes_total": int(world * N * width * 8),
+        "end_to_end_ms": e2e,
+        "elements_per_s": N * K_total * T / (e2e * 1e-3),
+        "single_rank_unsharded_launch_ms": t_one,
+        "speedup_vs_single_rank_launch": t_one / e2e,
+        "equals_unsharded_transform": bool(cols_ok == n_features),
+        "columns_checked": n_features, "columns_bit_identical": cols_ok,
+        "max_abs_diff": float(diff.max().item()),
+    }
+
+
+# --------------------------------------------------------------------------- main
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--quick-extras", action="store_true", help="skip the config 4 / 5 extras")
+    ap.add_argument("--no-word-shard", action="store_true")
     ap.add_argument("--groups", type=int, default=0)
     args = ap.parse_args()
 
@@ -157,11 +382,18 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("FRUITS_BENCH_BACKEND", "nccl")
     distributed = world > 1 or bool(os.environ.get("FRUITS_BENCH_FORCE_DIST"))
-    torch.cuda.set_device(local_rank)
+    n_dev = max(torch.cuda.device_count(), 1)
+    device_index = local_rank if backend == "nccl" else local_rank % n_dev
+    torch.cuda.set_device(device_index)
+    dist = None
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
     dev = nat.require_device()
 
     words = fr.words.of_weight(2, dim=N_DIMS)
@@ -172,22 +404,24 @@ def main() -> None:
     X = rng.standard_normal((N_SERIES, N_DIMS, N_STEPS_T))
     Xd = nat.to_device(X)
     out = torch.empty((K, N_SERIES, N_STEPS_T), dtype=torch.float64, device=dev)
+    plan.prepare(N_SERIES, N_STEPS_T, args.groups)
 
     def step():
         plan.run(Xd, None, out=out, layout="KNT", groups=args.groups)
 
-    for _ in range(args.warmup):
+    def barrier():
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 10)):   # >= 10 warm-ups whatever the driver asks for
         step()
     torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-        torch.cuda.synchronize()
-    # Kernel duration: ONE pair of HIP events around the K back-to-back launches of the
-    # timed region, on the stream the kernel is launched on (torch's current stream is
-    # passed through the C ABI); average = elapsed / K, an upper bound that still contains
-    # the launch gaps.  (An event pair per step inserts two barrier packets between
-    # consecutive kernels: measured 78 us/step and "72.6 us" per kernel where this loop
-    # takes 70.2 us per step and rocprofv3 reports 68.1 us per kernel.)
+    barrier()
+    # Timed region: exactly `steps` back-to-back launches between barrier + synchronize.
+    # Kernel duration: ONE pair of HIP events around those launches on the stream the
+    # kernel is launched on (torch's current stream is passed through the C ABI);
+    # average = elapsed / steps, an upper bound that still contains the launch gaps.
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev_a.record()
@@ -195,14 +429,13 @@ def main() -> None:
         step()
     ev_b.record()
     torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-        torch.cuda.synchronize()
+    barrier()
     elapsed = time.perf_counter() - t0
     kernel_avg_s = ev_a.elapsed_time(ev_b) / 1e3 / args.steps
 
     if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64,
+                          device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -210,17 +443,24 @@ def main() -> None:
     row0 = out[0, :4].cpu().numpy()
     assert np.allclose(row0, np.cumsum(X[:4, 0] ** 2, axis=1), rtol=1e-9)
 
+    # distribution of the per-launch time: median / min / max over >= 50 event-timed batches
+    batches = _batch_stats_us(torch, step) if rank == 0 else None
+
     elements = N_SERIES * K * N_STEPS_T
     value = elements * args.steps * world / elapsed
     d_used = plan.dims_used
     b_alg = 8.0 * N_SERIES * N_STEPS_T * (d_used + K)  # read X once, write every sum once
     achieved = b_alg / kernel_avg_s / 1e9
-    traffic = None
+    traffic, traffic_src = None, None
     prof = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(prof):
         try:
             with open(prof) as f:
-                traffic = json.load(f).get("iss_walk_bytes_per_launch")
+                tj = json.load(f)
+            traffic = tj.get("iss_walk_bytes_per_launch")
+            traffic_src = ("constant from profiles/traffic.json (separate rocprofv3 --pmc FETCH_SIZE / "
+                           "WRITE_SIZE passes over this command, " + str(tj.get("round", "r01")) +
+                           "; FETCH_SIZE x2 per MI355X_MICROARCH.md) - not measured in this run")
         except Exception:
             traffic = None
     res = {
@@ -241,21 +481,30 @@ def main() -> None:
                         "(W=15 words, K=18 iterated sums), float64 (2048,3,1024) per GPU, "
                         "(K,N,T) tensor materialised in HBM",
             "N": N_SERIES, "D": N_DIMS, "T": N_STEPS_T, "words": len(words), "K": K,
-            "sharding": "series (one batch per GPU), no data-path collective",
+            "sharding": "series (one batch per GPU), no data-path collective; the word-sharded "
+                        "RCCL all-gather split of configs[3] is measured beside it for n_gpus > 1 "
+                        "(word_sharded_config4)",
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "iss_walk_kernel", "algorithmic_bytes_per_launch": b_alg,
             "kernel_avg_us": kernel_avg_s * 1e6,
-            "timing": "one HIP event pair around the K launches of the timed region / K",
+            "timing": "one HIP event pair around the `steps` launches of the timed region / steps",
+            "batches": batches,
         },
     }
+    del out
+    if distributed and not args.no_word_shard:
+        ws = word_sharded_config4(torch, fr, nat, dist, rank, world, backend)
+        if rank == 0:
+            res["word_sharded_config4"] = ws
     if rank == 0 and world == 1 and not args.no_extras:
-        res["extras"] = extras(torch, fr, nat, dev)
+        res["extras"] = extras(torch, fr, nat, dev, quick=args.quick_extras)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(words)
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(res))

@@ -21,7 +21,7 @@ FR_W_NONE, FR_W_NONTOTAL, FR_W_TOTAL = 0, 1, 2
 FR_SIEVE_NPI, FR_SIEVE_MPI, FR_SIEVE_END = 0, 1, 2
 (FR_INFO_ROWS, FR_INFO_NODES, FR_INFO_LEVELS, FR_INFO_DIMS_USED, FR_INFO_MAX_DIM,
  FR_INFO_ALPHAS, FR_INFO_GROUPS, FR_INFO_SHARED, FR_INFO_STAGED_ROWS) = range(9)
-FR_E_ARG, FR_E_DIM, FR_E_HIP, FR_E_NOMEM, FR_E_LIMIT = -1, -2, -3, -4, -5
+FR_E_ARG, FR_E_DIM, FR_E_HIP, FR_E_NOMEM, FR_E_LIMIT, FR_E_INDEX = -1, -2, -3, -4, -5, -6
 
 EXPORTS = [
     "fr_last_error", "fr_version", "fr_device_count", "fr_malloc", "fr_free",
@@ -32,6 +32,7 @@ EXPORTS = [
     "fr_pipeline_create", "fr_pipeline_destroy", "fr_pipeline_info",
     "fr_pipeline_workspace_bytes", "fr_pipeline_run", "fr_pipeline_set_quantiles",
     "fr_select_ranks", "fr_coswiss_combine", "fr_plan_create_coswiss", "fr_nan_to_num",
+    "fr_plan_prepare", "fr_pipeline_prepare", "fr_plan_fits", "fr_release_scratch",
 ]
 
 _lib = None
@@ -80,6 +81,10 @@ def lib():
     L.fr_pipeline_info.argtypes = [C.c_void_p, C.c_int32]
     L.fr_pipeline_workspace_bytes.restype = C.c_int64
     L.fr_pipeline_workspace_bytes.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+    L.fr_plan_fits.restype = C.c_int32
+    L.fr_plan_fits.argtypes = [C.c_void_p, C.c_int64]
+    L.fr_plan_prepare.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32]
+    L.fr_pipeline_prepare.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     _lib = L
     return L
 
@@ -92,7 +97,7 @@ def check(rc: int, what: str = "") -> None:
     if rc >= 0:
         return
     msg = last_error()
-    if rc == FR_E_DIM:
+    if rc in (FR_E_DIM, FR_E_INDEX):
         raise IndexError(msg)
     if rc in (FR_E_ARG, FR_E_LIMIT):
         raise ValueError(msg)
@@ -212,9 +217,15 @@ class Plan:
 
     def fits(self, T: int) -> bool:
         """Whether a workgroup can stage the plan's rows (input dimensions + exp
-        tables) of one time chunk in LDS."""
-        chunk = 512 if T <= 512 else 1024
-        return self.staged_rows * chunk * 8 <= 150 * 1024
+        tables) of one time chunk in LDS (fr_plan_fits: the library's own rule)."""
+        rc = int(lib().fr_plan_fits(self._h, int(T)))
+        check(rc, "fr_plan_fits")
+        return rc == 1
+
+    def prepare(self, N: int, T: int, groups: int = 0) -> None:
+        """One-time upload of the device tables for (N, T) batches (fr_plan_prepare):
+        afterwards ``run`` only enqueues work and may be captured into a hipGraph."""
+        check(lib().fr_plan_prepare(self._h, int(N), int(T), int(groups)), "fr_plan_prepare")
 
     @property
     def dims_used(self) -> int:
@@ -323,7 +334,8 @@ class Pipeline:
                                  Q1.ctypes.data_as(ip),
                                  cuts.ctypes.data_as(C.POINTER(C.c_int64)), C.c_int64(self.T))
         if not h:
-            raise ValueError(last_error())
+            msg = last_error()
+            raise (IndexError if "out of bounds" in msg else ValueError)(msg)
         self._h = C.c_void_p(h)
         self.per_sum = int(L.fr_pipeline_info(self._h, 0))
         self.q_stride = int(L.fr_pipeline_info(self._h, 1))
@@ -345,6 +357,11 @@ class Pipeline:
             raise ValueError("quantile table must be (K, q_stride)")
         check(lib().fr_pipeline_set_quantiles(self._h, q.ctypes.data_as(C.POINTER(C.c_double))),
               "fr_pipeline_set_quantiles")
+
+    def prepare(self, N: int, groups: int = 0) -> None:
+        """fr_pipeline_prepare: uploads the plan's tables for batches of N series so
+        that ``run`` only enqueues work (hipGraph capture)."""
+        check(lib().fr_pipeline_prepare(self._h, int(N), int(groups)), "fr_pipeline_prepare")
 
     def run(self, Xd, lookup_d, feats=None, groups: int = 0, work=None):
         t = torch()

@@ -18,6 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libfruits_hip.so")
 HEADERS = ["kernels.h", "plan.h", "walk.h", "walk_scan.h", "coswiss.h", "walk_packed.h",
+           "launch_cache.h",
            os.path.join("..", "..", "include", "fruits_hip.h")]
 
 
@@ -47,8 +48,26 @@ def _newest_header() -> float:
     return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
 
 
+STAMP = LIB + ".flags"
+
+
+def build_tag() -> str:
+    """What distinguishes two builds of the same sources: the compile flags that
+    come from the environment (the diagnostic timing build carries stamps and
+    early returns and must never be mistaken for the product library)."""
+    return "timing" if os.environ.get("FRUITS_HIP_TIMING_BUILD") else "product"
+
+
+def _stamped_tag() -> str:
+    try:
+        with open(STAMP) as f:
+            return f.read().strip()
+    except OSError:
+        return ""
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or _stamped_tag() != build_tag():
         return True
     t = os.path.getmtime(LIB)
     srcs = {os.path.join(CSRC, u[1]) for u in units()}
@@ -88,6 +107,8 @@ def build_native(force: bool = False, verbose: bool = False, jobs: int = 0) -> s
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
+    with open(STAMP, "w") as f:
+        f.write(build_tag() + "\n")
     return LIB
 
 

@@ -40,9 +40,10 @@ class SharedSeedCache:
     # -- device side ------------------------------------------------------
     def input_device(self, X: Optional[np.ndarray] = None):
         """The raw input as a device tensor (uploaded once)."""
+        if self._input_dev is not None:      # uploaded before, or adopted from the caller
+            return self._input_dev
         if self._input is not None:
-            if self._input_dev is None:
-                self._input_dev = nat.to_device(self._input)
+            self._input_dev = nat.to_device(self._input)
             return self._input_dev
         if X is None:
             raise RuntimeError("No input for cache given")

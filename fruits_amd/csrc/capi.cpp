@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -19,6 +20,15 @@ struct fr_plan {
 namespace {
 
 thread_local std::string g_err;
+
+// grow-only device scratch of the synchronous fit entry point (fr_select_ranks), per device
+struct Scratch {
+  void *ptr = nullptr;
+  size_t bytes = 0;
+};
+constexpr int kScratchDevices = 64;
+std::mutex g_scratch_mu;
+Scratch g_scratch[kScratchDevices];
 
 int fail(int code, const std::string &msg) {
   g_err = msg;
@@ -45,10 +55,46 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// Uploads the node order for G groups once per plan (allocates: call
-// fr_plan_prepare before graph capture).
-int ensure_device_program(fr::Plan &p, fr::GroupedProgram &gp) {
+// A stream that is being captured into a hipGraph must not see allocations or
+// synchronous copies: the one-time uploads below refuse to run then (the caller
+// prepares the plan first: fr_plan_prepare / fr_pipeline_prepare).
+bool stream_is_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return cs != hipStreamCaptureStatusNone;
+}
+
+int current_device_id() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) (void)hipGetLastError();
+  return dev;
+}
+
+// The tables of a plan live on the device that was current at their first upload.
+int claim_device(fr::Plan &p, const char *who) {
+  const int dev = current_device_id();
+  if (p.device < 0) p.device = dev;
+  if (p.device != dev)
+    return fail(FR_E_ARG, std::string(who) + ": the plan's tables live on device " +
+                              std::to_string(p.device) + " but device " + std::to_string(dev) +
+                              " is current (plans are per device)");
+  return FR_OK;
+}
+
+// Uploads the node order for G groups once per plan.  Allocates and copies
+// synchronously: done by fr_plan_prepare, or by the first run outside a capture.
+// Caller holds p.mu.
+int ensure_device_program(fr::Plan &p, fr::GroupedProgram &gp, hipStream_t st, const char *who) {
+  int rc = claim_device(p, who);
+  if (rc != FR_OK) return rc;
   if (gp.d_blob) return FR_OK;
+  if (stream_is_capturing(st))
+    return fail(FR_E_ARG, std::string(who) + ": the stream is being captured and the plan's "
+                          "tables for this shape are not on the device yet - call "
+                          "fr_plan_prepare / fr_pipeline_prepare before the capture");
   const size_t n_recs = gp.recs.size();
   size_t off = 0;
   const size_t o_nodes = off;       off = align_up(off + n_recs * sizeof(fr::NodeRec), 64);
@@ -82,8 +128,15 @@ int ensure_device_program(fr::Plan &p, fr::GroupedProgram &gp) {
   return FR_OK;
 }
 
-int ensure_cos_program(fr::CosProgram &c) {
+// Caller holds p.mu.
+int ensure_cos_program(fr::Plan &p, fr::CosProgram &c, hipStream_t st, const char *who) {
+  int rc = claim_device(p, who);
+  if (rc != FR_OK) return rc;
   if (c.d_blob) return FR_OK;
+  if (stream_is_capturing(st))
+    return fail(FR_E_ARG, std::string(who) + ": the stream is being captured and the CosWISS "
+                          "program is not on the device yet - call fr_plan_prepare / "
+                          "fr_pipeline_prepare before the capture");
   size_t off = 0;
   const size_t o_lb = off;    off = align_up(off + c.letter_begin.size() * 4, 64);
   const size_t o_fb = off;    off = align_up(off + c.fac_begin.size() * 4, 64);
@@ -125,6 +178,31 @@ int choose_groups(const fr::Plan &p, int64_t N, int requested) {
   return G;
 }
 
+// How a (plan, N, T, groups) launch is shaped: decided identically by the run path
+// and by fr_plan_prepare (which uploads the node order the run will ask for).
+struct LaunchShape {
+  bool packed = false;    // wave-per-series kernel (short series)
+  bool fits = true;       // the staged rows of one time chunk fit the LDS
+  int G = 1;              // groups of root sub-tries per series
+};
+
+bool staged_rows_fit(const fr::Plan &p, int64_t T) {
+  return (size_t)p.rows_staged() * fr::walk_chunk_elems(T) * 8 <= 150 * 1024;
+}
+
+LaunchShape launch_shape(const fr::Plan &p, int64_t N, int64_t T, int requested_groups) {
+  LaunchShape s;
+  s.fits = staged_rows_fit(p, T);
+  // short series: four series per workgroup, one wave each (their rows side by side in LDS)
+  const int64_t packed_chunk = T <= 128 ? 128 : (T <= 256 ? 256 : 384);
+  s.packed = env_int("FRUITS_HIP_PACKED", 1) != 0 &&
+             fr::packed_supported(T, p.levels, p.semiring) &&
+             (size_t)4 * p.rows_staged() * packed_chunk * 8 <= 64 * 1024;
+  // (a packed workgroup holds four units: ask for four times the units)
+  s.G = choose_groups(p, s.packed ? (N + 3) / 4 : N, requested_groups);
+  return s;
+}
+
 struct WorkLayout {
   size_t aux_bytes = 0, carry_bytes = 0;
   size_t total() const { return aux_bytes + carry_bytes; }
@@ -149,7 +227,7 @@ extern "C" {
 
 const char *fr_last_error(void) { return g_err.c_str(); }
 
-int fr_version(void) { return 110; }
+int fr_version(void) { return 120; }
 
 int fr_device_count(void) {
   int n = 0;
@@ -283,6 +361,31 @@ int64_t fr_plan_workspace_bytes(const fr_plan_t *plan, int64_t N, int64_t T, int
   return (int64_t)work_layout(*plan->p, N, T, lookup_rows).total();
 }
 
+int32_t fr_plan_fits(const fr_plan_t *plan, int64_t T) {
+  if (!plan || !plan->p || T < 0) return fail(FR_E_ARG, "fr_plan_fits: bad argument");
+  const fr::Plan &p = *plan->p;
+  if (p.cos) return (p.cos->exponent <= fr::kCosMaxExponent && p.levels <= 16) ? 1 : 0;
+  return staged_rows_fit(p, T) ? 1 : 0;
+}
+
+int fr_plan_prepare(fr_plan_t *plan, int64_t N, int64_t T, int32_t groups) {
+  if (!plan || !plan->p || N < 0 || T < 0) return fail(FR_E_ARG, "fr_plan_prepare: bad argument");
+  fr::Plan &p = *plan->p;
+  std::lock_guard<std::mutex> lock(p.mu);
+  if (p.cos) return ensure_cos_program(p, *p.cos, nullptr, "fr_plan_prepare");
+  if (N == 0 || T == 0 || p.K == 0 || p.nodes.empty()) return FR_OK;
+  const LaunchShape shape = launch_shape(p, N, T, groups);
+  if (!shape.fits)
+    return fail(FR_E_LIMIT, "fr_plan_prepare: the plan stages " + std::to_string(p.rows_staged()) +
+                                " rows per time chunk, more than the LDS holds - split the word list");
+  int rc = ensure_device_program(p, fr::grouped(p, shape.G), nullptr, "fr_plan_prepare");
+  if (rc != FR_OK) return rc;
+  // the opt-in wave-per-row kernel (FRUITS_HIP_TEAM=1) always walks 4 groups
+  if (env_int("FRUITS_HIP_TEAM", 0) == 1 && groups <= 0 && p.units() >= 4 && shape.G != 4)
+    rc = ensure_device_program(p, fr::grouped(p, 4), nullptr, "fr_plan_prepare");
+  return rc;
+}
+
 }  // extern "C"
 
 namespace {
@@ -316,8 +419,11 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     if (!d_work || (size_t)work_bytes < need)
       return fail(FR_E_NOMEM, w + ": workspace too small (need " + std::to_string(need) +
                                   " bytes)");
-    int rc = ensure_cos_program(c);
-    if (rc != FR_OK) return rc;
+    {
+      std::lock_guard<std::mutex> lock(p.mu);
+      int rc = ensure_cos_program(p, c, st, who);
+      if (rc != FR_OK) return rc;
+    }
     double *trig = static_cast<double *>(d_work);
     hipError_t e = fr::launch_trig_tables(c.d_freqs, c.F, T, trig, st);
     if (e != hipSuccess) return hip_fail(e, "trig_tables launch");
@@ -371,24 +477,22 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
                          p.semiring == fr::kSemiReals &&
                          fr::wave_rows_supported(T, p.levels, vec_ok_pre);
   // the staged rows (input dimensions + exp tables) of one time chunk must fit the LDS
+  LaunchShape shape = launch_shape(p, N, T, groups);
+  if (!shape.fits)
+    return fail(FR_E_LIMIT, w + ": the plan stages " + std::to_string(p.rows_staged()) +
+                                " rows per time chunk (input dimensions + exp tables of " +
+                                std::to_string(p.alphas.size()) +
+                                " distinct alphas), more than the LDS holds - split the word list");
+  const bool packed = !wave_rows && shape.packed;
+  const int G = wave_rows ? 4 : shape.G;
+  fr::GroupedProgram *gpp = nullptr;
   {
-    const size_t rows_bytes = (size_t)p.rows_staged() * fr::walk_chunk_elems(T) * 8;
-    if (rows_bytes > 150 * 1024)
-      return fail(FR_E_LIMIT, w + ": the plan stages " + std::to_string(p.rows_staged()) +
-                                  " rows per time chunk (input dimensions + exp tables of " +
-                                  std::to_string(p.alphas.size()) +
-                                  " distinct alphas), more than the LDS holds - split the word list");
+    std::lock_guard<std::mutex> lock(p.mu);
+    gpp = &fr::grouped(p, G);   // (map nodes are stable: the reference outlives the lock)
+    int rc = ensure_device_program(p, *gpp, st, who);
+    if (rc != FR_OK) return rc;
   }
-  // short series: four series per workgroup, one wave each (their rows side by side in LDS)
-  const int64_t packed_chunk = T <= 128 ? 128 : (T <= 256 ? 256 : 384);
-  const bool packed = !wave_rows && env_int("FRUITS_HIP_PACKED", 1) != 0 &&
-                      fr::packed_supported(T, p.levels, p.semiring) &&
-                      (size_t)4 * p.rows_staged() * packed_chunk * 8 <= 64 * 1024;
-  // (a packed workgroup holds four units: ask for four times the units)
-  const int G = wave_rows ? 4 : choose_groups(p, packed ? (N + 3) / 4 : N, groups);
-  fr::GroupedProgram &gp = fr::grouped(p, G);
-  int rc = ensure_device_program(p, gp);
-  if (rc != FR_OK) return rc;
+  fr::GroupedProgram &gp = *gpp;
 
   fr::IssArgs a{};
   a.X = d_X;
@@ -528,6 +632,14 @@ fr_pipeline_t *fr_pipeline_create(fr_plan_t *plan, int32_t n_sieves, const int32
     }
     for (int j = 0; j < c1; ++j) {
       const int64_t c = *cuts++;
+      // END reads X[:, c - 1] (index -1 wraps like numpy): the reference raises IndexError
+      // outside [-T, T-1] (np.take_along_axis, fruits/sieving/segment.py:213-218)
+      if (sv.kind == FR_SIEVE_END && j > 0 && (c - 1 < -T || c - 1 > T - 1)) {
+        fail(FR_E_INDEX, "fr_pipeline_create: END cut " + std::to_string(c) +
+                             " is out of bounds for series of length " + std::to_string(T));
+        delete pl;
+        return nullptr;
+      }
       sv.cuts.push_back((int32_t)(c < 0 ? 0 : (c > T ? T : c)));
     }
     const int nf = sv.kind == FR_SIEVE_END ? c1 - 1 : (c1 - 1) * (sv.Q1 - 1);
@@ -660,6 +772,14 @@ int64_t fr_pipeline_workspace_bytes(const fr_pipeline_t *pl, int64_t N, int64_t 
   return (int64_t)b;
 }
 
+int fr_pipeline_prepare(fr_pipeline_t *pl, int64_t N, int32_t groups) {
+  if (!pl || !pl->plan || !pl->plan->p || N < 0)
+    return fail(FR_E_ARG, "fr_pipeline_prepare: bad argument");
+  if (!pl->have_quantiles)
+    return fail(FR_E_ARG, "fr_pipeline_prepare: call fr_pipeline_set_quantiles first");
+  return fr_plan_prepare(pl->plan, N, pl->T, groups);
+}
+
 int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, int64_t T,
                     const double *d_lookup, int64_t lookup_rows, double *d_feats,
                     int64_t feat_stride, void *d_work, int64_t work_bytes, int32_t groups,
@@ -684,11 +804,19 @@ int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, 
   fu.feat_stride = feat_stride;
   fu.n_ops = pl->n_ops_eff;
   fu.n_ops_padded = pl->n_ops_padded;
+  // (the population table of MPI features shares the feature row stride)
+  if (!pl->mpi_cols.empty() && feat_stride != F)
+    return fail(FR_E_ARG, "fr_pipeline_run: MPI needs feat_stride == F");
+  if (N < 0 || D < 1 || !d_X) return fail(FR_E_ARG, "fr_pipeline_run: bad input");
+  if (p.max_dim > D)
+    return fail(FR_E_DIM, "fr_pipeline_run: a word references dimension " +
+                              std::to_string(p.max_dim) + " but the input has only " +
+                              std::to_string(D));
+  if (p.weighting != 0 && !p.cos && (!d_lookup || (lookup_rows != 1 && lookup_rows != N)))
+    return fail(FR_E_ARG, "fr_pipeline_run: weighted plan needs a lookup of 1 or N rows");
   // features accumulate with atomics: clear them (memset nodes, graph-capturable)
   HIP_TRY(hipMemset2DAsync(d_feats, (size_t)feat_stride * 8, 0, (size_t)F * 8, (size_t)N, st));
   if (!pl->mpi_cols.empty()) {
-    // the population table shares the feature row stride
-    if (feat_stride != F) return fail(FR_E_ARG, "fr_pipeline_run: MPI needs feat_stride == F");
     fu.cnt = reinterpret_cast<double *>(static_cast<char *>(d_work) + plan_ws);
     HIP_TRY(hipMemsetAsync(fu.cnt, 0, (size_t)N * F * 8, st));
   } else {
@@ -836,38 +964,49 @@ int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32
   const int n_groups = (int)groups.size() / 2;
   std::vector<double> sorted_out(n_jobs);
   hipStream_t st = (hipStream_t)stream;
-  void *d_jobs = nullptr, *d_hist = nullptr, *d_out = nullptr, *d_groups = nullptr;
-  int rc = FR_OK;
-  do {
-    hipError_t e;
-    if ((e = hipMalloc(&d_jobs, jobs.size() * sizeof(HostJob))) != hipSuccess ||
-        (e = hipMalloc(&d_groups, groups.size() * 4)) != hipSuccess ||
-        (e = hipMalloc(&d_hist, (size_t)n_jobs * 256 * 4)) != hipSuccess ||
-        (e = hipMalloc(&d_out, (size_t)n_jobs * 8)) != hipSuccess ||
-        (e = hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(HostJob),
-                            hipMemcpyHostToDevice, st)) != hipSuccess ||
-        (e = hipMemcpyAsync(d_groups, groups.data(), groups.size() * 4, hipMemcpyHostToDevice,
-                            st)) != hipSuccess ||
-        (e = hipMemsetAsync(d_hist, 0, (size_t)n_jobs * 256 * 4, st)) != hipSuccess ||
-        (e = fr::launch_select_ranks(d_jobs, n_jobs, d_groups, n_groups, N, T,
-                                     static_cast<unsigned int *>(d_hist),
-                                     static_cast<double *>(d_out), st)) != hipSuccess ||
-        (e = hipMemcpyAsync(sorted_out.data(), d_out, (size_t)n_jobs * 8, hipMemcpyDeviceToHost,
-                            st)) != hipSuccess ||
-        (e = hipStreamSynchronize(st)) != hipSuccess) {
-      rc = hip_fail(e, "fr_select_ranks");
-    }
-  } while (0);
-  const std::string keep = g_err;
-  if (d_jobs) (void)hipFree(d_jobs);
-  if (d_groups) (void)hipFree(d_groups);
-  if (d_hist) (void)hipFree(d_hist);
-  if (d_out) (void)hipFree(d_out);
-  if (rc != FR_OK) {
-    g_err = keep;
-    return rc;
+  // one grow-only scratch blob per device (jobs | groups | histograms | results): fit calls
+  // this once per word batch and slice, and hipMalloc / hipFree synchronise the device
+  const size_t o_jobs = 0;
+  const size_t o_groups = align_up(o_jobs + jobs.size() * sizeof(HostJob), 256);
+  const size_t o_hist = align_up(o_groups + groups.size() * 4, 256);
+  const size_t o_out = align_up(o_hist + (size_t)n_jobs * 256 * 4, 256);
+  const size_t need = align_up(o_out + (size_t)n_jobs * 8, 256);
+  const int dev = current_device_id();
+  if (dev < 0 || dev >= kScratchDevices) return fail(FR_E_ARG, "fr_select_ranks: device id");
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  Scratch &sc = g_scratch[dev];
+  if (sc.bytes < need) {
+    if (sc.ptr) (void)hipFree(sc.ptr);
+    sc.ptr = nullptr;
+    sc.bytes = 0;
+    const size_t want = std::max(need + need / 2, (size_t)1 << 20);
+    HIP_TRY(hipMalloc(&sc.ptr, want));
+    sc.bytes = want;
   }
+  char *b = static_cast<char *>(sc.ptr);
+  hipError_t e;
+  if ((e = hipMemcpyAsync(b + o_jobs, jobs.data(), jobs.size() * sizeof(HostJob),
+                          hipMemcpyHostToDevice, st)) != hipSuccess ||
+      (e = hipMemcpyAsync(b + o_groups, groups.data(), groups.size() * 4, hipMemcpyHostToDevice,
+                          st)) != hipSuccess ||
+      (e = hipMemsetAsync(b + o_hist, 0, (size_t)n_jobs * 256 * 4, st)) != hipSuccess ||
+      (e = fr::launch_select_ranks(b + o_jobs, n_jobs, b + o_groups, n_groups, N, T,
+                                   reinterpret_cast<unsigned int *>(b + o_hist),
+                                   reinterpret_cast<double *>(b + o_out), st)) != hipSuccess ||
+      (e = hipMemcpyAsync(sorted_out.data(), b + o_out, (size_t)n_jobs * 8,
+                          hipMemcpyDeviceToHost, st)) != hipSuccess ||
+      (e = hipStreamSynchronize(st)) != hipSuccess)
+    return hip_fail(e, "fr_select_ranks");
   for (int s = 0; s < n_jobs; ++s) h_out[order[s]] = sorted_out[s];
+  return FR_OK;
+}
+
+int fr_release_scratch(void) {
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  for (int d = 0; d < kScratchDevices; ++d) {
+    if (g_scratch[d].ptr) (void)hipFree(g_scratch[d].ptr);
+    g_scratch[d] = Scratch{};
+  }
   return FR_OK;
 }
 

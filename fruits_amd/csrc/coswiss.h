@@ -362,14 +362,10 @@ template <int P, bool VEC, int MODE, int S>
 static hipError_t launch_coswiss_packed_cfg(const IssArgs &a, hipStream_t st) {
   using C = WalkCfg<(P == 2 ? 4 : 2), (P == 2 ? 1 : P), 1, 0, VEC, false, 1, MODE, 0>;
   const int64_t units = a.N * a.cw_W * a.cw_F;
-  static int per_cu = 0;
-  if (per_cu == 0) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, coswiss_packed_kernel<C, S>,
-                                                     kWalkThreads, 0) != hipSuccess || nb < 1)
-      nb = 1;
-    per_cu = nb;
-  }
+  static LaunchCache cache;  // per instantiation; per-device entries, thread-safe
+  int per_cu = 1;
+  hipError_t e = cache.facts(coswiss_packed_kernel<C, S>, kWalkThreads, 0, &per_cu);
+  if (e != hipSuccess) return e;
   int64_t blocks = (units + C::TEAMS - 1) / C::TEAMS;
   const int64_t resident = (int64_t)per_cu * device_cu_count();
   if (blocks > resident) blocks = resident;
@@ -388,14 +384,10 @@ static hipError_t launch_coswiss_cfg(const IssArgs &a, hipStream_t st) {
   const size_t lds = (2 * C::NW * (S + 1) + 4 * C::NW + (kCosMaxLetters * (S + 1) + 8)) *
                      sizeof(double);
   const int64_t units = a.N * a.cw_W * a.cw_F;
-  static int per_cu = 0;
-  if (per_cu == 0) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, coswiss_kernel<C, S>, kWalkThreads,
-                                                     lds) != hipSuccess || nb < 1)
-      nb = 1;
-    per_cu = nb;
-  }
+  static LaunchCache cache;  // per instantiation; per-device entries, thread-safe
+  int per_cu = 1;
+  hipError_t e = cache.facts(coswiss_kernel<C, S>, kWalkThreads, lds, &per_cu);
+  if (e != hipSuccess) return e;
   int64_t blocks = (int64_t)per_cu * device_cu_count();
   if (blocks > units) blocks = units;
   if (blocks < 1) return hipSuccess;

@@ -217,7 +217,9 @@ __global__ __launch_bounds__(256) void sieve_kernel(int kind, const double *__re
     for (int j = tid; j < C1 - 1; j += blockDim.x) {
       int64_t idx = cut[j + 1] - 1;
       if (idx < 0) idx += T;
-      out[n * out_stride + j] = row[idx];
+      // out of range: the reference raises IndexError (the host validates integer cuts);
+      // a device cut table that slipped through yields NaN, never a stray read
+      out[n * out_stride + j] = (idx >= 0 && idx < T) ? row[idx] : __builtin_nan("");
     }
     return;
   }

@@ -9,6 +9,7 @@
 #pragma once
 #include <cstdint>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -109,7 +110,8 @@ struct Plan {
   bool multiplicative() const { return semiring != kSemiArctic; }
   int dims_used = 0;
   std::map<int, GroupedProgram> programs;  // per G
-  int device = -1;
+  int device = -1;     // HIP device the uploaded tables live on (-1: nothing uploaded yet)
+  std::mutex mu;       // guards `programs`, `cos->d_blob` and `device` (uploads at run time)
 
   int units() const { return (int)unit_begin.size() - 1; }
   int rows_staged() const { return (int)row_src.size(); }

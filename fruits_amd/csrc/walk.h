@@ -17,6 +17,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "kernels.h"
+#include "launch_cache.h"
 #include "walk_scan.h"
 
 namespace fr {
@@ -830,18 +831,6 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
 }
 
 // ---------------------------------------------------------------- launch
-static int device_cu_count() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
-  return cus;
-}
-
 template <int E, int P, int LV, int MULTI, bool VEC, bool W, int TEAM = 4, int MODE = 0,
           int SEMI = 0>
 static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
@@ -850,27 +839,15 @@ static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
                       (MULTI == 1 ? a.carry_slots : 0)) *
                      sizeof(double);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  static size_t lds_attr = 0;  // per instantiation
-  if (lds > 64 * 1024 && lds > lds_attr) {
-    hipError_t e = hipFuncSetAttribute((const void *)iss_walk_kernel<C>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    lds_attr = lds;
-  }
+  static LaunchCache cache;  // per instantiation; per-device entries, thread-safe
+  int per_cu = 1;
+  hipError_t e = cache.facts(iss_walk_kernel<C>, kWalkThreads, lds,
+                             a.persistent ? &per_cu : nullptr);
+  if (e != hipSuccess) return e;
   const int64_t units = TEAM == 1 ? a.N : a.N * a.G;
   int64_t blocks = units;
   if (a.persistent) {
     // one resident round of workgroups (a multiple of 8 for the XCD mapping)
-    static size_t cached_lds = (size_t)-1;
-    static int per_cu = 0;
-    if (cached_lds != lds) {
-      int nb = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iss_walk_kernel<C>, kWalkThreads,
-                                                       lds) != hipSuccess || nb < 1)
-        nb = 1;
-      per_cu = nb;
-      cached_lds = lds;
-    }
     int64_t resident = (int64_t)per_cu * device_cu_count();
     resident -= resident % 8;
     if (resident < 8) resident = 8;

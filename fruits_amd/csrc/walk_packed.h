@@ -83,16 +83,10 @@ static hipError_t launch_walk_packed_cfg(const IssArgs &a, hipStream_t st) {
   if (lds > 64 * 1024) return hipErrorInvalidValue;
   const int64_t units = a.N * a.G;
   int64_t blocks = (units + C::TEAMS - 1) / C::TEAMS;
-  static size_t cached_lds = (size_t)-1;
-  static int per_cu = 0;
-  if (cached_lds != lds) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iss_walk_packed_kernel<C>, kWalkThreads,
-                                                     lds) != hipSuccess || nb < 1)
-      nb = 1;
-    per_cu = nb;
-    cached_lds = lds;
-  }
+  static LaunchCache cache;  // per instantiation; per-device entries, thread-safe
+  int per_cu = 1;
+  hipError_t e = cache.facts(iss_walk_packed_kernel<C>, kWalkThreads, lds, &per_cu);
+  if (e != hipSuccess) return e;
   const int64_t resident = (int64_t)per_cu * device_cu_count();
   if (a.persistent && blocks > resident) blocks = resident;
   if (blocks < 1) return hipSuccess;

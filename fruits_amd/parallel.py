@@ -102,10 +102,15 @@ def column_map(parts, depths, features_per_sum: int):
     return maps
 
 
-def gather_features(local, maps, n_features: int, rank: int, world: int, group=None):
+def gather_features(local, maps, n_features: int, rank: int, world: int, group=None,
+                    timings: Optional[dict] = None):
     """All-gathers the per-rank ``(N, F_r)`` blocks and scatters their columns to
-    the reference positions.  ``local`` is a torch tensor (device tensor with the
-    nccl backend, CPU tensor with gloo)."""
+    the reference positions.  ``local`` is a torch tensor: a device tensor with
+    the nccl (= RCCL) backend; with gloo (CPU rehearsals of the same path) a
+    device tensor is staged through the host for the collective only.
+    ``timings``: filled with the seconds spent in the collective (synchronised)."""
+    import time
+
     import torch
     import torch.distributed as dist
 
@@ -114,8 +119,22 @@ def gather_features(local, maps, n_features: int, rank: int, world: int, group=N
     padded = torch.zeros((n, width), dtype=local.dtype, device=local.device)
     padded[:, :local.shape[1]] = local
     if world > 1:
-        flat = torch.empty((world * n, width), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(flat, padded, group=group)
+        via_host = local.is_cuda and dist.get_backend(group) == "gloo"
+        if timings is not None and local.is_cuda:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if via_host:
+            flat_h = torch.empty((world * n, width), dtype=local.dtype)
+            dist.all_gather_into_tensor(flat_h, padded.cpu(), group=group)
+            flat = flat_h.to(local.device)
+        else:
+            flat = torch.empty((world * n, width), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(flat, padded, group=group)
+        if timings is not None:
+            if local.is_cuda:
+                torch.cuda.synchronize()
+            timings["allgather_s"] = time.perf_counter() - t0
+            timings["allgather_bytes_per_rank"] = int(n * width * local.element_size())
         gathered = flat.view(world, n, width)
     else:
         gathered = padded.unsqueeze(0)

@@ -174,3 +174,29 @@ class END(SegmentSieve):
 
     def quantiles_device(self):
         return None
+
+    @staticmethod
+    def _check_cuts(rows: np.ndarray, T: int) -> None:
+        """The reference gathers ``X[:, cuts[:, 1:] - 1]`` with np.take_along_axis
+        (fruits/sieving/segment.py:213-218) from the SORTED cut rows: an index
+        outside [-T, T-1] raises IndexError there, and here."""
+        idx = np.asarray(rows)[..., 1:] - 1
+        bad = (idx < -T) | (idx > T - 1)
+        if bad.any():
+            raise IndexError(
+                f"index {int(idx[bad].ravel()[0])} is out of bounds for axis 1 with size {T} "
+                f"(END cut {self_cut_repr(rows)})")
+
+    def _int_cut_row(self, T: int) -> np.ndarray:
+        row = super()._int_cut_row(T)
+        self._check_cuts(row, T)
+        return row
+
+    def _get_transformed_cuts(self, X: np.ndarray) -> np.ndarray:
+        cuts = super()._get_transformed_cuts(X)
+        self._check_cuts(cuts, X.shape[1])
+        return cuts
+
+
+def self_cut_repr(rows) -> str:
+    return np.array2string(np.asarray(rows).reshape(-1, np.asarray(rows).shape[-1])[0])

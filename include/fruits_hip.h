@@ -13,8 +13,16 @@
  *     C-contiguous, exactly like the reference's numba signatures
  *     (f8 arrays; i4 word tables; f4 alpha; i8 cuts).
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
- *     Device entry points only ENQUEUE work; they never allocate, free or
- *     synchronise, so they may be captured into a hipGraph.
+ *     Device entry points only ENQUEUE work once their plan has been PREPARED
+ *     for the shape (fr_plan_prepare / fr_pipeline_prepare: the one-time upload
+ *     of the plan's tables): they then never allocate, free or synchronise, so
+ *     they may be captured into a hipGraph.  An unprepared plan is uploaded by
+ *     its first run (an allocation + a synchronous copy); while the stream is
+ *     being captured that run fails with FR_E_ARG instead of breaking the
+ *     capture.  A plan's tables live on the device that was current at the
+ *     first upload; running it with another device current fails with FR_E_ARG.
+ *     Entry points are safe to call from several host threads (plans guard
+ *     their own tables; launch-time caches are per device).
  *   - Return value: 0 = ok, <0 = error (FR_E_*); fr_last_error() returns a
  *     thread-local message.  Nothing here ever falls back to a CPU path: with
  *     no HIP device every compute call fails with FR_E_HIP.
@@ -35,6 +43,8 @@ extern "C" {
 #define FR_E_HIP (-3)    /* HIP runtime error (no device, launch failure, ...)  */
 #define FR_E_NOMEM (-4)  /* workspace too small / allocation failure            */
 #define FR_E_LIMIT (-5)  /* plan exceeds a compiled-in limit                    */
+#define FR_E_INDEX (-6)  /* an index the reference would raise IndexError for
+                            (END cut outside the series, fruits/sieving/segment.py:213-218) */
 
 /* weighting modes of fr_plan_create */
 #define FR_W_NONE 0      /* weighting is None  -> semiring.py:27-28,35 (alpha=0, lookup=0, total) */
@@ -114,6 +124,16 @@ int32_t fr_plan_dump(const fr_plan_t *plan, int32_t *buf, int32_t cap);
  * (exp tables for weighted plans, chunk carries for T > one chunk). */
 int64_t fr_plan_workspace_bytes(const fr_plan_t *plan, int64_t N, int64_t T,
                                 int64_t lookup_rows);
+/* 1 when a workgroup can stage the plan's rows (input dimensions + exp tables) of one
+ * time chunk of a length-T series in LDS, 0 when fr_iss_run would return FR_E_LIMIT
+ * (the caller then splits the word list). */
+int32_t fr_plan_fits(const fr_plan_t *plan, int64_t T);
+/* One-time upload of the plan's device tables for batches of N series of length T
+ * (`groups` as in fr_iss_run).  Allocates and synchronises - call it OUTSIDE a stream
+ * capture; afterwards fr_iss_run for that (N, T, groups) only enqueues work.  The
+ * reference's callers are synchronous and stateless (fruits/iss/semiring.py:43-52):
+ * this is the explicit form of the state a device plan needs.  Idempotent. */
+int fr_plan_prepare(fr_plan_t *plan, int64_t N, int64_t T, int32_t groups);
 
 /* ------------------------------------------------------------------ ISS
  * Replaces Reals._iterated_sum_fast for ALL words of the plan in one launch
@@ -203,7 +223,8 @@ int fr_sieve(int32_t kind, const double *d_A, int64_t N, int64_t T, int64_t a_st
  *   kinds/incs/C1/Q1   per sieve; Q1 is ignored for END
  *   cuts               concatenated transformed cut rows (C1[s] values each: sorted,
  *                      leading 0, negative cuts already resolved for length T -
- *                      fruits/sieving/segment.py:51-64)
+ *                      fruits/sieving/segment.py:51-64); an END cut c with c - 1 outside
+ *                      [-T, T-1] fails with FR_E_INDEX (the reference raises IndexError)
  *   h_quant            HOST (K, q_stride) thresholds of every iterated sum (the fitted
  *                      sieve copies of fruit.py:484-496), q_stride =
  *                      fr_pipeline_info(p, 1) = sum of Q1 over the NPI/MPI sieves;
@@ -222,6 +243,10 @@ int64_t fr_pipeline_info(const fr_pipeline_t *pipeline, int32_t what);
 int64_t fr_pipeline_workspace_bytes(const fr_pipeline_t *pipeline, int64_t N,
                                     int64_t lookup_rows);
 int fr_pipeline_set_quantiles(fr_pipeline_t *pipeline, const double *h_quant);
+/* fr_plan_prepare for the pipeline's plan and series length (after
+ * fr_pipeline_set_quantiles): fr_pipeline_run for batches of N series then only
+ * enqueues work (two memsets, the exp-table kernel, the walk, the MPI finalize). */
+int fr_pipeline_prepare(fr_pipeline_t *pipeline, int64_t N, int32_t groups);
 int fr_pipeline_run(fr_pipeline_t *pipeline, const double *d_X, int64_t N, int64_t D, int64_t T,
                     const double *d_lookup, int64_t lookup_rows, double *d_feats,
                     int64_t feat_stride, void *d_work, int64_t work_bytes, int32_t groups,
@@ -239,10 +264,13 @@ int fr_pre_transform(const double *d_A, int64_t N, int64_t T, int64_t a_stride, 
  * interpolates between the two order statistics around q*(n-1); job j returns the
  * job_rank[j]-th smallest (0-based) of the job_inc[j]-times differenced
  * (N, T) block number job_row[j] of the device tensor d_A (rows, N, T).  Exact
- * (radix select); synchronous; allocates its scratch (fit is not a capture path). */
+ * (radix select); synchronous (fit is not a capture path); its device scratch is a
+ * grow-only blob per device kept between calls - fr_release_scratch frees it. */
 int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32_t n_jobs,
                     const int32_t *job_row, const int32_t *job_inc, const int64_t *job_rank,
                     double *h_out, void *stream);
+
+int fr_release_scratch(void);
 
 /* ------------------------------------------------------------------ STD ("next" row)
  * STD._transform with separately=True (fruits/preparation/transform.py:141-147):

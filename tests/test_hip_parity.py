@@ -714,6 +714,75 @@ def test_entry_points_capture_into_a_hip_graph(fr):
         np.testing.assert_allclose(feats.cpu().numpy(), feager.cpu().numpy(), rtol=1e-12)
 
 
+def test_capture_without_prior_eager_run(fr):
+    """fr_plan_prepare / fr_pipeline_prepare do the one-time upload: a plan that has never
+    run eagerly is captured into a graph; an UNPREPARED plan refuses to run inside a
+    capture (it would allocate and synchronise) instead of breaking it."""
+    import torch
+    from fruits_amd import _native as nat
+    from oracle import ref_numpy as orc_np
+    rng = np.random.default_rng(21)
+    N, T = 24, 1024
+    X = rng.standard_normal((N, 2, T)).cumsum(axis=2) / np.sqrt(T)
+    Xd = nat.to_device(X)
+    words = fr.words.of_weight(3, 2)
+    # materialising plan, never run before
+    iss = fr.ISS(words, mode=fr.ISSMode.EXTENDED)
+    plan = iss._plan(0, len(words))
+    out = torch.zeros((plan.rows, N, T), dtype=torch.float64, device=Xd.device)
+    # fused pipeline, never run before
+    fruit = fr.Fruit()
+    fruit.add(fr.ISS(words, mode=fr.ISSMode.EXTENDED), fr.sieving.NPI, fr.sieving.END)
+    fruit.fit(X)                      # unfitted sieves: no device work on this plan
+    slc = fruit.get_slice()
+    pipe = slc._fused(T)
+    feats = torch.zeros((N, pipe.n_features), dtype=torch.float64, device=Xd.device)
+    pwork = torch.empty(int(nat.lib().fr_pipeline_workspace_bytes(pipe._h, N, 0)) + 1,
+                        dtype=torch.uint8, device=Xd.device)
+    # an unprepared plan inside a capture: refused, the capture survives
+    other = fr.ISS(fr.words.of_weight(2, 2))._plan(0, 6)
+    oout = torch.zeros((other.rows, N, T), dtype=torch.float64, device=Xd.device)
+    plan.prepare(N, T)
+    pipe.prepare(N)
+    torch.cuda.synchronize()
+    g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            plan.run(Xd, None, out=out)
+            pipe.run(Xd, None, feats=feats, work=pwork)
+            with pytest.raises(ValueError, match="fr_plan_prepare"):
+                other.run(Xd, None, out=oout)
+    g.replay()
+    torch.cuda.synchronize()
+    ref = orc_np.iss_transform(X, [str(w) for w in words], "EXTENDED")
+    assert rowwise_close(out.cpu().numpy(), ref)
+    np.testing.assert_allclose(feats.cpu().numpy(), fruit.transform(X), rtol=1e-12)
+    # outside a capture the unprepared plan uploads by itself
+    other.run(Xd, None, out=oout)
+    assert plan.fits(T) and plan.fits(100)
+
+
+def test_end_cut_out_of_range_raises(fr):
+    """END(cut=c) with c - 1 outside [-T, T-1]: the reference raises IndexError
+    (np.take_along_axis); fused and unfused paths agree on that."""
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((4, 1, 50))
+    for cut in (51, 1000, [-130, -120]):
+        with pytest.raises(IndexError):
+            fr.sieving.END(cut=cut).fit_transform(X[:, 0, :])
+        fruit = fr.Fruit()
+        fruit.add(fr.ISS([fr.words.SimpleWord("[1]")]), fr.sieving.END(cut=cut))
+        fruit.fit(X)
+        with pytest.raises(IndexError):
+            fruit.transform(X)
+    # the extremes the reference accepts
+    ref = X[:, 0, :].cumsum(axis=1)
+    fruit = fr.Fruit()
+    fruit.add(fr.ISS([fr.words.SimpleWord("[1]")]), fr.sieving.END(cut=[50, 1, -50, -1]))
+    fruit.fit(X)
+    np.testing.assert_allclose(fruit.transform(X), ref[:, [0, 0, 49, 49]], rtol=1e-12)
+
+
 def test_coswiss_unsupported(fr):
     cw = fr.CosWISS([fr.words.SimpleWord("[1]")], [0.5], dropout=0.5)
     with pytest.raises(NotImplementedError):

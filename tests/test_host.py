@@ -46,6 +46,19 @@ def test_no_cpu_fallback():
         fr.semiring.Reals().iterated_sum_fast(X, np.array([[1]], np.int32), None, None, 1, True)
 
 
+def test_end_cut_validation_is_host_side():
+    """Integer END cuts are validated before anything touches a device (the reference
+    raises IndexError from np.take_along_axis, fruits/sieving/segment.py:213-218)."""
+    for cut, T, ok in [(-1, 10, True), (10, 10, True), (1, 10, True), (-10, 10, True),
+                       (11, 10, False), (-12, 10, True), (0, 10, True), ([-30, -25], 10, False)]:
+        sv = fr.sieving.END(cut=cut)
+        if ok:
+            sv._int_cut_row(T)
+        else:
+            with pytest.raises(IndexError):
+                sv._int_cut_row(T)
+
+
 def test_no_oracle_import_in_product():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "fruits_amd")):
         for f in files:
