@@ -15,7 +15,8 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfruits_hip.so")
+# FRUITS_HIP_LIB: an experiment build of the same sources (fruits_amd.build --variant=...)
+LIB_PATH = os.path.join(_HERE, os.environ.get("FRUITS_HIP_LIB", "libfruits_hip.so"))
 
 FR_W_NONE, FR_W_NONTOTAL, FR_W_TOTAL = 0, 1, 2
 FR_SIEVE_NPI, FR_SIEVE_MPI, FR_SIEVE_END = 0, 1, 2

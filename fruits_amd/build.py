@@ -74,16 +74,29 @@ def needs_build() -> bool:
     return any(os.path.getmtime(s) > t for s in srcs) or _newest_header() > t
 
 
-def build_native(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
+def build_native(force: bool = False, verbose: bool = False, jobs: int = 0,
+                 variant: str = "", defines=()) -> str:
+    """``variant`` / ``defines``: an experiment library next to the product one
+    (``libfruits_hip.<variant>.so``, selected at run time with FRUITS_HIP_LIB), built
+    with extra ``-D`` flags; its objects carry the variant in their names."""
+    if variant:
+        return _build(LIB[:-3] + f".{variant}.so", f"v{variant}", list(defines), True, verbose, jobs)
     if not force and not needs_build():
         return LIB
+    tag = "t" if os.environ.get("FRUITS_HIP_TIMING_BUILD") else "p"
+    lib = _build(LIB, tag, [], force, verbose, jobs)
+    with open(STAMP, "w") as f:
+        f.write(build_tag() + "\n")
+    return lib
+
+
+def _build(lib_path: str, tag: str, defines, force: bool, verbose: bool, jobs: int) -> str:
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
-             "-Wno-unused-function"]
+             "-Wno-unused-function"] + [f"-D{d}" for d in defines]
     if os.environ.get("FRUITS_HIP_TIMING_BUILD"):
         flags.append("-DFRUITS_HIP_TIMING_BUILD")
-    tag = "t" if os.environ.get("FRUITS_HIP_TIMING_BUILD") else "p"
     hdr_t = _newest_header()
 
     def compile_one(unit):
@@ -102,15 +115,20 @@ def build_native(force: bool = False, verbose: bool = False, jobs: int = 0) -> s
     jobs = jobs or min(8, os.cpu_count() or 1)
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(compile_one, units()))
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
-    with open(STAMP, "w") as f:
-        f.write(build_tag() + "\n")
-    return LIB
+    os.replace(lib_path + ".tmp", lib_path)
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build_native(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    variant, defines = "", []
+    for arg in sys.argv[1:]:
+        if arg.startswith("--variant="):
+            variant = arg.split("=", 1)[1]
+        elif arg.startswith("-D"):
+            defines.append(arg[2:])
+    print(build_native(force="--force" in sys.argv, verbose="-v" in sys.argv, variant=variant,
+                       defines=defines))

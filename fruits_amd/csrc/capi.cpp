@@ -7,6 +7,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/fruits_hip.h"
@@ -203,6 +204,118 @@ LaunchShape launch_shape(const fr::Plan &p, int64_t N, int64_t T, int requested_
   return s;
 }
 
+// LDS carry slots of a multi-chunk walk: 3 per record of the program (nodes + one sentinel
+// per group); sized for up to kSpanGroupsMax groups so that the kernel's LDS footprint -
+// and with it the number of resident workgroups the group choice is made for - does not
+// depend on the choice itself
+constexpr int kSpanGroupsMax = 12;
+int carry_slots_for(const fr::Plan &p, int G) {
+  return 3 * ((int)p.nodes.size() + std::max(G, kSpanGroupsMax));
+}
+bool carries_fit_lds(const fr::Plan &p, int64_t T, int G) {
+  // rows + carries must leave room for >= 4 workgroups per CU (160 KiB LDS)
+  const size_t rows_bytes = (size_t)p.rows_staged() * fr::walk_chunk_elems(T) * 8;
+  return env_int("FRUITS_HIP_LDS_CARRY", 1) != 0 &&
+         rows_bytes + (size_t)carry_slots_for(p, G) * 8 <= 40 * 1024;
+}
+
+// Resident workgroups of the cooperative walk kernel instance that (plan, T, fused,
+// vec_ok) selects: a dry run of the launcher (nothing is enqueued).
+int64_t query_resident(const fr::Plan &p, int64_t N, int64_t T, bool fused, bool vec_ok) {
+  if (env_int("FRUITS_HIP_PERSIST", 1) == 0) return 0;
+  fr::IssArgs a{};
+  int32_t resident = 0;
+  double *const dummy = reinterpret_cast<double *>(uintptr_t(256));  // never dereferenced
+  a.N = N;
+  a.D = std::max(1, p.max_dim);
+  a.T = T;
+  a.G = 1;
+  a.R = p.rows_staged();
+  a.total_nodes = (int32_t)p.nodes.size();
+  a.aux = p.weighting != 0 ? dummy : nullptr;
+  a.carry = T > fr::walk_chunk_elems(T) ? dummy : nullptr;
+  a.vec_ok = vec_ok ? 1 : 0;
+  a.persistent = 1;
+  a.semiring = p.semiring;
+  a.carry_slots = carry_slots_for(p, 1);
+  a.carry_in_lds = carries_fit_lds(p, T, 1) ? 1 : 0;
+  a.feats = fused ? dummy : nullptr;
+  a.resident_out = &resident;
+  if (fr::launch_iss_walk(a, p.levels, nullptr) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return resident;
+}
+
+// Groups per series for the contiguous-span schedule of the cooperative kernel (walk.h):
+// workgroup b of `grid` walks units [b*M/grid, (b+1)*M/grid) of the M = N*G units
+// (series-major).  Picks the G whose most loaded span is lightest, counting a staging of a
+// series' rows as kStageCost nodes.  Caller holds p.mu (grouped() fills the plan's cache).
+int choose_groups_spans(fr::Plan &p, int64_t N, int64_t resident) {
+  const int U = p.units();
+  if (U <= 1 || N <= 0) return 1;
+  if (resident <= 0) return choose_groups(p, N, 0);
+  const auto key = std::make_pair(N, resident);
+  auto it = p.span_choice.find(key);
+  if (it != p.span_choice.end()) return it->second;
+  constexpr double kStageCost = 2.0;
+  int best = 1;
+  double best_t = 1e300;
+  for (int G = 1; G <= std::min(U, kSpanGroupsMax); ++G) {
+    const fr::GroupedProgram &gp = fr::grouped(p, G);
+    std::vector<double> pre(G + 1, 0.0);
+    for (int g = 0; g < G; ++g)
+      pre[g + 1] = pre[g] + (double)(gp.group_begin[g + 1] - gp.group_begin[g] - 1);
+    const int64_t M = N * G, grid = std::min<int64_t>(resident, M);
+    auto F = [&](int64_t u) { return (double)(u / G) * pre[G] + pre[u % G]; };
+    double worst = 0.0;
+    for (int64_t b = 0; b < grid; ++b) {
+      const int64_t u0 = M * b / grid, u1 = M * (b + 1) / grid;
+      if (u1 <= u0) continue;
+      const double t = F(u1) - F(u0) + kStageCost * (double)((u1 - 1) / G - u0 / G + 1);
+      worst = std::max(worst, t);
+    }
+    worst *= 1.0 + 0.01 * (G - 1);  // ties: fewer groups (less restaging, less scalar work)
+    if (worst < best_t - 1e-9) {
+      best_t = worst;
+      best = G;
+    }
+  }
+  p.span_choice[key] = best;
+  return best;
+}
+
+// One-time uploads for every node order a run of this (N, T, groups) may ask for: the
+// group choice depends on the kernel instance (fused or not, 16-byte aligned or not),
+// which is only known when the pointers are.
+int prepare_plan(fr::Plan &p, int64_t N, int64_t T, int32_t groups, bool fused, const char *who) {
+  std::lock_guard<std::mutex> lock(p.mu);
+  if (p.cos) return ensure_cos_program(p, *p.cos, nullptr, who);
+  if (N == 0 || T == 0 || p.K == 0 || p.nodes.empty()) return FR_OK;
+  const LaunchShape shape = launch_shape(p, N, T, groups);
+  if (!shape.fits)
+    return fail(FR_E_LIMIT, std::string(who) + ": the plan stages " +
+                                std::to_string(p.rows_staged()) +
+                                " rows per time chunk, more than the LDS holds - split the word list");
+  std::vector<int> Gs;
+  const bool spans = !shape.packed && groups <= 0 && env_int("FRUITS_HIP_GROUPS", 0) <= 0;
+  if (spans) {
+    Gs.push_back(choose_groups_spans(p, N, query_resident(p, N, T, fused, true)));
+    if (!fused) Gs.push_back(choose_groups_spans(p, N, query_resident(p, N, T, false, false)));
+  } else {
+    Gs.push_back(shape.G);
+  }
+  // the opt-in wave-per-row kernel (FRUITS_HIP_TEAM=1) always walks 4 groups
+  if (!fused && env_int("FRUITS_HIP_TEAM", 0) == 1 && groups <= 0 && p.units() >= 4)
+    Gs.push_back(4);
+  for (int G : Gs) {
+    int rc = ensure_device_program(p, fr::grouped(p, G), nullptr, who);
+    if (rc != FR_OK) return rc;
+  }
+  return FR_OK;
+}
+
 struct WorkLayout {
   size_t aux_bytes = 0, carry_bytes = 0;
   size_t total() const { return aux_bytes + carry_bytes; }
@@ -370,20 +483,7 @@ int32_t fr_plan_fits(const fr_plan_t *plan, int64_t T) {
 
 int fr_plan_prepare(fr_plan_t *plan, int64_t N, int64_t T, int32_t groups) {
   if (!plan || !plan->p || N < 0 || T < 0) return fail(FR_E_ARG, "fr_plan_prepare: bad argument");
-  fr::Plan &p = *plan->p;
-  std::lock_guard<std::mutex> lock(p.mu);
-  if (p.cos) return ensure_cos_program(p, *p.cos, nullptr, "fr_plan_prepare");
-  if (N == 0 || T == 0 || p.K == 0 || p.nodes.empty()) return FR_OK;
-  const LaunchShape shape = launch_shape(p, N, T, groups);
-  if (!shape.fits)
-    return fail(FR_E_LIMIT, "fr_plan_prepare: the plan stages " + std::to_string(p.rows_staged()) +
-                                " rows per time chunk, more than the LDS holds - split the word list");
-  int rc = ensure_device_program(p, fr::grouped(p, shape.G), nullptr, "fr_plan_prepare");
-  if (rc != FR_OK) return rc;
-  // the opt-in wave-per-row kernel (FRUITS_HIP_TEAM=1) always walks 4 groups
-  if (env_int("FRUITS_HIP_TEAM", 0) == 1 && groups <= 0 && p.units() >= 4 && shape.G != 4)
-    rc = ensure_device_program(p, fr::grouped(p, 4), nullptr, "fr_plan_prepare");
-  return rc;
+  return prepare_plan(*plan->p, N, T, groups, false, "fr_plan_prepare");
 }
 
 }  // extern "C"
@@ -484,10 +584,12 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
                                 std::to_string(p.alphas.size()) +
                                 " distinct alphas), more than the LDS holds - split the word list");
   const bool packed = !wave_rows && shape.packed;
-  const int G = wave_rows ? 4 : shape.G;
+  const bool spans = !wave_rows && !packed && groups <= 0 && env_int("FRUITS_HIP_GROUPS", 0) <= 0;
+  const int64_t resident = spans ? query_resident(p, N, T, fu != nullptr, vec_ok_pre) : 0;
   fr::GroupedProgram *gpp = nullptr;
   {
     std::lock_guard<std::mutex> lock(p.mu);
+    const int G = wave_rows ? 4 : (spans ? choose_groups_spans(p, N, resident) : shape.G);
     gpp = &fr::grouped(p, G);   // (map nodes are stable: the reference outlives the lock)
     int rc = ensure_device_program(p, *gpp, st, who);
     if (rc != FR_OK) return rc;
@@ -523,7 +625,6 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   }
   if (wl.carry_bytes) a.carry = reinterpret_cast<double *>(work + wl.aux_bytes);
   a.vec_ok = vec_ok_pre && (!a.aux || aligned16(a.aux));
-  a.xcd_map = (a.G > 1 && N % 8 == 0) ? 1 : 0;
   a.debug = env_int("FRUITS_HIP_DEBUG", 0);
   if (a.debug & 16) {
     // diagnostic build only: stamps go to the tail of the workspace if the caller
@@ -537,18 +638,10 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   a.packed = packed ? 1 : 0;
   a.prefetch_next = env_int("FRUITS_HIP_PREFETCH", 24);  // longest unit (nodes) that prefetches; 0: off
   a.semiring = p.semiring;
-  {
-    int max_nodes = 0;
-    for (size_t g = 0; g + 1 < gp.group_begin.size(); ++g)
-      max_nodes = std::max(max_nodes, gp.group_begin[g + 1] - gp.group_begin[g]);
-    a.carry_slots = 3 * max_nodes;
-    // rows + carries must leave room for >= 4 workgroups per CU (160 KiB LDS)
-    const size_t rows_bytes = (size_t)a.R * fr::walk_chunk_elems(T) * 8;
-    a.carry_in_lds = (env_int("FRUITS_HIP_LDS_CARRY", 1) != 0 &&
-                      rows_bytes + (size_t)a.carry_slots * 8 <= 40 * 1024)
-                         ? 1
-                         : 0;
-  }
+  a.k_stride_bytes32 = (out_k_stride > 0 && out_k_stride < (int64_t(1) << 29))
+                           ? (uint32_t)(out_k_stride * 8) : 0u;
+  a.carry_slots = carry_slots_for(p, gp.groups);
+  a.carry_in_lds = carries_fit_lds(p, T, gp.groups) ? 1 : 0;
   if (fu) {
     a.ops = fu->ops;
     a.feats = fu->feats;
@@ -777,7 +870,7 @@ int fr_pipeline_prepare(fr_pipeline_t *pl, int64_t N, int32_t groups) {
     return fail(FR_E_ARG, "fr_pipeline_prepare: bad argument");
   if (!pl->have_quantiles)
     return fail(FR_E_ARG, "fr_pipeline_prepare: call fr_pipeline_set_quantiles first");
-  return fr_plan_prepare(pl->plan, N, pl->T, groups);
+  return prepare_plan(*pl->plan->p, N, pl->T, groups, true, "fr_pipeline_prepare");
 }
 
 int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, int64_t T,

@@ -43,9 +43,9 @@ struct IssArgs {
   int32_t total_nodes;
   int32_t vec_ok;           // 16-byte accesses are aligned
   int32_t nchunks;
-  int32_t xcd_map;
+  int32_t xcd_map;          // (unused since the contiguous-span schedule)
   int32_t persistent;       // grid = one resident round of workgroups
-  int32_t carry_slots;      // 3 * (largest group's node count): LDS carry slots
+  int32_t carry_slots;      // 3 * (records of the program): LDS carry slots
   int32_t carry_in_lds;     // multi-chunk carries fit in LDS
   int32_t semiring;         // kSemiReals / kSemiArctic
   int32_t prefetch_next;    // units of at most this many nodes touch the next unit's rows (0: off)
@@ -63,6 +63,9 @@ struct IssArgs {
   const int32_t *cw_letter_begin;
   const int32_t *cw_fac_begin;
   int32_t cw_W, cw_F, cw_total;
+  uint32_t k_stride_bytes32; // out_k_stride * 8 when that fits 32 bits (and is > 0), else 0
+  int32_t *resident_out;    // HOST pointer; non-null: the launcher stores the number of resident
+                            // workgroups of the kernel it would launch there and launches nothing
   unsigned long long *dbg;  // diagnostic stamps (timing build only)
   int32_t debug;            // timing experiments (FRUITS_HIP_DEBUG), 0 in production
 };

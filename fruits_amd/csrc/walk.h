@@ -184,6 +184,11 @@ __device__ __forceinline__ void block_scan(WalkCtx &cx, const double (&s)[C::EP]
     STAMP(cx, 2);  // local sums + wave scans
     double *tot = cx.tot + cx.buf * NW;
     if (cx.lane == 0) tot[cx.wave] = wave_total;
+#ifdef FRUITS_HIP_TIMING_BUILD
+    if (cx.a->debug & 32)  // timing experiments only: the cost of the rendezvous itself
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else
+#endif
     lds_barrier();
     STAMP(cx, 3);  // LDS write + barrier
     // exclusive prefix of the wave totals
@@ -229,19 +234,32 @@ __device__ __forceinline__ void emit_store(const WalkCtx &cx, const double (&v)[
                                            double *dst) {
   constexpr int E = C::E, P = C::P;
   const int64_t T = cx.a->T;
+#ifdef FRUITS_HIP_TIMING_BUILD
+  // timing experiments only: keep the arithmetic alive, drop the stores
+  if ((cx.a->debug & 1) && v[0] != 1.2345678e300) return;
+#endif
+  if constexpr (C::VEC) {
+    if (cx.full_chunk) {
+      // the common case, decided once per chunk: no per-lane bounds checks (each would
+      // cost an exec-mask save / branch / restore around every store)
+#pragma unroll
+      for (int h = 0; h < P; ++h) {
+        const int idx = cx.wave * C::SPAN + h * C::PIECE + cx.lane * E;
+#pragma unroll
+        for (int e = 0; e < E; e += 2)
+          *reinterpret_cast<vd2 *>(dst + idx + e) = vd2{v[h * E + e], v[h * E + e + 1]};
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int h = 0; h < P; ++h) {
     const int idx = cx.wave * C::SPAN + h * C::PIECE + cx.lane * E;
-#ifdef FRUITS_HIP_TIMING_BUILD
-    // timing experiments only: keep the arithmetic alive, drop the stores
-    if ((cx.a->debug & 1) && v[h * E] != 1.2345678e300) continue;
-#endif
     if constexpr (C::VEC) {
 #pragma unroll
       for (int e = 0; e < E; e += 2) {
         const vd2 val = {v[h * E + e], v[h * E + e + 1]};
-        if (cx.full_chunk || cx.t0 + idx + e < T)
-          *reinterpret_cast<vd2 *>(dst + idx + e) = val;
+        if (cx.t0 + idx + e < T) *reinterpret_cast<vd2 *>(dst + idx + e) = val;
       }
     } else {
 #pragma unroll
@@ -320,18 +338,28 @@ __device__ __forceinline__ void slow_factors(const WalkCtx &cx, int fac_begin, i
   }
 }
 
+// Address of output row k of the current series / chunk.  Rows are at most 4 GiB apart in
+// every layout the host code uses, so the byte offset is ONE 32 x 32 -> 64 bit scalar
+// multiply (the general 64 x 64 product costs ten scalar instructions per emitted row).
+__device__ __forceinline__ double *emit_ptr(const WalkCtx &cx, int k) {
+  const IssArgs &a = *cx.a;
+  if (a.k_stride_bytes32 != 0) {
+    const uint64_t off = (uint64_t)(uint32_t)k * (uint64_t)a.k_stride_bytes32;
+    return reinterpret_cast<double *>(reinterpret_cast<char *>(cx.out_base) + off);
+  }
+  return cx.out_base + (int64_t)k * a.out_k_stride;
+}
+
 template <class C>
 __device__ __forceinline__ void emit_all(const WalkCtx &cx, const Rec &nd,
                                          const double (&c)[C::EP]) {
   const IssArgs &a = *cx.a;
   const int ne = nd.emit_count();
-  if (ne > 0) emit_store<C>(cx, c, cx.out_base + (int64_t)nd.w[7] * a.out_k_stride);
+  if (ne > 0) emit_store<C>(cx, c, emit_ptr(cx, nd.w[7]));
   if (ne > 1) {
-    emit_store<C>(cx, c, cx.out_base + (int64_t)nd.w[8] * a.out_k_stride);
-    for (int j = kRecInlineEmits; j < ne; ++j) {
-      const int64_t k = as_const(a.emit_rows)[nd.emit_begin() + j];
-      emit_store<C>(cx, c, cx.out_base + k * a.out_k_stride);
-    }
+    emit_store<C>(cx, c, emit_ptr(cx, nd.w[8]));
+    for (int j = kRecInlineEmits; j < ne; ++j)
+      emit_store<C>(cx, c, emit_ptr(cx, as_const(a.emit_rows)[nd.emit_begin() + j]));
   }
 }
 
@@ -560,13 +588,14 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd, int slo
   if (need1) {
     double c[EP], x[EP];
     block_scan<C>(cx, s, c, x, slot);
-    if (has_children && !need2) {
-      // Reals: children start from the exclusive shift (strictly increasing indices);
-      // Arctic: from the inclusive maximum (semiring.py:282-338 has no shift).  Taken
-      // BEFORE the emitted values are rescaled in place below.
+    // Reals: children start from the exclusive shift (strictly increasing indices);
+    // Arctic: from the inclusive maximum (semiring.py:282-338 has no shift).  Taken
+    // BEFORE the emitted values are rescaled in place below.  Written whether or not
+    // the node has children (a leaf's frame is never read: its next sibling starts from
+    // the frame below, and a second scan - need2 - overwrites it): a conditional
+    // hand-over compiles to a select per register.
 #pragma unroll
-      for (int i = 0; i < EP; ++i) pout[i] = C::SEMI == 0 ? x[i] : c[i];
-    }
+    for (int i = 0; i < EP; ++i) pout[i] = C::SEMI == 0 ? x[i] : c[i];
     if (nd.emit_count() > 0) {
       // total weighting: Reals emit c * exp(-g alpha_k), Arctic emit c - g alpha_k
       if (C::WEIGHTED && emit_mul >= 0)
@@ -658,9 +687,21 @@ __device__ __forceinline__ void walk(WalkCtx &cx, Rec &cur, int &pc,
   }
 }
 
+// WALK_SPILL_LV: fused kernels with at least this many register levels are built for three
+// waves per SIMD (<= 168 VGPRs, no scratch) instead of four (128 VGPRs, the deepest frames
+// spill 20-92 bytes per lane).  Measured (fruits_amd.build --variant, one process per arm,
+// interleaved, r02h): four waves WITH the spills are faster - config 4 (6 levels) 23.9 vs
+// 27.8 ms, config 5 (8 levels, 4 chunks) 42.0 vs 49.5 ms - so the default keeps four waves.
+#ifndef WALK_SPILL_LV
+#define WALK_SPILL_LV 99
+#endif
 // The fused kernels for 1024-element chunks sit just above 128 VGPRs; at least 4 waves
 // per SIMD (<= 128 VGPRs) is worth the compiler's effort there.
-#if defined(WALK_MODE) && WALK_MODE == 1
+#if defined(WALK_MODE) && WALK_MODE == 1 && defined(WALK_LV) && WALK_LV >= WALK_SPILL_LV
+// deep tries: 8 VGPRs per register frame on top of the epilogue - three waves per SIMD
+// (<= 168 VGPRs) hold them without scratch
+#define WALK_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(3)))
+#elif defined(WALK_MODE) && WALK_MODE == 1
 #define WALK_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(4)))
 #else
 #define WALK_KERNEL_ATTR
@@ -685,8 +726,6 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
   cx.buf = 0;
   cx.tail_buf = 0;
   double *rows_w = lds;
-  // TEAM = 1: a unit is a series, its G = TEAMS groups go to the 4 waves
-  const int64_t units = C::TEAM == 1 ? a.N : a.N * a.G;
   bool first_unit = true;
 #ifdef FRUITS_HIP_TIMING_BUILD
   if (a.debug & 4) return;
@@ -695,12 +734,18 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
   const unsigned long long t_begin = cx.last;
   const unsigned long long real_begin = __builtin_amdgcn_s_memrealtime();  // 100 MHz, global
 #endif
-  // Persistent workgroups: the grid holds one resident round of workgroups and
-  // each walks units b, b + grid, ...  A unit is (series n, group g of sub-tries).
-  // Workgroups are dealt round-robin over the 8 XCDs and the grid is a multiple
-  // of 8, so with the mapping below all groups of one series meet in one XCD's
-  // L2 (speed only, never correctness).
-  int sink = 0;  // next-unit prefetch (see below): one word per 128-byte line of the rows
+  // Persistent workgroups: the grid holds (at most) one resident round of workgroups.
+  // A unit is (series n, group g of root sub-tries), numbered u = n * G + g, and
+  // workgroup b walks the CONTIGUOUS span [b * units / grid, (b + 1) * units / grid):
+  // every workgroup gets the same number of units (the host picks G so that the spans
+  // are balanced in nodes), the groups of one series that fall into a span share ONE
+  // staging of its rows, and a span that crosses into the next series restages in the
+  // middle of its work, when the other workgroups of the CU cover the read latency -
+  // not in a thin last round with nothing to hide behind (the strided schedule left
+  // 2048 units on 1536 resident workgroups with a 1/3-full second round that cost as
+  // much as half a full one).  TEAM = 1: a unit is a series, its G = TEAMS groups go
+  // to the 4 waves, strided over the grid.
+  int sink = 0;  // next-series prefetch (see below): one word per 128-byte line of the rows
   int pf_val = 0, pf_off = -1;
   if constexpr (C::TEAM != 1 && C::MODE == 0) {
     const int lines = (int)((a.T * 8 + 127) >> 7);
@@ -710,26 +755,38 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
       if (src >= 0) pf_off = src * (int)a.T + line * 16;
     }
   }
-  for (int64_t u = blockIdx.x; u < units; u += gridDim.x) {
+  int u, u_end, u_step;  // (the host checks N * G < 2^31)
+  if constexpr (C::TEAM == 1) {
+    u = blockIdx.x;
+    u_end = (int)a.N;
+    u_step = gridDim.x;
+  } else {
+    const int64_t units = a.N * a.G;
+    u = (int)((units * (int64_t)blockIdx.x) / (int64_t)gridDim.x);
+    u_end = (int)((units * ((int64_t)blockIdx.x + 1)) / (int64_t)gridDim.x);
+    u_step = 0;  // advanced by the groups walked per series
+  }
+  while (u < u_end) {
     int64_t n;
-    int g;
+    int g0, g1;  // groups [g0, g1) of series n
     if constexpr (C::TEAM == 1) {
       n = u;
-      g = cx.team;
-    } else if (a.xcd_map) {
-      const int64_t q = u >> 3, r = u & 7;
-      n = (q / a.G) * 8 + r;
-      g = (int)(q % a.G);
+      g0 = cx.team;
+      g1 = g0 + 1;
     } else {
-      n = u / a.G;
-      g = (int)(u % a.G);
+      const int ni = u / a.G;
+      n = ni;
+      g0 = u - ni * a.G;
+      const int series_end = (ni + 1) * a.G;
+      g1 = g0 + ((series_end < u_end ? series_end : u_end) - u);
+      u_step = g1 - g0;
     }
+    const int node_begin = as_const(a.group_begin)[g0];
     if constexpr (C::MULTI == 1)
       cx.carry = lds + (int64_t)a.R * C::CHUNK + 4 * C::NW;
     else
       cx.carry = a.carry ? a.carry + n * (kCarrySlots * (int64_t)a.total_nodes) : nullptr;
-    const int node_begin = as_const(a.group_begin)[g];
-    cx.pc_begin = node_begin;
+    cx.pc_begin = node_begin;  // LDS carry slots are indexed from the span's first record
     for (int64_t chunk = 0; chunk < a.nchunks; ++chunk) {
       const int64_t t0 = chunk * C::CHUNK;
       cx.t0 = t0;
@@ -784,38 +841,31 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
       __syncthreads();
       if constexpr (C::TEAM != 1 && C::MODE == 0) {
         if (a.prefetch_next && a.nchunks == 1) {
-          // Touch one word per 128-byte line of the rows of this workgroup's NEXT unit, so
+          // Touch one word per 128-byte line of the rows of the NEXT series of this span, so
           // that its staging - issued when the memory system is full of this kernel's
           // stores - finds them in the L2 / Infinity Cache.  The loaded value is only
           // consumed behind the next staging wait (no extra stall).
           sink += pf_val;
           pf_val = 0;
-          const int64_t un = u + gridDim.x;
-          // (lines touched a whole long unit ahead are evicted before they are used:
-          // units of more than prefetch_next nodes do not prefetch)
-          const int n_rec = as_const(a.group_begin)[g + 1] - node_begin;
-          if (un < units && n_rec <= a.prefetch_next) {
-            int64_t n2;
-            if (a.xcd_map) {
-              const int64_t q = un >> 3, r = un & 7;
-              n2 = (q / a.G) * 8 + r;
-            } else {
-              n2 = un / a.G;
-            }
-            if (pf_off >= 0)
-              pf_val = *reinterpret_cast<const int *>(a.X + n2 * a.D * a.T + pf_off);
-          }
+          // (lines touched a long walk ahead are evicted before they are used: walks of
+          // more than prefetch_next nodes do not prefetch)
+          const int n_rec = as_const(a.group_begin)[g1] - node_begin;
+          if (u + u_step < u_end && n_rec <= a.prefetch_next && pf_off >= 0)
+            pf_val = *reinterpret_cast<const int *>(a.X + (n + 1) * a.D * a.T + pf_off);
         }
       }
       STAMP(cx, 6);  // staging
       double ones[C::EP];  // identity of the semiring's product: 1 (Reals, Bayesian), 0 (Arctic)
 #pragma unroll
       for (int i = 0; i < C::EP; ++i) ones[i] = C::SEMI != 1 ? 1.0 : 0.0;
-      int pc = node_begin;
-      Rec cur = load_rec(a.recs, pc);
-      walk<C, 0>(cx, cur, pc, ones);
+      for (int g = g0; g < g1; ++g) {
+        int pc = as_const(a.group_begin)[g];
+        Rec cur = load_rec(a.recs, pc);
+        walk<C, 0>(cx, cur, pc, ones);
+      }
     }
     first_unit = false;
+    u += u_step;
   }
   if (sink + pf_val == 0x7fffffff) a.out[0] = (double)sink;  // keeps the prefetch loads alive
 #ifdef FRUITS_HIP_TIMING_BUILD
@@ -845,13 +895,19 @@ static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
                              a.persistent ? &per_cu : nullptr);
   if (e != hipSuccess) return e;
   const int64_t units = TEAM == 1 ? a.N : a.N * a.G;
+  if (units > 0x7fffffffLL) return hipErrorInvalidValue;  // unit indices are 32-bit in the kernel
   int64_t blocks = units;
   if (a.persistent) {
-    // one resident round of workgroups (a multiple of 8 for the XCD mapping)
-    int64_t resident = (int64_t)per_cu * device_cu_count();
-    resident -= resident % 8;
-    if (resident < 8) resident = 8;
+    // at most one resident round of workgroups; each walks a contiguous span of units
+    const int64_t resident = (int64_t)per_cu * device_cu_count();
+    if (a.resident_out != nullptr) {  // the host only asks how many workgroups are resident
+      *a.resident_out = (int32_t)resident;
+      return hipSuccess;
+    }
     if (blocks > resident) blocks = resident;
+  } else if (a.resident_out != nullptr) {
+    *a.resident_out = 0;
+    return hipSuccess;
   }
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(iss_walk_kernel<C>, dim3((unsigned)blocks), dim3(kWalkThreads), lds, st, a);

@@ -1,0 +1,16 @@
+#!/bin/bash
+# usage: bash tools/gpu_quick.sh <tag> : parity suite + headline A/B + short bench
+export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/$1; mkdir -p $O
+python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; rc=$?
+tail -4 $O/pytest.log
+[ $rc -ne 0 ] && exit $rc
+V='[{"FRUITS_HIP_GROUPS":0},{"FRUITS_HIP_GROUPS":1},{"FRUITS_HIP_GROUPS":3}]'
+for shape in 2048,3,1024 8192,3,1024; do
+  echo "== shape $shape" | tee -a $O/ab.log
+  TUNE_SHAPE=$shape python tools/tune2.py "$V" 2>&1 | grep -v amdgpu.ids | tee -a $O/ab.log
+done
+python bench.py --quick-extras --no-cpu-baseline > $O/bench.json 2> $O/bench.err || tail -5 $O/bench.err
+python -c "
+import json;d=json.load(open('$O/bench.json'));print(d['roofline']['kernel_avg_us'], d['roofline']['frac'], d['roofline']['batches'], d['extras']['words48_single'], d['extras']['config3_fused_pipeline']['launch_us'])"
