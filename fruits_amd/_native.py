@@ -34,6 +34,7 @@ EXPORTS = [
     "fr_pipeline_workspace_bytes", "fr_pipeline_run", "fr_pipeline_set_quantiles",
     "fr_select_ranks", "fr_coswiss_combine", "fr_plan_create_coswiss", "fr_nan_to_num",
     "fr_plan_prepare", "fr_pipeline_prepare", "fr_plan_fits", "fr_release_scratch",
+    "fr_pipeline_set_preparation",
 ]
 
 _lib = None
@@ -86,6 +87,8 @@ def lib():
     L.fr_plan_fits.argtypes = [C.c_void_p, C.c_int64]
     L.fr_plan_prepare.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32]
     L.fr_pipeline_prepare.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
+    L.fr_pipeline_set_preparation.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                              C.c_int32, C.c_double]
     _lib = L
     return L
 
@@ -338,6 +341,7 @@ class Pipeline:
             msg = last_error()
             raise (IndexError if "out of bounds" in msg else ValueError)(msg)
         self._h = C.c_void_p(h)
+        self.raw_dims = 0    # > 0: fused preparation, run() takes the raw input
         self.per_sum = int(L.fr_pipeline_info(self._h, 0))
         self.q_stride = int(L.fr_pipeline_info(self._h, 1))
         self.n_features = int(L.fr_pipeline_info(self._h, 2))
@@ -358,6 +362,20 @@ class Pipeline:
             raise ValueError("quantile table must be (K, q_stride)")
         check(lib().fr_pipeline_set_quantiles(self._h, q.ctypes.data_as(C.POINTER(C.c_double))),
               "fr_pipeline_set_quantiles")
+
+    def set_preparation(self, D: int, inc_lag: int = 0, as_new: bool = False,
+                        standardize: int = 0, std_eps: float = 1e-5) -> bool:
+        """fr_pipeline_set_preparation: ``run`` then takes the RAW (N, D, T) input and forms
+        INC / NEW(INC) / STD rows while staging.  False when this plan's kernel has no fused
+        staging (the caller keeps materialising the prepared input)."""
+        rc = lib().fr_pipeline_set_preparation(self._h, int(D), int(inc_lag), 1 if as_new else 0,
+                                               int(standardize), float(std_eps))
+        if rc == FR_E_LIMIT:
+            self.raw_dims = 0
+            return False
+        check(rc, "fr_pipeline_set_preparation")
+        self.raw_dims = int(D) if (inc_lag or standardize) else 0
+        return self.raw_dims > 0
 
     def prepare(self, N: int, groups: int = 0) -> None:
         """fr_pipeline_prepare: uploads the plan's tables for batches of N series so

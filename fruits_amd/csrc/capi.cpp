@@ -12,6 +12,7 @@
 
 #include "../../include/fruits_hip.h"
 #include "kernels.h"
+#include "launch_cache.h"
 #include "plan.h"
 
 struct fr_plan {
@@ -219,76 +220,24 @@ bool carries_fit_lds(const fr::Plan &p, int64_t T, int G) {
          rows_bytes + (size_t)carry_slots_for(p, G) * 8 <= 40 * 1024;
 }
 
-// Resident workgroups of the cooperative walk kernel instance that (plan, T, fused,
-// vec_ok) selects: a dry run of the launcher (nothing is enqueued).
-int64_t query_resident(const fr::Plan &p, int64_t N, int64_t T, bool fused, bool vec_ok) {
-  if (env_int("FRUITS_HIP_PERSIST", 1) == 0) return 0;
-  fr::IssArgs a{};
-  int32_t resident = 0;
-  double *const dummy = reinterpret_cast<double *>(uintptr_t(256));  // never dereferenced
-  a.N = N;
-  a.D = std::max(1, p.max_dim);
-  a.T = T;
-  a.G = 1;
-  a.R = p.rows_staged();
-  a.total_nodes = (int32_t)p.nodes.size();
-  a.aux = p.weighting != 0 ? dummy : nullptr;
-  a.carry = T > fr::walk_chunk_elems(T) ? dummy : nullptr;
-  a.vec_ok = vec_ok ? 1 : 0;
-  a.persistent = 1;
-  a.semiring = p.semiring;
-  a.carry_slots = carry_slots_for(p, 1);
-  a.carry_in_lds = carries_fit_lds(p, T, 1) ? 1 : 0;
-  a.feats = fused ? dummy : nullptr;
-  a.resident_out = &resident;
-  if (fr::launch_iss_walk(a, p.levels, nullptr) != hipSuccess) {
-    (void)hipGetLastError();
-    return 0;
-  }
-  return resident;
-}
-
 // Groups per series for the contiguous-span schedule of the cooperative kernel (walk.h):
-// workgroup b of `grid` walks units [b*M/grid, (b+1)*M/grid) of the M = N*G units
-// (series-major).  Picks the G whose most loaded span is lightest, counting a staging of a
-// series' rows as kStageCost nodes.  Caller holds p.mu (grouped() fills the plan's cache).
-int choose_groups_spans(fr::Plan &p, int64_t N, int64_t resident) {
+// a unit is (series, group of root sub-tries); every unit stages the series' rows again, so
+// groups only pay while the batch alone cannot fill the chip.  Measured on config 2
+// (tools/tune2.py, FRUITS_HIP_GROUPS = 1, 2, 3, 6, 9 against N = 64 ... 4096): the fastest
+// choice is the smallest G with N * G >= ~3 workgroups per CU (N = 64: G = 6, 256: 3,
+// 512: 2, >= 768: 1); with more units than that the extra stagings cost more than the
+// finer balance gains (N = 1000: G = 1 30.5 us, G = 2 35.6 us), and beyond one resident
+// round every choice is within 2.5 %.
+int choose_groups_spans(const fr::Plan &p, int64_t N) {
   const int U = p.units();
   if (U <= 1 || N <= 0) return 1;
-  if (resident <= 0) return choose_groups(p, N, 0);
-  const auto key = std::make_pair(N, resident);
-  auto it = p.span_choice.find(key);
-  if (it != p.span_choice.end()) return it->second;
-  constexpr double kStageCost = 2.0;
-  int best = 1;
-  double best_t = 1e300;
-  for (int G = 1; G <= std::min(U, kSpanGroupsMax); ++G) {
-    const fr::GroupedProgram &gp = fr::grouped(p, G);
-    std::vector<double> pre(G + 1, 0.0);
-    for (int g = 0; g < G; ++g)
-      pre[g + 1] = pre[g] + (double)(gp.group_begin[g + 1] - gp.group_begin[g] - 1);
-    const int64_t M = N * G, grid = std::min<int64_t>(resident, M);
-    auto F = [&](int64_t u) { return (double)(u / G) * pre[G] + pre[u % G]; };
-    double worst = 0.0;
-    for (int64_t b = 0; b < grid; ++b) {
-      const int64_t u0 = M * b / grid, u1 = M * (b + 1) / grid;
-      if (u1 <= u0) continue;
-      const double t = F(u1) - F(u0) + kStageCost * (double)((u1 - 1) / G - u0 / G + 1);
-      worst = std::max(worst, t);
-    }
-    worst *= 1.0 + 0.01 * (G - 1);  // ties: fewer groups (less restaging, less scalar work)
-    if (worst < best_t - 1e-9) {
-      best_t = worst;
-      best = G;
-    }
-  }
-  p.span_choice[key] = best;
-  return best;
+  const int64_t target = 3 * (int64_t)fr::device_cu_count();
+  int64_t G = (target + N - 1) / N;
+  G = std::min<int64_t>(G, std::min(U, kSpanGroupsMax));
+  return (int)std::max<int64_t>(G, 1);
 }
 
-// One-time uploads for every node order a run of this (N, T, groups) may ask for: the
-// group choice depends on the kernel instance (fused or not, 16-byte aligned or not),
-// which is only known when the pointers are.
+// One-time uploads for the node order a run of this (N, T, groups) asks for.
 int prepare_plan(fr::Plan &p, int64_t N, int64_t T, int32_t groups, bool fused, const char *who) {
   std::lock_guard<std::mutex> lock(p.mu);
   if (p.cos) return ensure_cos_program(p, *p.cos, nullptr, who);
@@ -300,12 +249,7 @@ int prepare_plan(fr::Plan &p, int64_t N, int64_t T, int32_t groups, bool fused, 
                                 " rows per time chunk, more than the LDS holds - split the word list");
   std::vector<int> Gs;
   const bool spans = !shape.packed && groups <= 0 && env_int("FRUITS_HIP_GROUPS", 0) <= 0;
-  if (spans) {
-    Gs.push_back(choose_groups_spans(p, N, query_resident(p, N, T, fused, true)));
-    if (!fused) Gs.push_back(choose_groups_spans(p, N, query_resident(p, N, T, false, false)));
-  } else {
-    Gs.push_back(shape.G);
-  }
+  Gs.push_back(spans ? choose_groups_spans(p, N) : shape.G);
   // the opt-in wave-per-row kernel (FRUITS_HIP_TEAM=1) always walks 4 groups
   if (!fused && env_int("FRUITS_HIP_TEAM", 0) == 1 && groups <= 0 && p.units() >= 4)
     Gs.push_back(4);
@@ -495,6 +439,10 @@ struct FusedArgs {          // non-null feats selects the fused sieve kernels
   double *feats = nullptr, *cnt = nullptr;
   int64_t feat_stride = 0;
   int32_t n_ops = 0, n_ops_padded = 0;
+  // fused preparation: d_X is the raw input, the staging forms the prepared rows
+  const int32_t *prep = nullptr;   // device (n_prep, 4) table
+  const double *stats = nullptr;   // device (N, n_prep, 2) or nullptr (no STD)
+  int32_t n_prep = 0;
 };
 
 // Shared body of fr_iss_run and fr_pipeline_run: validates, lays out the
@@ -505,9 +453,10 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
              hipStream_t st, const FusedArgs *fu) {
   const std::string w(who);
   if (N < 0 || D < 1 || T < 0) return fail(FR_E_ARG, w + ": bad shape");
-  if (p.max_dim > D)
+  const int64_t D_words = (fu && fu->prep) ? fu->n_prep : D;   // dimensions the words may name
+  if (p.max_dim > D_words)
     return fail(FR_E_DIM, w + ": a word references dimension " + std::to_string(p.max_dim) +
-                              " but the input has only " + std::to_string(D));
+                              " but the input has only " + std::to_string(D_words));
   if (N == 0 || T == 0 || p.K == 0 || (!p.cos && p.nodes.empty())) return FR_OK;
   if (!d_X || (!fu && !d_out)) return fail(FR_E_ARG, w + ": null device pointer");
   if (p.cos) {
@@ -585,11 +534,10 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
                                 " distinct alphas), more than the LDS holds - split the word list");
   const bool packed = !wave_rows && shape.packed;
   const bool spans = !wave_rows && !packed && groups <= 0 && env_int("FRUITS_HIP_GROUPS", 0) <= 0;
-  const int64_t resident = spans ? query_resident(p, N, T, fu != nullptr, vec_ok_pre) : 0;
   fr::GroupedProgram *gpp = nullptr;
   {
     std::lock_guard<std::mutex> lock(p.mu);
-    const int G = wave_rows ? 4 : (spans ? choose_groups_spans(p, N, resident) : shape.G);
+    const int G = wave_rows ? 4 : (spans ? choose_groups_spans(p, N) : shape.G);
     gpp = &fr::grouped(p, G);   // (map nodes are stable: the reference outlives the lock)
     int rc = ensure_device_program(p, *gpp, st, who);
     if (rc != FR_OK) return rc;
@@ -649,6 +597,13 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     a.feat_stride = fu->feat_stride;
     a.n_ops = fu->n_ops;
     a.n_ops_padded = fu->n_ops_padded;
+    if (fu->prep) {
+      if (packed || wave_rows)
+        return fail(FR_E_LIMIT, w + ": the fused preparation needs the cooperative kernel");
+      a.prep = fu->prep;
+      a.stats = fu->stats;
+      a.n_prep = fu->n_prep;
+    }
   }
   hipError_t e = fr::launch_iss_walk(a, p.levels, st);
   if (e != hipSuccess) return hip_fail(e, "iss_walk launch");
@@ -674,6 +629,10 @@ struct fr_pipeline {
   void *d_ops = nullptr;           // (K, n_ops_padded) FeatOp
   void *d_mpi_cols = nullptr;
   bool have_quantiles = false;
+  // fused preparation (fr_pipeline_set_preparation): 0 dims = none
+  int32_t prep_D = 0, prep_n = 0, prep_std = 0;
+  double prep_eps = 0.0;
+  void *d_prep = nullptr;          // (prep_n, 4) int32
 };
 
 extern "C" {
@@ -757,6 +716,7 @@ void fr_pipeline_destroy(fr_pipeline_t *pl) {
   if (pl->d_ops) (void)hipFree(pl->d_ops);
   if (pl->d_mpi_cols) (void)hipFree(pl->d_mpi_cols);
   if (pl->d_npi_pairs) (void)hipFree(pl->d_npi_pairs);
+  if (pl->d_prep) (void)hipFree(pl->d_prep);
   delete pl;
 }
 
@@ -862,7 +822,43 @@ int64_t fr_pipeline_workspace_bytes(const fr_pipeline_t *pl, int64_t N, int64_t 
   const fr::Plan &p = *pl->plan->p;
   size_t b = align_up(work_layout(p, N, pl->T, p.weighting ? lookup_rows : 0).total(), 256);
   if (!pl->mpi_cols.empty()) b += align_up((size_t)N * pl->per_sum * p.K * 8, 256);
+  if (pl->prep_n > 0 && pl->prep_std != 0) b += align_up((size_t)N * pl->prep_n * 16, 256);
   return (int64_t)b;
+}
+
+int fr_pipeline_set_preparation(fr_pipeline_t *pl, int32_t D, int32_t inc_lag, int32_t as_new,
+                                int32_t standardize, double std_eps) {
+  if (!pl || !pl->plan || !pl->plan->p || D < 1 || inc_lag < 0 || standardize < 0 ||
+      standardize > 2 || (as_new && inc_lag < 1))
+    return fail(FR_E_ARG, "fr_pipeline_set_preparation: bad argument");
+  const fr::Plan &p = *pl->plan->p;
+  if (pl->d_prep) (void)hipFree(pl->d_prep);
+  pl->d_prep = nullptr;
+  pl->prep_D = pl->prep_n = pl->prep_std = 0;
+  if (inc_lag == 0 && standardize == 0) return FR_OK;   // nothing to fuse
+  if (p.cos || launch_shape(p, 1 << 20, pl->T, 0).packed)
+    return fail(FR_E_LIMIT, "fr_pipeline_set_preparation: only the cooperative walk kernel "
+                            "(Reals / Arctic / Bayesian plans, T > 384) fuses the preparation");
+  const int n_prep = as_new ? 2 * D : D;
+  std::vector<int32_t> tab((size_t)n_prep * 4, 0);
+  for (int d = 0; d < n_prep; ++d) {
+    const bool inc_row = as_new ? d >= D : inc_lag > 0;
+    tab[4 * d] = as_new ? d % D : d;
+    tab[4 * d + 1] = inc_row ? inc_lag : 0;
+    tab[4 * d + 2] = standardize != 0 ? 1 : 0;
+  }
+  HIP_TRY(hipMalloc(&pl->d_prep, tab.size() * 4));
+  hipError_t e = hipMemcpy(pl->d_prep, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(pl->d_prep);
+    pl->d_prep = nullptr;
+    return hip_fail(e, "hipMemcpy(preparation table)");
+  }
+  pl->prep_D = D;
+  pl->prep_n = n_prep;
+  pl->prep_std = standardize;
+  pl->prep_eps = std_eps;
+  return FR_OK;
 }
 
 int fr_pipeline_prepare(fr_pipeline_t *pl, int64_t N, int32_t groups) {
@@ -901,10 +897,15 @@ int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, 
   if (!pl->mpi_cols.empty() && feat_stride != F)
     return fail(FR_E_ARG, "fr_pipeline_run: MPI needs feat_stride == F");
   if (N < 0 || D < 1 || !d_X) return fail(FR_E_ARG, "fr_pipeline_run: bad input");
-  if (p.max_dim > D)
+  if (pl->prep_n > 0 && D != pl->prep_D)
+    return fail(FR_E_ARG, "fr_pipeline_run: the fused preparation was set for " +
+                              std::to_string(pl->prep_D) + " raw dimensions, the input has " +
+                              std::to_string(D));
+  const int64_t D_words = pl->prep_n > 0 ? pl->prep_n : D;
+  if (p.max_dim > D_words)
     return fail(FR_E_DIM, "fr_pipeline_run: a word references dimension " +
                               std::to_string(p.max_dim) + " but the input has only " +
-                              std::to_string(D));
+                              std::to_string(D_words));
   if (p.weighting != 0 && !p.cos && (!d_lookup || (lookup_rows != 1 && lookup_rows != N)))
     return fail(FR_E_ARG, "fr_pipeline_run: weighted plan needs a lookup of 1 or N rows");
   // features accumulate with atomics: clear them (memset nodes, graph-capturable)
@@ -914,6 +915,20 @@ int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, 
     HIP_TRY(hipMemsetAsync(fu.cnt, 0, (size_t)N * F * 8, st));
   } else {
     fu.cnt = d_feats;  // never touched without MPI sieves
+  }
+  if (pl->prep_n > 0) {
+    fu.prep = static_cast<const int32_t *>(pl->d_prep);
+    fu.n_prep = pl->prep_n;
+    if (pl->prep_std != 0) {
+      // STD's statistics of the prepared rows: a small pre-pass over the raw input
+      size_t off = plan_ws;
+      if (!pl->mpi_cols.empty()) off += align_up((size_t)N * F * 8, 256);
+      double *stats = reinterpret_cast<double *>(static_cast<char *>(d_work) + off);
+      hipError_t e = fr::launch_row_stats(d_X, N, D, T, fu.prep, pl->prep_n,
+                                          pl->prep_std == 2 ? 1 : 0, pl->prep_eps, stats, st);
+      if (e != hipSuccess) return hip_fail(e, "row_stats launch");
+      fu.stats = stats;
+    }
   }
   int rc = run_walk("fr_pipeline_run", p, d_X, N, D, T, d_lookup, lookup_rows, nullptr, 0, 0,
                     d_work, (int64_t)plan_ws, groups, st, &fu);

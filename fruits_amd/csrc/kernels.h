@@ -64,8 +64,13 @@ struct IssArgs {
   const int32_t *cw_fac_begin;
   int32_t cw_W, cw_F, cw_total;
   uint32_t k_stride_bytes32; // out_k_stride * 8 when that fits 32 bits (and is > 0), else 0
-  int32_t *resident_out;    // HOST pointer; non-null: the launcher stores the number of resident
-                            // workgroups of the kernel it would launch there and launches nothing
+  // fused preparation (MODE 1 cooperative kernels): X is the RAW (N, D, T) input and the
+  // staging forms the prepared rows on the fly.  prep[4 * d'] for prepared dimension d':
+  // {raw dimension, increment lag (0: none), standardise (0 / 1), unused}; stats holds
+  // (N, n_prep, 2) = {mean, std + eps} of the prepared rows (written by row_stats_kernel)
+  const int32_t *prep;
+  const double *stats;
+  int32_t n_prep;
   unsigned long long *dbg;  // diagnostic stamps (timing build only)
   int32_t debug;            // timing experiments (FRUITS_HIP_DEBUG), 0 in production
 };
@@ -105,5 +110,7 @@ hipError_t launch_coswiss_combine(const double *A, int64_t N, int64_t T, int n_o
 hipError_t launch_nan_to_num(double *x, int64_t count, hipStream_t st);
 hipError_t launch_standardize(const double *X, int64_t rows, int64_t T, int div_std, double eps,
                               double *out, hipStream_t st);
+hipError_t launch_row_stats(const double *X, int64_t N, int64_t D, int64_t T, const int32_t *prep,
+                            int n_prep, int div_std, double eps, double *stats, hipStream_t st);
 
 }  // namespace fr

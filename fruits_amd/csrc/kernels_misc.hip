@@ -308,6 +308,51 @@ __global__ __launch_bounds__(256) void standardize_kernel(const double *__restri
   for (int64_t t = threadIdx.x; t < T; t += blockDim.x) o[t] = (x[t] - mean) / den;
 }
 
+// Statistics of the PREPARED rows for the fused preparation of the walk kernel (walk.h):
+// prepared dimension d' = prep[4 d'] (raw dimension), prep[4 d' + 1] (increment lag, 0 none).
+// Same passes and the same summation order as standardize_kernel over the materialised
+// rows, so the fused pipeline reproduces the unfused one bit for bit.
+// stats[(n * n_prep + d') * 2] = mean, [.. + 1] = std + eps (1 + eps when div_std == 0).
+__global__ __launch_bounds__(256) void row_stats_kernel(const double *__restrict__ X, int64_t D,
+                                                         int64_t T, const int32_t *__restrict__ prep,
+                                                         int n_prep, int div_std, double eps,
+                                                         double *__restrict__ stats) {
+  __shared__ double sm[4];
+  const int64_t n = blockIdx.x / n_prep;
+  const int dp = (int)(blockIdx.x % n_prep);
+  const int raw = prep[4 * dp], lag = prep[4 * dp + 1];
+  const double *x = X + (n * D + raw) * T;
+  auto value = [&](int64_t t) -> double {
+    if (lag <= 0) return x[t];
+    return t >= lag ? x[t] - x[t - lag] : 0.0;
+  };
+  double acc = 0.0;
+  for (int64_t t = threadIdx.x; t < T; t += blockDim.x) acc += value(t);
+  const double mean = block_reduce_sum(acc, sm) / (double)T;
+  double sd = 1.0;
+  if (div_std) {
+    double v = 0.0;
+    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
+      const double d = value(t) - mean;
+      v += d * d;
+    }
+    sd = sqrt(block_reduce_sum(v, sm) / (double)T);
+  }
+  if (threadIdx.x == 0) {
+    stats[(n * n_prep + dp) * 2] = mean;
+    stats[(n * n_prep + dp) * 2 + 1] = sd + eps;
+  }
+}
+
+hipError_t launch_row_stats(const double *X, int64_t N, int64_t D, int64_t T, const int32_t *prep,
+                            int n_prep, int div_std, double eps, double *stats, hipStream_t st) {
+  if (N <= 0 || T <= 0 || n_prep <= 0) return hipSuccess;
+  if (N * n_prep > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)(N * n_prep)), dim3(256), 0, st, X, D, T,
+                     prep, n_prep, div_std, eps, stats);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- rank selection (fit)
 // SegmentSieve._fit needs np.quantile of the pre-transformed fit sample
 // (fruits/sieving/segment.py:66-75, increment.py:73-74).  np.quantile interpolates

@@ -112,9 +112,7 @@ struct Plan {
   int dims_used = 0;
   std::map<int, GroupedProgram> programs;  // per G
   int device = -1;     // HIP device the uploaded tables live on (-1: nothing uploaded yet)
-  std::mutex mu;       // guards `programs`, `span_choice`, `cos->d_blob` and `device`
-  // groups per series chosen for (N, resident workgroups) by the span model (capi.cpp)
-  std::map<std::pair<int64_t, int64_t>, int> span_choice;
+  std::mutex mu;       // guards `programs`, `cos->d_blob` and `device` (uploads at run time)
 
   int units() const { return (int)unit_begin.size() - 1; }
   int rows_staged() const { return (int)row_src.size(); }

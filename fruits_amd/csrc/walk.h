@@ -737,14 +737,12 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
   // Persistent workgroups: the grid holds (at most) one resident round of workgroups.
   // A unit is (series n, group g of root sub-tries), numbered u = n * G + g, and
   // workgroup b walks the CONTIGUOUS span [b * units / grid, (b + 1) * units / grid):
-  // every workgroup gets the same number of units (the host picks G so that the spans
-  // are balanced in nodes), the groups of one series that fall into a span share ONE
-  // staging of its rows, and a span that crosses into the next series restages in the
-  // middle of its work, when the other workgroups of the CU cover the read latency -
-  // not in a thin last round with nothing to hide behind (the strided schedule left
-  // 2048 units on 1536 resident workgroups with a 1/3-full second round that cost as
-  // much as half a full one).  TEAM = 1: a unit is a series, its G = TEAMS groups go
-  // to the 4 waves, strided over the grid.
+  // every workgroup gets the same number of units (+-1), the groups of one series that
+  // fall into a span share ONE staging of its rows, and a span that crosses into the next
+  // series restages in the middle of its work, when the other workgroups of the CU cover
+  // the read latency.  The host keeps G = 1 unless the batch alone cannot fill the chip
+  // (capi.cpp, choose_groups_spans).  TEAM = 1: a unit is a series, its G = TEAMS groups
+  // go to the 4 waves, strided over the grid.
   int sink = 0;  // next-series prefetch (see below): one word per 128-byte line of the rows
   int pf_val = 0, pf_off = -1;
   if constexpr (C::TEAM != 1 && C::MODE == 0) {
@@ -810,19 +808,58 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
         for (int rr = 0; rr < kStageRows; ++rr) {
           if (r0 + rr < a.R) {
             const int src = as_const(a.row_src)[r0 + rr];
-            const double *gp =
-                src >= 0 ? a.X + (n * a.D + src) * a.T
-                         : a.aux + (int64_t)(-src - 1) * a.aux_tab_stride + n * a.aux_n_stride;
+            bool prepared = false;
+            if constexpr (C::MODE == 1 && C::TEAM != 1) {
+              if (a.prep != nullptr && src >= 0) {
+                // fused preparation: the row is formed from the RAW input while it is staged -
+                // INC (x[t] - x[t - lag], zero-padded: fruits/cache.py:8-13), NEW(INC) (the
+                // prepared dimension names a raw dimension and a lag) and STD's apply step
+                // ((x - mean) / (std + eps), fruits/preparation/transform.py:141-147; the
+                // statistics come from row_stats_kernel)
+                prepared = true;
+                const int raw = as_const(a.prep)[4 * src], lag = as_const(a.prep)[4 * src + 1];
+                const bool standardise = as_const(a.prep)[4 * src + 2] != 0;
+                const double *gp = a.X + (n * a.D + raw) * a.T;
+                double mean = 0.0, den = 1.0;
+                if (standardise) {
+                  mean = as_const(a.stats)[(n * a.n_prep + src) * 2];
+                  den = as_const(a.stats)[(n * a.n_prep + src) * 2 + 1];
+                }
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-              const int i = 2 * (k * kWalkThreads + tid);
-              const int64_t t = t0 + i;
-              v[rr][k] = vd2{0.0, 0.0};
-              if (a.vec_ok) {
-                if (cx.full_chunk || t < a.T) v[rr][k] = *reinterpret_cast<const vd2 *>(gp + t);
-              } else {
-                if (t < a.T) v[rr][k].x = gp[t];
-                if (t + 1 < a.T) v[rr][k].y = gp[t + 1];
+                for (int k = 0; k < U; ++k) {
+                  const int i = 2 * (k * kWalkThreads + tid);
+                  const int64_t t = t0 + i;
+                  double e0 = 0.0, e1 = 0.0;
+                  if (t < a.T) e0 = gp[t];
+                  if (t + 1 < a.T) e1 = gp[t + 1];
+                  if (lag > 0) {
+                    e0 = (t >= lag && t < a.T) ? e0 - gp[t - lag] : 0.0;
+                    e1 = (t + 1 >= lag && t + 1 < a.T) ? e1 - gp[t + 1 - lag] : 0.0;
+                  }
+                  if (standardise) {
+                    e0 = (e0 - mean) / den;
+                    e1 = (e1 - mean) / den;
+                  }
+                  // (elements beyond T stay what the unfused path stages there: zeros)
+                  v[rr][k] = vd2{t < a.T ? e0 : 0.0, t + 1 < a.T ? e1 : 0.0};
+                }
+              }
+            }
+            if (!prepared) {
+              const double *gp =
+                  src >= 0 ? a.X + (n * a.D + src) * a.T
+                           : a.aux + (int64_t)(-src - 1) * a.aux_tab_stride + n * a.aux_n_stride;
+#pragma unroll
+              for (int k = 0; k < U; ++k) {
+                const int i = 2 * (k * kWalkThreads + tid);
+                const int64_t t = t0 + i;
+                v[rr][k] = vd2{0.0, 0.0};
+                if (a.vec_ok) {
+                  if (cx.full_chunk || t < a.T) v[rr][k] = *reinterpret_cast<const vd2 *>(gp + t);
+                } else {
+                  if (t < a.T) v[rr][k].x = gp[t];
+                  if (t + 1 < a.T) v[rr][k].y = gp[t + 1];
+                }
               }
             }
           }
@@ -900,14 +937,7 @@ static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
   if (a.persistent) {
     // at most one resident round of workgroups; each walks a contiguous span of units
     const int64_t resident = (int64_t)per_cu * device_cu_count();
-    if (a.resident_out != nullptr) {  // the host only asks how many workgroups are resident
-      *a.resident_out = (int32_t)resident;
-      return hipSuccess;
-    }
     if (blocks > resident) blocks = resident;
-  } else if (a.resident_out != nullptr) {
-    *a.resident_out = 0;
-    return hipSuccess;
   }
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(iss_walk_kernel<C>, dim3((unsigned)blocks), dim3(kWalkThreads), lds, st, a);

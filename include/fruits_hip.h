@@ -243,6 +243,22 @@ int64_t fr_pipeline_info(const fr_pipeline_t *pipeline, int32_t what);
 int64_t fr_pipeline_workspace_bytes(const fr_pipeline_t *pipeline, int64_t N,
                                     int64_t lookup_rows);
 int fr_pipeline_set_quantiles(fr_pipeline_t *pipeline, const double *h_quant);
+/* Fuses the slice's preparateurs into the launch: fr_pipeline_run then takes the RAW
+ * (N, D, T) input and forms the prepared rows while it stages them - no prepared tensor is
+ * written or read.  Covers the chains of the experiment fruits:
+ *   inc_lag > 0, as_new == 0   INC(shift=inc_lag)           fruits/preparation/transform.py:60-75
+ *   inc_lag > 0, as_new != 0   NEW(INC(shift=inc_lag))      fruits/preparation/wrapper.py:78-93
+ *                              (2 D prepared dimensions: the raw ones, then their increments)
+ *   standardize 1 / 2          followed by STD(var=False / True), std_eps
+ *                                                           fruits/preparation/transform.py:141-147
+ * (INC with depth 1 and zero padding, _increments of fruits/cache.py:8-13; STD per series
+ * and dimension).  With STD one small pre-pass computes the row statistics into the
+ * workspace; everything else is the one fused launch.  D = raw input dimensions.  Returns
+ * FR_E_LIMIT when the plan runs on a kernel without fused staging (wave-per-series kernels
+ * for T <= 384, CosWISS): the caller then materialises the prepared input as before.
+ * Call before fr_pipeline_workspace_bytes / fr_pipeline_prepare; (0, 0, 0) switches it off. */
+int fr_pipeline_set_preparation(fr_pipeline_t *pipeline, int32_t D, int32_t inc_lag,
+                                int32_t as_new, int32_t standardize, double std_eps);
 /* fr_plan_prepare for the pipeline's plan and series length (after
  * fr_pipeline_set_quantiles): fr_pipeline_run for batches of N series then only
  * enqueues work (two memsets, the exp-table kernel, the walk, the MPI finalize). */

@@ -594,6 +594,41 @@ class SieveOracle:
         return fn(arr, cuts, self.quantiles)
 
 
+    def exposure(self, A, X_raw=None, rel=1e-10):
+        """Test helper (not part of the reference): for every feature the number of
+        elements of its cut segment that lie within ``rel * max|A[n]|`` of one of the
+        band's finite thresholds.  A band test ``q_lo < v <= q_hi`` can only come out
+        differently under a re-associated scan for such elements (an exact tie with a
+        fitted quantile that IS a data point, a whole plateau of a running maximum equal
+        to it, an increment the running sum absorbs next to the threshold 0), so a
+        count may differ from the reference's by at most this number - and by nothing
+        where it is 0.  (Element 0 of a series is left out: it is computed without any
+        addition - or zero-padded - on every path.)"""
+        out = np.zeros((A.shape[0], self.nfeatures()), dtype=np.int64)
+        if self.kind == "END":
+            return out
+        if not requires_fitting(self.q):
+            self.quantiles = fit_quantiles(self.q)
+        arr = pre_transform(A, self.inc)
+        cuts = transformed_cuts(A.shape[0], A.shape[1], self.cut, X_raw, self.norm)
+        tol = rel * np.maximum(np.abs(A).max(axis=1), np.abs(arr).max(axis=1))
+        Q = len(self.quantiles) - 1
+        for i in range(A.shape[0]):
+            for j in range(cuts.shape[1] - 1):
+                seg = arr[i, cuts[i, j]:cuts[i, j + 1]]
+                for k in range(Q):
+                    near = np.zeros(seg.shape, dtype=bool)
+                    for thr in (self.quantiles[k], self.quantiles[k + 1]):
+                        if np.isfinite(thr):
+                            near |= np.abs(seg - thr) <= tol[i]
+                    # t = 0 is exact on both sides (the first value of a scan is its first
+                    # summand; increments are zero-padded there): never a disagreement
+                    if cuts[i, j] == 0 and near.size:
+                        near[0] = False
+                    out[i, j * Q + k] = int(near.sum())
+        return out
+
+
 # --------------------------------------------------------------------------
 # whole pipeline (the spec format of tests/golden/golden.json "fruit" cases)
 # --------------------------------------------------------------------------
@@ -707,3 +742,24 @@ def fruit_transform(spec, fitted, X):
         blocks.append(np.concatenate(cols, axis=1))
     res = np.concatenate(blocks, axis=1)
     return np.nan_to_num(res, copy=False, nan=0.0)
+
+
+def fruit_transform_exposure(spec, fitted, X, rel=1e-10):
+    """fruit_transform and, from the same iterated sums, the (N, F) near-threshold element
+    counts of every feature (SieveOracle.exposure, a test helper) in the same column order."""
+    feats, expos = [], []
+    for sl, (sieves, ext) in zip(spec["slices"], fitted):
+        P = _apply_preps(X, sl.get("preps", []))
+        cols, ecols = [], []
+        for i, itsum in enumerate(_iterate_iss(P, sl["iss"], X)):
+            for s in (ext[i] if ext else sieves):
+                cols.append(s.transform(itsum, X))
+                ecols.append(s.exposure(itsum, X, rel))
+        feats.append(np.concatenate(cols, axis=1))
+        expos.append(np.concatenate(ecols, axis=1))
+    res = np.nan_to_num(np.concatenate(feats, axis=1), copy=False, nan=0.0)
+    return res, np.concatenate(expos, axis=1)
+
+
+def fruit_exposure(spec, fitted, X, rel=1e-10):
+    return fruit_transform_exposure(spec, fitted, X, rel)[1]

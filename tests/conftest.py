@@ -54,3 +54,30 @@ def load_golden():
 @pytest.fixture(scope="session")
 def golden():
     return load_golden()
+
+
+# Parity report: every feature comparison of the GPU suite records how many counting
+# features were compared, how many were exposed to a threshold tie, and how many differed;
+# printed at the end of the run (pytest -m gpu) so the observed mismatches are on record.
+PARITY_REPORT = []
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not PARITY_REPORT:
+        return
+    tr = terminalreporter
+    tr.write_sep("-", "feature parity report (counting sieves vs the oracle)")
+    tot = {"entries": 0, "exposed": 0, "differ": 0, "differ_unexposed": 0}
+    for r in PARITY_REPORT:
+        for k in tot:
+            tot[k] += r[k]
+    worst = sorted(PARITY_REPORT, key=lambda r: -r["differ"])[:12]
+    for r in worst:
+        if r["differ"] == 0:
+            break
+        tr.write_line(f"  {r['what'][:70]:70s} entries {r['entries']:8d} exposed {r['exposed']:7d} "
+                      f"differ {r['differ']:5d} (max |d| {r['max_d']:.0f}, unexposed {r['differ_unexposed']})")
+    tr.write_line(f"  TOTAL over {len(PARITY_REPORT)} comparisons: count entries {tot['entries']}, "
+                  f"tie-exposed {tot['exposed']}, differing {tot['differ']} "
+                  f"({100.0 * tot['differ'] / max(tot['entries'], 1):.4f} %), "
+                  f"differing outside exposure {tot['differ_unexposed']}")
