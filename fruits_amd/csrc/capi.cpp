@@ -220,21 +220,61 @@ bool carries_fit_lds(const fr::Plan &p, int64_t T, int G) {
          rows_bytes + (size_t)carry_slots_for(p, G) * 8 <= 40 * 1024;
 }
 
+// Resident workgroups of the cooperative walk kernel instance that (plan, T, fused,
+// vec_ok) selects: a dry run of the launcher (nothing is enqueued).
+int64_t query_resident(const fr::Plan &p, int64_t N, int64_t T, bool fused, bool vec_ok) {
+  if (env_int("FRUITS_HIP_PERSIST", 1) == 0) return 0;
+  fr::IssArgs a{};
+  int32_t resident = 0;
+  double *const dummy = reinterpret_cast<double *>(uintptr_t(256));  // never dereferenced
+  a.N = N;
+  a.D = std::max(1, p.max_dim);
+  a.T = T;
+  a.G = 1;
+  a.R = p.rows_staged();
+  a.total_nodes = (int32_t)p.nodes.size();
+  a.aux = p.weighting != 0 ? dummy : nullptr;
+  a.carry = T > fr::walk_chunk_elems(T) ? dummy : nullptr;
+  a.vec_ok = vec_ok ? 1 : 0;
+  a.persistent = 1;
+  a.semiring = p.semiring;
+  a.carry_slots = carry_slots_for(p, 1);
+  a.carry_in_lds = carries_fit_lds(p, T, 1) ? 1 : 0;
+  a.feats = fused ? dummy : nullptr;
+  a.resident_out = &resident;
+  if (fr::launch_iss_walk(a, p.levels, nullptr) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return resident;
+}
+
 // Groups per series for the contiguous-span schedule of the cooperative kernel (walk.h):
 // a unit is (series, group of root sub-tries); every unit stages the series' rows again, so
-// groups only pay while the batch alone cannot fill the chip.  Measured on config 2
-// (tools/tune2.py, FRUITS_HIP_GROUPS = 1, 2, 3, 6, 9 against N = 64 ... 4096): the fastest
-// choice is the smallest G with N * G >= ~3 workgroups per CU (N = 64: G = 6, 256: 3,
-// 512: 2, >= 768: 1); with more units than that the extra stagings cost more than the
-// finer balance gains (N = 1000: G = 1 30.5 us, G = 2 35.6 us), and beyond one resident
-// round every choice is within 2.5 %.
-int choose_groups_spans(const fr::Plan &p, int64_t N) {
+// groups only pay (a) while the batch alone cannot fill the chip and (b) when the batch is
+// a little more than one resident round, where whole series leave a third of the workgroups
+// with twice the work.  Measured on config 2 (tools/tune2.py, FRUITS_HIP_GROUPS = 1, 2, 3,
+// 6, 9 against N = 64 ... 4096): (a) the fastest choice is the smallest G with N * G >= ~3
+// workgroups per CU (N = 64: G = 6, 256: 3, 512: 2, >= 768: 1) - more units than that cost
+// more in stagings than the finer balance gains (N = 1000: G = 1 30.5 us, G = 2 35.6 us);
+// (b) N = 2048 on 1536 resident workgroups: G = 3 (4 units each) 69.9 us against 74.1 us
+// with whole series (1 or 2 each), at 50 MB more staging reads out of the L2 / Infinity
+// Cache; from two full rounds on every choice is within 2.5 %.
+int choose_groups_spans(const fr::Plan &p, int64_t N, int64_t resident) {
   const int U = p.units();
   if (U <= 1 || N <= 0) return 1;
+  const int Gmax = std::min(U, kSpanGroupsMax);
   const int64_t target = 3 * (int64_t)fr::device_cu_count();
-  int64_t G = (target + N - 1) / N;
-  G = std::min<int64_t>(G, std::min(U, kSpanGroupsMax));
-  return (int)std::max<int64_t>(G, 1);
+  if (N < target) return (int)std::max<int64_t>(1, std::min<int64_t>((target + N - 1) / N, Gmax));
+  if (resident <= 0 || N >= 2 * resident) return 1;
+  auto imbalance = [&](int64_t units) {   // most loaded span / mean span, in units
+    const int64_t per = (units + resident - 1) / resident;
+    return (double)per * (double)resident / (double)units;
+  };
+  if (imbalance(N) <= 1.2) return 1;
+  for (int G = 2; G <= Gmax; ++G)
+    if (imbalance(N * G) <= 1.05) return G;
+  return 1;
 }
 
 // One-time uploads for the node order a run of this (N, T, groups) asks for.
@@ -249,7 +289,14 @@ int prepare_plan(fr::Plan &p, int64_t N, int64_t T, int32_t groups, bool fused, 
                                 " rows per time chunk, more than the LDS holds - split the word list");
   std::vector<int> Gs;
   const bool spans = !shape.packed && groups <= 0 && env_int("FRUITS_HIP_GROUPS", 0) <= 0;
-  Gs.push_back(spans ? choose_groups_spans(p, N) : shape.G);
+  if (spans) {
+    // (the choice depends on the kernel instance - fused or not, 16-byte aligned or not -
+    // which is only known when the pointers are: upload what either would ask for)
+    Gs.push_back(choose_groups_spans(p, N, query_resident(p, N, T, fused, true)));
+    if (!fused) Gs.push_back(choose_groups_spans(p, N, query_resident(p, N, T, false, false)));
+  } else {
+    Gs.push_back(shape.G);
+  }
   // the opt-in wave-per-row kernel (FRUITS_HIP_TEAM=1) always walks 4 groups
   if (!fused && env_int("FRUITS_HIP_TEAM", 0) == 1 && groups <= 0 && p.units() >= 4)
     Gs.push_back(4);
@@ -534,10 +581,11 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
                                 " distinct alphas), more than the LDS holds - split the word list");
   const bool packed = !wave_rows && shape.packed;
   const bool spans = !wave_rows && !packed && groups <= 0 && env_int("FRUITS_HIP_GROUPS", 0) <= 0;
+  const int64_t resident = spans ? query_resident(p, N, T, fu != nullptr, vec_ok_pre) : 0;
   fr::GroupedProgram *gpp = nullptr;
   {
     std::lock_guard<std::mutex> lock(p.mu);
-    const int G = wave_rows ? 4 : (spans ? choose_groups_spans(p, N) : shape.G);
+    const int G = wave_rows ? 4 : (spans ? choose_groups_spans(p, N, resident) : shape.G);
     gpp = &fr::grouped(p, G);   // (map nodes are stable: the reference outlives the lock)
     int rc = ensure_device_program(p, *gpp, st, who);
     if (rc != FR_OK) return rc;

@@ -64,6 +64,8 @@ struct IssArgs {
   const int32_t *cw_fac_begin;
   int32_t cw_W, cw_F, cw_total;
   uint32_t k_stride_bytes32; // out_k_stride * 8 when that fits 32 bits (and is > 0), else 0
+  int32_t *resident_out;    // HOST pointer; non-null: the launcher stores the number of resident
+                            // workgroups of the kernel it would launch there and launches nothing
   // fused preparation (MODE 1 cooperative kernels): X is the RAW (N, D, T) input and the
   // staging forms the prepared rows on the fly.  prep[4 * d'] for prepared dimension d':
   // {raw dimension, increment lag (0: none), standardise (0 / 1), unused}; stats holds

@@ -937,7 +937,14 @@ static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
   if (a.persistent) {
     // at most one resident round of workgroups; each walks a contiguous span of units
     const int64_t resident = (int64_t)per_cu * device_cu_count();
+    if (a.resident_out != nullptr) {  // the host only asks how many workgroups are resident
+      *a.resident_out = (int32_t)resident;
+      return hipSuccess;
+    }
     if (blocks > resident) blocks = resident;
+  } else if (a.resident_out != nullptr) {
+    *a.resident_out = 0;
+    return hipSuccess;
   }
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(iss_walk_kernel<C>, dim3((unsigned)blocks), dim3(kWalkThreads), lds, st, a);

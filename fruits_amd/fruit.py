@@ -418,6 +418,36 @@ class FruitSlice:
         self._fused_cache[key] = entry
         return entry
 
+    def _fusable_preparation(self, T: int):
+        """(inc_lag, as_new, standardize, eps) when the preparateur chain is one the fused
+        launch forms while staging the raw input - [INC | NEW(INC)] [STD], the chains of the
+        experiment fruits - else None (the prepared input is then materialised)."""
+        from .preparation.transform import INC, STD
+        from .preparation.wrapper import NEW
+        if os.environ.get("FRUITS_AMD_FUSED_PREP", "1") == "0":
+            return None
+        preps = list(self._preparateurs)
+        lag, as_new, std, eps = 0, False, 0, 0.0
+
+        def plain_inc(p):
+            return (type(p) is INC and p._depth == 1 and p._zero_padding
+                    and isinstance(p._lag(T), int) and 1 <= p._lag(T) < T)
+        if preps and plain_inc(preps[0]):
+            lag = preps.pop(0)._lag(T)
+        elif preps and type(preps[0]) is NEW and preps[0]._preparateur is not None \
+                and plain_inc(preps[0]._preparateur):
+            lag, as_new = preps.pop(0)._preparateur._lag(T), True
+        if preps and type(preps[0]) is STD and preps[0]._separately:
+            p = preps.pop(0)
+            std, eps = (2 if p._div_std else 1), float(p._eps)
+        if preps or (lag == 0 and std == 0):
+            return None
+        for iss in self._iss:            # a weighting computed from the PREPARED input needs it
+            w = getattr(iss, "weighting", None)
+            if w is not None and getattr(w, "_on_prepared", False):
+                return None
+        return lag, as_new, std, eps
+
     def _attach(self, cache) -> None:
         for iss in self._iss:
             iss._cache = cache
@@ -472,12 +502,28 @@ class FruitSlice:
             cache = SharedSeedCache(X)
         t = nat.torch()
         Xd = cache.input_device(X) if cache._input is X else nat.to_device(X)
+        if not callbacks:
+            # INC / NEW(INC) / STD formed while the fused launch stages the RAW rows: no
+            # prepared tensor is written (one launch [+ the STD statistics pre-pass])
+            T = int(Xd.shape[2])
+            chain = self._fusable_preparation(T)
+            fused = self._fused(T) if chain is not None else None
+            if fused is not None:
+                if getattr(fused, "_prep_chain", None) != (chain, int(Xd.shape[1])):
+                    fused.set_preparation(int(Xd.shape[1]), chain[0], chain[1], chain[2], chain[3])
+                    fused._prep_chain = (chain, int(Xd.shape[1]))
+                if fused.raw_dims > 0:
+                    self._attach(cache)
+                    return fused.run(Xd, self._iss[0].lookup_device(Xd))
         Pd = self._prepare_device(Xd, cache, callbacks)
         for cb in callbacks:
             cb.on_preparation_end(nat.to_host(Pd))
         self._attach(cache)
         fused = None if callbacks else self._fused(int(Pd.shape[2]))
         if fused is not None:
+            if fused.raw_dims > 0:       # (was configured for raw input by another call)
+                fused.set_preparation(int(Pd.shape[1]))
+                fused._prep_chain = None
             return fused.run(Pd, self._iss[0].lookup_device(Pd))
         feats = t.zeros((X.shape[0], self.nfeatures()), dtype=t.float64, device=Pd.device)
         col = 0

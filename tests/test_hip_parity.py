@@ -1025,6 +1025,51 @@ def test_fused_ragged_and_multichunk(fr, T):
     compare_features(got, ref, labels, expo, what=f"ragged / multi-chunk T={T}")
 
 
+@pytest.mark.parametrize("T", [511, 1024, 1500])
+@pytest.mark.parametrize("chain", ["INC", "INC3", "NEW_INC", "STD", "INC_STD", "NEW_INC_STD0"])
+def test_fused_preparation(fr, monkeypatch, chain, T):
+    """INC / NEW(INC) / STD formed while the fused launch stages the RAW rows
+    (fr_pipeline_set_preparation) against the same pipeline on a materialised prepared
+    input - bit for bit (same arithmetic, same summation order of the statistics) - and
+    against the oracle; Reals + Indices and Arctic slices, single and multi chunk."""
+    preps = {"INC": [{"kind": "INC"}], "INC3": [{"kind": "INC", "shift": 3}],
+             "NEW_INC": [{"kind": "NEW", "inner": {"kind": "INC"}}], "STD": [{"kind": "STD"}],
+             "INC_STD": [{"kind": "INC"}, {"kind": "STD"}],
+             "NEW_INC_STD0": [{"kind": "NEW", "inner": {"kind": "INC"}},
+                              {"kind": "STD", "var": False}]}[chain]
+    D = 2
+    Dp = 2 * D if chain.startswith("NEW") else D
+    rng = np.random.default_rng(T + len(chain))
+    X = rng.standard_normal((12, D, T)).cumsum(axis=2) / 4.0
+    words = ["[1]", "[1][%d]" % Dp, "[%d][1%d]" % (Dp, Dp), "[%d]" % Dp]
+    spec = {"slices": [
+        {"preps": preps, "iss": [{"words": words, "mode": "EXTENDED",
+                                  "weighting": {"kind": "Indices", "scale": 3.0}}],
+         "sieves": [{"kind": "NPI", "q": [0.5, 1.0]}, {"kind": "MPI", "inc": 0}, {"kind": "END"}],
+         "fit_sample_size": 1.0},
+        {"preps": preps, "iss": [{"words": ["[1][%d][1]" % Dp], "mode": "EXTENDED",
+                                  "semiring": "Arctic"}],
+         "sieves": [{"kind": "NPI", "q": [0.3, 1.0], "inc": 2}, {"kind": "END", "cut": [T // 2, -1]}],
+         "fit_sample_size": 1.0}]}
+    fruit = build_fruit(fr, spec)
+    np.random.seed(1)
+    fruit.fit(X)
+    got = fruit.transform(X)
+    for slc in fruit:
+        pipe = slc._fused(T)
+        assert pipe is not None and pipe.raw_dims == D      # the raw input went in
+    monkeypatch.setenv("FRUITS_AMD_FUSED_PREP", "0")
+    plain = fruit.transform(X)
+    for slc in fruit:
+        assert slc._fused(T).raw_dims == 0
+    labels = [fruit.label(i) for i in range(fruit.nfeatures())]
+    exact = np.array(["MPI" not in lb for lb in labels])   # (band sums: float atomics)
+    np.testing.assert_array_equal(got[:, exact], plain[:, exact])
+    np.testing.assert_allclose(got, plain, rtol=1e-12, atol=1e-300)
+    ref, expo = oracle_features(spec, X, X, np_seed=1)
+    compare_features(got, ref, labels, expo, what=f"fused preparation {chain} T={T}")
+
+
 @pytest.mark.parametrize("name", ["cfg3_small", "reduced_slice1_small", "readme", "readme_fullfit"])
 def test_device_fit_equals_host_fit(fr, name, monkeypatch):
     """Thresholds fitted from device-selected order statistics are bit-identical to
