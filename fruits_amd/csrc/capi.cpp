@@ -1097,36 +1097,63 @@ int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32
         job_rank[j] < 0 || job_rank[j] >= N * T)
       return fail(FR_E_ARG, "fr_select_ranks: job " + std::to_string(j) + " out of range");
   // jobs that read the same row block share their passes over it (sorted by row, then
-  // differencing order, so a group computes every difference once per element)
+  // differencing order, then rank, so a group computes every difference once per element);
+  // identical jobs are run once, and a job that asks for rank r + 1 of the same values as
+  // its predecessor's rank r rides on it (one extra pass instead of eight: np.quantile
+  // always asks for such neighbours)
   std::vector<int> order(n_jobs);
   for (int j = 0; j < n_jobs; ++j) order[j] = j;
   std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
     if (job_row[x] != job_row[y]) return job_row[x] < job_row[y];
-    return job_inc[x] < job_inc[y];
+    if (job_inc[x] != job_inc[y]) return job_inc[x] < job_inc[y];
+    return job_rank[x] < job_rank[y];
   });
-  std::vector<HostJob> jobs(n_jobs);
+  std::vector<HostJob> jobs;
+  std::vector<int> dev_of(n_jobs), via_succ(n_jobs, 0);   // per sorted position
   std::vector<int32_t> groups;  // {first, count} pairs
+  std::vector<int> group_row;
   for (int s = 0; s < n_jobs; ++s) {
     const int j = order[s];
-    jobs[s] = HostJob{d_A + (int64_t)job_row[j] * N * T, 0ull, (long long)job_rank[j], job_inc[j], 0};
-    if (!groups.empty() && job_row[order[groups[groups.size() - 2]]] == job_row[j] &&
-        groups.back() < fr::kSelGroupMax)
+    if (s > 0) {
+      const int q = order[s - 1];
+      if (job_row[q] == job_row[j] && job_inc[q] == job_inc[j]) {
+        if (job_rank[q] == job_rank[j]) {          // duplicate
+          dev_of[s] = dev_of[s - 1];
+          via_succ[s] = via_succ[s - 1];
+          continue;
+        }
+        if (!via_succ[s - 1] && job_rank[q] + 1 == job_rank[j]) {   // neighbour
+          jobs[dev_of[s - 1]].pad |= 1;
+          dev_of[s] = dev_of[s - 1];
+          via_succ[s] = 1;
+          continue;
+        }
+      }
+    }
+    dev_of[s] = (int)jobs.size();
+    jobs.push_back(HostJob{d_A + (int64_t)job_row[j] * N * T, 0ull, (long long)job_rank[j],
+                           job_inc[j], 0});
+    if (!groups.empty() && group_row.back() == job_row[j] && groups.back() < fr::kSelGroupMax)
       ++groups.back();
     else {
-      groups.push_back(s);
+      groups.push_back(dev_of[s]);
       groups.push_back(1);
+      group_row.push_back(job_row[j]);
     }
   }
+  const int n_dev = (int)jobs.size();
   const int n_groups = (int)groups.size() / 2;
-  std::vector<double> sorted_out(n_jobs);
+  std::vector<double> dev_out(n_dev);
+  std::vector<unsigned long long> dev_succ(n_dev);
   hipStream_t st = (hipStream_t)stream;
-  // one grow-only scratch blob per device (jobs | groups | histograms | results): fit calls
-  // this once per word batch and slice, and hipMalloc / hipFree synchronise the device
+  // one grow-only scratch blob per device (jobs | groups | histograms | results | successors):
+  // fit calls this once per word batch and slice, and hipMalloc / hipFree synchronise
   const size_t o_jobs = 0;
   const size_t o_groups = align_up(o_jobs + jobs.size() * sizeof(HostJob), 256);
   const size_t o_hist = align_up(o_groups + groups.size() * 4, 256);
-  const size_t o_out = align_up(o_hist + (size_t)n_jobs * 256 * 4, 256);
-  const size_t need = align_up(o_out + (size_t)n_jobs * 8, 256);
+  const size_t o_out = align_up(o_hist + (size_t)n_dev * 256 * 4, 256);
+  const size_t o_succ = align_up(o_out + (size_t)n_dev * 8, 256);
+  const size_t need = align_up(o_succ + (size_t)n_dev * 8, 256);
   const int dev = current_device_id();
   if (dev < 0 || dev >= kScratchDevices) return fail(FR_E_ARG, "fr_select_ranks: device id");
   std::lock_guard<std::mutex> lock(g_scratch_mu);
@@ -1145,15 +1172,30 @@ int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32
                           hipMemcpyHostToDevice, st)) != hipSuccess ||
       (e = hipMemcpyAsync(b + o_groups, groups.data(), groups.size() * 4, hipMemcpyHostToDevice,
                           st)) != hipSuccess ||
-      (e = hipMemsetAsync(b + o_hist, 0, (size_t)n_jobs * 256 * 4, st)) != hipSuccess ||
-      (e = fr::launch_select_ranks(b + o_jobs, n_jobs, b + o_groups, n_groups, N, T,
+      (e = hipMemsetAsync(b + o_hist, 0, (size_t)n_dev * 256 * 4, st)) != hipSuccess ||
+      (e = hipMemsetAsync(b + o_succ, 0xff, (size_t)n_dev * 8, st)) != hipSuccess ||
+      (e = fr::launch_select_ranks(b + o_jobs, n_dev, b + o_groups, n_groups, N, T,
                                    reinterpret_cast<unsigned int *>(b + o_hist),
-                                   reinterpret_cast<double *>(b + o_out), st)) != hipSuccess ||
-      (e = hipMemcpyAsync(sorted_out.data(), b + o_out, (size_t)n_jobs * 8,
-                          hipMemcpyDeviceToHost, st)) != hipSuccess ||
+                                   reinterpret_cast<double *>(b + o_out),
+                                   reinterpret_cast<unsigned long long *>(b + o_succ), st)) !=
+          hipSuccess ||
+      (e = hipMemcpyAsync(dev_out.data(), b + o_out, (size_t)n_dev * 8, hipMemcpyDeviceToHost,
+                          st)) != hipSuccess ||
+      (e = hipMemcpyAsync(dev_succ.data(), b + o_succ, (size_t)n_dev * 8, hipMemcpyDeviceToHost,
+                          st)) != hipSuccess ||
       (e = hipStreamSynchronize(st)) != hipSuccess)
     return hip_fail(e, "fr_select_ranks");
-  for (int s = 0; s < n_jobs; ++s) h_out[order[s]] = sorted_out[s];
+  for (int s = 0; s < n_jobs; ++s) {
+    double v = dev_out[dev_of[s]];
+    if (via_succ[s]) {
+      const unsigned long long k = dev_succ[dev_of[s]];
+      if (k != ~0ull) {   // the order-preserving key back to the double (kernels_misc.hip)
+        const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+        std::memcpy(&v, &u, 8);
+      }
+    }
+    h_out[order[s]] = v;
+  }
   return FR_OK;
 }
 

@@ -97,8 +97,11 @@ hipError_t launch_sieve(int kind, const double *A, int64_t N, int64_t T, int64_t
 // jobs sorted so that the jobs of one group (<= kSelGroupMax, same row block) are adjacent;
 // groups = int2 {first job, count}
 constexpr int kSelGroupMax = 8;
+// job.pad bit 0: also return the next order statistic (succ[job] = its order key; all-ones
+// when there is none); succ must be preset to all-ones
 hipError_t launch_select_ranks(void *jobs, int n_jobs, const void *groups, int n_groups, int64_t N,
-                               int64_t T, unsigned int *hist, double *out, hipStream_t st);
+                               int64_t T, unsigned int *hist, double *out,
+                               unsigned long long *succ, hipStream_t st);
 constexpr int kSelJobBytes = 32;
 hipError_t launch_pre_transform(const double *A, int64_t N, int64_t T, int64_t a_stride, int inc,
                                 double *out, hipStream_t st);

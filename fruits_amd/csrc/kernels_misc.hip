@@ -389,10 +389,15 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const SelJob *__restri
   for (int j = 0; j < nj; ++j) lh[j][threadIdx.x] = 0;
   __syncthreads();
   const double *base = jobs[jb].base;
-  const int64_t total = N * T;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t n = i / T, t = i - n * T;
+  // element order: block b takes series b, b + grid, ... and its threads stride over the time
+  // axis (no per-element 64-bit division; few series: the time axis is split over the blocks)
+  const int64_t per_series = (N >= (int64_t)gridDim.x) ? 1 : ((int64_t)gridDim.x + N - 1) / N;
+  const int64_t n_first = (int64_t)blockIdx.x / per_series, part = (int64_t)blockIdx.x % per_series;
+  const int64_t n_step = ((int64_t)gridDim.x + per_series - 1) / per_series;
+  const int64_t t_len = (T + per_series - 1) / per_series;
+  const int64_t t_lo = part * t_len, t_hi = (t_lo + t_len < T) ? t_lo + t_len : T;
+  for (int64_t n = n_first; n < N; n += n_step)
+  for (int64_t t = t_lo + threadIdx.x; t < t_hi; t += blockDim.x) {
     unsigned long long key = 0;
     int key_inc = -1;
     for (int j = 0; j < nj; ++j) {
@@ -425,7 +430,8 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const SelJob *__restri
 }
 
 __global__ void select_pick_kernel(SelJob *__restrict__ jobs, int shift,
-                                   unsigned int *__restrict__ hist, double *__restrict__ out) {
+                                   unsigned int *__restrict__ hist, double *__restrict__ out,
+                                   unsigned long long *__restrict__ succ) {
   const int job = blockIdx.x;
   if (threadIdx.x == 0) {
     long long k = jobs[job].k, run = 0;
@@ -437,14 +443,71 @@ __global__ void select_pick_kernel(SelJob *__restrict__ jobs, int shift,
     }
     jobs[job].k = k - run;
     jobs[job].prefix |= (unsigned long long)d << shift;
-    if (shift == 0) out[job] = key_to_double(jobs[job].prefix);
+    if (shift == 0) {
+      out[job] = key_to_double(jobs[job].prefix);
+      // the NEXT order statistic (np.quantile interpolates between two neighbours): the same
+      // value when more copies of it remain, else the smallest larger element (one more pass,
+      // select_succ_kernel) - instead of a second 8-pass selection
+      if (jobs[job].pad & 1) {
+        if (k - run + 1 < (long long)hist[job * 256 + d])
+          succ[job] = jobs[job].prefix;
+        else
+          jobs[job].pad |= 2;
+      }
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[job * 256 + i] = 0;
 }
 
+// smallest key above the selected one, for the jobs select_pick_kernel flagged (pad & 2);
+// succ[] starts at the largest key
+__global__ __launch_bounds__(256) void select_succ_kernel(const SelJob *__restrict__ jobs,
+                                                           const int2 *__restrict__ groups,
+                                                           int64_t N, int64_t T,
+                                                           unsigned long long *__restrict__ succ) {
+  const int jb = groups[blockIdx.y].x, nj = groups[blockIdx.y].y;
+  bool any = false;
+  for (int j = 0; j < nj; ++j) any = any || (jobs[jb + j].pad & 2);
+  if (!any) return;
+  const double *base = jobs[jb].base;
+  unsigned long long best[kSelGroupJobs];
+  for (int j = 0; j < kSelGroupJobs; ++j) best[j] = ~0ull;
+  const int64_t per_series = (N >= (int64_t)gridDim.x) ? 1 : ((int64_t)gridDim.x + N - 1) / N;
+  const int64_t n_first = (int64_t)blockIdx.x / per_series, part = (int64_t)blockIdx.x % per_series;
+  const int64_t n_step = ((int64_t)gridDim.x + per_series - 1) / per_series;
+  const int64_t t_len = (T + per_series - 1) / per_series;
+  const int64_t t_lo = part * t_len, t_hi = (t_lo + t_len < T) ? t_lo + t_len : T;
+  for (int64_t n = n_first; n < N; n += n_step)
+  for (int64_t t = t_lo + threadIdx.x; t < t_hi; t += blockDim.x) {
+    unsigned long long key = 0;
+    int key_inc = -1;
+#pragma unroll
+    for (int j = 0; j < kSelGroupJobs; ++j) {
+      if (j >= nj || !(jobs[jb + j].pad & 2)) continue;
+      const int inc = jobs[jb + j].inc;
+      if (inc != key_inc) {
+        key = order_key(diff_at(base + n * T, t, inc));
+        key_inc = inc;
+      }
+      if (key > jobs[jb + j].prefix && key < best[j]) best[j] = key;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kSelGroupJobs; ++j) {
+    if (j >= nj || !(jobs[jb + j].pad & 2)) continue;
+    unsigned long long b = best[j];
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long w = __shfl_xor(b, o);
+      b = w < b ? w : b;
+    }
+    if ((threadIdx.x & 63) == 0 && b != ~0ull) atomicMin(&succ[jb + j], b);
+  }
+}
+
 hipError_t launch_select_ranks(void *jobs, int n_jobs, const void *groups, int n_groups, int64_t N,
-                               int64_t T, unsigned int *hist, double *out, hipStream_t st) {
+                               int64_t T, unsigned int *hist, double *out,
+                               unsigned long long *succ, hipStream_t st) {
   if (n_jobs <= 0 || n_groups <= 0 || N * T <= 0) return hipSuccess;
   int64_t bpj = (N * T + 256 * 16 - 1) / (256 * 16);
   if (bpj > 512) bpj = 512;
@@ -454,8 +517,11 @@ hipError_t launch_select_ranks(void *jobs, int n_jobs, const void *groups, int n
                        st, static_cast<const SelJob *>(jobs), static_cast<const int2 *>(groups), N,
                        T, shift, hist);
     hipLaunchKernelGGL(select_pick_kernel, dim3((unsigned)n_jobs), dim3(64), 0, st,
-                       static_cast<SelJob *>(jobs), shift, hist, out);
+                       static_cast<SelJob *>(jobs), shift, hist, out, succ);
   }
+  hipLaunchKernelGGL(select_succ_kernel, dim3((unsigned)bpj, (unsigned)n_groups), dim3(256), 0, st,
+                     static_cast<const SelJob *>(jobs), static_cast<const int2 *>(groups), N, T,
+                     succ);
   return hipGetLastError();
 }
 

@@ -331,24 +331,29 @@ class FruitSlice:
         lookup = iss.lookup_device(Sd)
         for s, e in iss.word_batches(Ns, T):
             block = iss.transform_device(Sd, s, e, lookup)
-            copies, rows, incs, ranks, owners = [], [], [], [], []
+            copies, owners = [], []
+            jobs: dict = {}          # (row, inc, rank) -> job index: sieves that differ only in
+            rows, incs, ranks = [], [], []   # kind (NPI / MPI) or band ask for the same statistics
+
+            def job(k, inc, rank):
+                key = (k, inc, rank)
+                if key not in jobs:
+                    jobs[key] = len(rows)
+                    rows.append(k); incs.append(inc); ranks.append(rank)
+                return jobs[key]
             for k in range(block.shape[0]):
                 fitted = [sieve.copy() for sieve in self._sieves]
                 for sieve in fitted:
                     sieve._cache = cache
                     if sieve.requires_fitting:
                         reqs = sieve._quantile_requests(n)
-                        owners.append((sieve, reqs, len(rows)))
-                        for (_, lo, hi, _) in reqs:
-                            rows += [k, k]
-                            incs += [sieve._inc, sieve._inc]
-                            ranks += [lo, hi]
+                        owners.append((sieve, reqs, [(job(k, sieve._inc, lo), job(k, sieve._inc, hi))
+                                                     for (_, lo, hi, _) in reqs]))
                 copies.append(fitted)
             vals = nat.select_ranks(block, rows, incs, ranks) if rows else np.zeros(0)
-            for sieve, reqs, first in owners:
-                lo_vals = [vals[first + 2 * j] for j in range(len(reqs))]
-                hi_vals = [vals[first + 2 * j + 1] for j in range(len(reqs))]
-                sieve._set_quantiles_from_stats(reqs, lo_vals, hi_vals)
+            for sieve, reqs, idx in owners:
+                sieve._set_quantiles_from_stats(reqs, [vals[a] for a, _ in idx],
+                                                [vals[b] for _, b in idx])
             self._sieves_extended.extend(copies)
         return True
 
