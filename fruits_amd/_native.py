@@ -34,7 +34,7 @@ EXPORTS = [
     "fr_pipeline_workspace_bytes", "fr_pipeline_run", "fr_pipeline_set_quantiles",
     "fr_select_ranks", "fr_coswiss_combine", "fr_plan_create_coswiss", "fr_nan_to_num",
     "fr_plan_prepare", "fr_pipeline_prepare", "fr_plan_fits", "fr_release_scratch",
-    "fr_pipeline_set_preparation",
+    "fr_pipeline_set_preparation", "fr_arctic_argmax",
 ]
 
 _lib = None
@@ -155,7 +155,8 @@ class Plan:
 
     def __init__(self, words: Sequence[np.ndarray], depths: Sequence[int],
                  alphas: Optional[Sequence[np.ndarray]] = None, weighting: int = FR_W_NONE,
-                 share_prefixes: bool = True, arctic: bool = False, bayesian: bool = False):
+                 share_prefixes: bool = True, arctic: bool = False, bayesian: bool = False,
+                 letter_sum: bool = False):
         L = lib()
         self._h = None
         mats = [np.ascontiguousarray(w, dtype=np.int32) for w in words]
@@ -185,7 +186,7 @@ class Plan:
             al.ctypes.data_as(C.POINTER(C.c_float)) if al is not None else None,
             dep.ctypes.data_as(ip), C.c_int32(weighting),
             C.c_int32((1 if share_prefixes else 0) | (2 if arctic else 0)
-                      | (4 if bayesian else 0)))
+                      | (4 if bayesian else 0) | (8 if letter_sum else 0)))
         if not h:
             raise ValueError(last_error())
         self._h = C.c_void_p(h)
@@ -536,3 +537,29 @@ def nan_to_num(xd):
         raise TypeError("nan_to_num needs a contiguous tensor")
     check(lib().fr_nan_to_num(dptr(xd), C.c_int64(xd.numel()), stream_ptr()), "fr_nan_to_num")
     return xd
+
+
+def arctic_argmax(Vd, word_lengths) -> "object":
+    """fr_arctic_argmax: the rows of Arctic(argmax=True) from the running maxima ``Vd``
+    (sum(L), N, T) of all prefixes of all words (lengths ``word_lengths``)."""
+    t = torch()
+    rows, N, T = (int(v) for v in Vd.shape)
+    jobs, v0, o0 = [], 0, 0
+    for L in word_lengths:
+        for k in range(L):
+            jobs.append((v0, k, o0 + k + k * (k + 1) // 2))
+        v0 += L
+        o0 += L + L * (L + 1) // 2
+    if v0 != rows:
+        raise ValueError("Vd must hold one row per prefix of every word")
+    if max(word_lengths, default=0) > 63:
+        raise NotImplementedError("Arctic argmax: words of more than 63 letters")
+    out = t.empty((o0, N, T), dtype=t.float64, device=Vd.device)
+    if not jobs or N == 0 or T == 0:
+        return out
+    jd = to_device(np.asarray(jobs, dtype=np.int32), dtype=np.int32)
+    P = t.empty_like(Vd)
+    check(lib().fr_arctic_argmax(dptr(Vd), C.c_int64(rows), C.c_int64(N), C.c_int64(T),
+                                 C.c_int32(len(jobs)), dptr(jd), dptr(P), dptr(out), stream_ptr()),
+          "fr_arctic_argmax")
+    return out

@@ -634,6 +634,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   a.packed = packed ? 1 : 0;
   a.prefetch_next = env_int("FRUITS_HIP_PREFETCH", 24);  // longest unit (nodes) that prefetches; 0: off
   a.semiring = p.semiring;
+  a.letter_sum = p.letter_sum ? 1 : 0;
   a.k_stride_bytes32 = (out_k_stride > 0 && out_k_stride < (int64_t(1) << 29))
                            ? (uint32_t)(out_k_stride * 8) : 0u;
   a.carry_slots = carry_slots_for(p, gp.groups);
@@ -1225,6 +1226,23 @@ int fr_standardize(const double *d_X, int64_t rows, int64_t T, int32_t div_std, 
   if (!d_X || !d_out) return fail(FR_E_ARG, "fr_standardize: null device pointer");
   hipError_t e = fr::launch_standardize(d_X, rows, T, div_std, eps, d_out, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "standardize launch");
+  return FR_OK;
+}
+
+int fr_arctic_argmax(const double *d_V, int64_t rows, int64_t N, int64_t T, int32_t n_jobs,
+                     const int32_t *d_jobs, double *d_P, double *d_out, void *stream) {
+  if (rows < 0 || N < 0 || T < 0 || n_jobs < 0)
+    return fail(FR_E_ARG, "fr_arctic_argmax: bad shape");
+  if (rows == 0 || N == 0 || T == 0 || n_jobs == 0) return FR_OK;
+  if (!d_V || !d_jobs || !d_P || !d_out)
+    return fail(FR_E_ARG, "fr_arctic_argmax: null device pointer");
+  hipError_t e = fr::launch_arctic_argmax(d_V, rows, N, T, n_jobs, d_jobs, d_P, d_out,
+                                          (hipStream_t)stream);
+  if (e == hipErrorInvalidValue) {
+    (void)hipGetLastError();
+    return fail(FR_E_LIMIT, "fr_arctic_argmax: grid too large (rows * N, N or jobs)");
+  }
+  if (e != hipSuccess) return hip_fail(e, "arctic argmax launch");
   return FR_OK;
 }
 

@@ -47,6 +47,7 @@ struct IssArgs {
   int32_t persistent;       // grid = one resident round of workgroups
   int32_t carry_slots;      // 3 * (records of the program): LDS carry slots
   int32_t carry_in_lds;     // multi-chunk carries fit in LDS
+  int32_t letter_sum;       // Arctic: sum a letter's terms before adding them to the prefix
   int32_t semiring;         // kSemiReals / kSemiArctic
   int32_t prefetch_next;    // units of at most this many nodes touch the next unit's rows (0: off)
   int32_t packed;           // short series: wave-per-series kernel (walk_packed.h)
@@ -115,6 +116,8 @@ hipError_t launch_coswiss_combine(const double *A, int64_t N, int64_t T, int n_o
 hipError_t launch_nan_to_num(double *x, int64_t count, hipStream_t st);
 hipError_t launch_standardize(const double *X, int64_t rows, int64_t T, int div_std, double eps,
                               double *out, hipStream_t st);
+hipError_t launch_arctic_argmax(const double *V, int64_t rows, int64_t N, int64_t T, int n_jobs,
+                                const int32_t *jobs, double *P, double *out, hipStream_t st);
 hipError_t launch_row_stats(const double *X, int64_t N, int64_t D, int64_t T, const int32_t *prep,
                             int n_prep, int div_std, double eps, double *stats, hipStream_t st);
 

@@ -353,6 +353,73 @@ hipError_t launch_row_stats(const double *X, int64_t N, int64_t D, int64_t T, co
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- Arctic argmax
+// Arctic(argmax=True), fruits/iss/semiring.py:239-284.  The running maxima V of every
+// prefix of every word come from the walk kernel (bit-exact); this is the rest:
+// (1) positions: result[2k+1, i] of the reference is the index at which the running
+//     maximum was last raised (`>=` keeps the earlier index), i.e. a running maximum of
+//     i * [V[i] > V[i-1]] - computable from the materialised row alone;
+// (2) the back-tracking of :275-283: for prefix k (index = k + k(k+1)/2) row index is V_k,
+//     row index+k+1 is P_k, and for s = k..1 row index+s is P_(s-1) frozen from the final
+//     position of row index+s+1 on: R_s[t] = P_(s-1)[min(t, m_s)], m_(k+1) = T-1,
+//     m_s = P_s[m_(s+1)].
+__global__ __launch_bounds__(256) void argmax_positions_kernel(const double *__restrict__ V,
+                                                                int64_t T,
+                                                                double *__restrict__ P) {
+  __shared__ double sm[256];
+  const double *v = V + (int64_t)blockIdx.x * T;
+  double *p = P + (int64_t)blockIdx.x * T;
+  const int tid = threadIdx.x;
+  const int64_t per = (T + 255) / 256, lo = tid * per, hi = lo + per < T ? lo + per : T;
+  double best = 0.0;   // positions are exact small integers in a double
+  for (int64_t t = lo > 0 ? lo : 1; t < hi; ++t)
+    if (v[t] > v[t - 1]) best = (double)t;
+  sm[tid] = best;
+  __syncthreads();
+  double before = 0.0;
+  for (int i = 0; i < tid; ++i) before = fmax(before, sm[i]);
+  double run = before;
+  for (int64_t t = lo; t < hi; ++t) {
+    if (t > 0 && v[t] > v[t - 1]) run = (double)t;
+    p[t] = run;
+  }
+}
+
+// jobs (n_jobs, 3) int32: {first V / P row of the word, level k, first output row of prefix k}
+__global__ __launch_bounds__(256) void argmax_assemble_kernel(
+    const double *__restrict__ V, const double *__restrict__ P, int64_t N, int64_t T,
+    const int32_t *__restrict__ jobs, double *__restrict__ out) {
+  __shared__ int64_t m[64];   // m_s for s = 1..k+1 (words of <= 63 letters)
+  const int64_t n = blockIdx.x;
+  const int32_t *jb = jobs + 3 * (int64_t)blockIdx.y;
+  const int64_t row0 = jb[0], index = jb[2];
+  const int k = jb[1];
+  auto prow = [&](int level) { return P + ((row0 + level) * N + n) * T; };
+  if (threadIdx.x == 0) {
+    m[k + 1] = T - 1;
+    for (int s_ = k; s_ >= 1; --s_) m[s_] = (int64_t)prow(s_)[m[s_ + 1]];
+  }
+  __syncthreads();
+  const double *v = V + ((row0 + k) * N + n) * T;
+  for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
+    out[(index * N + n) * T + t] = v[t];
+    for (int s_ = 1; s_ <= k + 1; ++s_) {
+      const int64_t tt = t < m[s_] ? t : m[s_];
+      out[((index + s_) * N + n) * T + t] = prow(s_ - 1)[tt];
+    }
+  }
+}
+
+hipError_t launch_arctic_argmax(const double *V, int64_t rows, int64_t N, int64_t T, int n_jobs,
+                                const int32_t *jobs, double *P, double *out, hipStream_t st) {
+  if (rows <= 0 || N <= 0 || T <= 0 || n_jobs <= 0) return hipSuccess;
+  if (rows * N > 0x7fffffffLL || N > 0x7fffffffLL || n_jobs > 65535) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(argmax_positions_kernel, dim3((unsigned)(rows * N)), dim3(256), 0, st, V, T, P);
+  hipLaunchKernelGGL(argmax_assemble_kernel, dim3((unsigned)N, (unsigned)n_jobs), dim3(256), 0, st,
+                     V, P, N, T, jobs, out);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- rank selection (fit)
 // SegmentSieve._fit needs np.quantile of the pre-transformed fit sample
 // (fruits/sieving/segment.py:66-75, increment.py:73-74).  np.quantile interpolates

@@ -73,7 +73,9 @@ struct Builder {
       for (size_t d = 0; d < tn.exps.size(); ++d)
         if (tn.exps[d] != 0) p->factors.push_back(fac_arctic(dim_row[(int)d], tn.exps[d]));
       if (weighted && p->weighting == 1) {
-        if (has_parent) p->factors.push_back(fac_arctic(row_lin(trie[tn.parent].alpha_bits), -1));
+        if (has_parent)
+          p->factors.push_back(fac_arctic(row_lin(trie[tn.parent].alpha_bits), -1) |
+                               (p->letter_sum ? FAC_FOLD : 0));
         if (!tn.children.empty()) nd.z_mul = row_lin(tn.alpha_bits);
       } else if (weighted) {
         p->factors.push_back(fac_arctic(row_lin(tn.alpha_bits), 1));
@@ -207,6 +209,7 @@ Plan *build_plan(int W, const int32_t *exps, const int32_t *L, const int32_t *Dw
     p->W = W;
     p->weighting = weighting;
     p->semiring = (flags & 2) ? kSemiArctic : ((flags & 4) ? kSemiBayesian : kSemiReals);
+    p->letter_sum = (flags & 8) != 0 && (flags & 2) != 0;
     p->shared = share;
     Builder b;
     b.p = p;
@@ -331,7 +334,7 @@ GroupedProgram &grouped(Plan &p, int G) {
       for (int i = p.unit_begin[u]; i < p.unit_begin[u + 1]; ++i) {
         const NodeDesc &nd = p.nodes[i];
         NodeRec r{};
-        bool slow = nd.fac_count > kRecInlineFactors;
+        bool slow = nd.fac_count > kRecInlineFactors || p.letter_sum;
         for (int j = 0; j < nd.fac_count; ++j)
           if (p.multiplicative() && (p.factors[nd.fac_begin + j] & FAC_DIV)) slow = true;
         r.w[0] = (nd.level & 0xff) | (((nd.flags | (slow ? F_SLOW : 0)) & 0xff) << 8);

@@ -26,6 +26,9 @@ constexpr int32_t FAC_DIV = 0x80;
 constexpr int32_t FAC_ROW_MASK = 0x7f;
 constexpr int kSemiReals = 0, kSemiArctic = 1, kSemiBayesian = 2;
 constexpr int32_t fac_arctic(int row, int el) { return row | ((el & 0xff) << 8); }
+// letter-sum plans (Arctic argmax): the letter's terms collected so far are added to the
+// prefix BEFORE this factor is applied (the weight term follows `tmp = tmp + C`)
+constexpr int32_t FAC_FOLD = 1 << 16;
 
 constexpr int kMaxLevels = 8;   // deepest register-frame stack a kernel variant supports
 
@@ -93,6 +96,10 @@ struct Plan {
   int weighting = 0;
   int semiring = kSemiReals;
   bool shared = true;
+  // Arctic: the terms el * Z[dim] of one extended letter are summed FIRST and their sum is
+  // added to the prefix (the argmax body, fruits/iss/semiring.py:252-256) instead of being
+  // added to the prefix one by one (:294-295) - the two round differently
+  bool letter_sum = false;
   int K = 0;                 // output rows
   int levels = 0;            // register frames needed
   int max_dim = 0;           // highest dimension referenced (1-based)

@@ -319,10 +319,17 @@ __device__ __forceinline__ void mul_row(const WalkCtx &cx, int code, double (&s)
 // the factor table (codes row | FAC_DIV), one factor at a time, in order.
 template <class C>
 __device__ __forceinline__ void slow_factors(const WalkCtx &cx, int fac_begin, int nf,
-                                          double (&s)[C::EP]) {
+                                          double (&s)[C::EP], const double (&pin)[C::EP],
+                                          bool letter_sum) {
+  bool folded = !letter_sum;
   for (int f = 0; f < nf; ++f) {
     const int code = as_const(cx.a->factors)[fac_begin + f];
     if constexpr (C::SEMI == 1) {
+      if (!folded && (code & FAC_FOLD)) {   // prefix + (sum of the letter's terms), then weights
+#pragma unroll
+        for (int i = 0; i < C::EP; ++i) s[i] = pin[i] + s[i];
+        folded = true;
+      }
       mul_row<C>(cx, code, s);
       continue;
     }
@@ -334,6 +341,12 @@ __device__ __forceinline__ void slow_factors(const WalkCtx &cx, int fac_begin, i
     } else {
 #pragma unroll
       for (int i = 0; i < C::EP; ++i) s[i] = s[i] * v[i];
+    }
+  }
+  if constexpr (C::SEMI == 1) {
+    if (!folded) {
+#pragma unroll
+      for (int i = 0; i < C::EP; ++i) s[i] = pin[i] + s[i];
     }
   }
 }
@@ -561,8 +574,19 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd, int slo
     if (nd.emit_count() > 0) pre = load_ops2(*cx.a, nd.w[7], 0);
   }
   const int nf = nd.fac_count();
+  bool letter_sum = false;
+  if constexpr (C::SEMI == 1) {
+    // Arctic argmax plans: C = sum of the letter's terms, then prefix + C
+    // (fruits/iss/semiring.py:252-256); 0 + term is exact, so starting from zero changes
+    // nothing but the association
+    letter_sum = cx.a->letter_sum != 0;
+    if (letter_sum) {
+#pragma unroll
+      for (int i = 0; i < EP; ++i) s[i] = 0.0;
+    }
+  }
   if (nd.flags() & F_SLOW) {
-    slow_factors<C>(cx, nd.fac_begin(), nf, s);
+    slow_factors<C>(cx, nd.fac_begin(), nf, s, pin, letter_sum);
   } else {
     // multiply-only letter, factors in the reference's order (ascending dimension)
     if (nf > 0) mul_row<C>(cx, nd.w[2], s);

@@ -363,6 +363,8 @@ class FruitSlice:
         from .sieving.segment import END
         if os.environ.get("FRUITS_AMD_FUSED", "1") == "0" or len(self._iss) != 1:
             return False
+        if getattr(self._iss[0], "_argmax", False):
+            return False     # (position rows are assembled from materialised maxima)
         if type(self._iss[0]) is not ISS:
             from .iss.cos import CosWISS
             # the factorised CosWISS kernels fuse; the term-by-term path reduces first

@@ -55,20 +55,27 @@ class ISS(Seed):
         pass
 
     # ------------------------------------------------------------------ plans
+    @property
+    def _argmax(self) -> bool:
+        return isinstance(self.semiring, Arctic) and self.semiring._argmax
+
     def _depth(self, i: int) -> int:
+        """Rows word i contributes (EXTENDED: CachePlan's depth; Arctic argmax: every prefix
+        with the positions of its maxima, L + L(L+1)/2 rows - fruits/iss/iss.py:37-47)."""
+        if self._argmax:
+            L = len(self.words[i])
+            return L + L * (L + 1) // 2
         return self._cache_plan.unique_el_depth(i) if self.mode == ISSMode.EXTENDED else 1
 
     def _rows_of(self, start: int, stop: int) -> int:
         return sum(self._depth(i) for i in range(start, stop))
 
     def _check_supported(self) -> None:
-        if isinstance(self.semiring, Arctic) and self.semiring._argmax \
-                and self.mode == ISSMode.SINGLE:
+        if self._argmax and self.mode == ISSMode.SINGLE:
             raise NotImplementedError(
                 "Arctic argmax is not implemented when using ISSMode.SINGLE")
         if isinstance(self.semiring, Arctic):
-            if self.semiring._argmax:
-                raise NotImplementedError("Arctic argmax is not on the MI355X path")
+            pass
         elif not isinstance(self.semiring, (Reals, Bayesian)):
             raise NotImplementedError(
                 f"semiring {type(self.semiring).__name__} is not on the MI355X hot path")
@@ -89,7 +96,10 @@ class ISS(Seed):
         if self.weighting is None:
             wmode, alphas = nat.FR_W_NONE, None
         else:
-            wmode = nat.FR_W_TOTAL if self.weighting.total else nat.FR_W_NONTOTAL
+            # (the argmax body weights like the non-total one whatever `total` says,
+            # fruits/iss/semiring.py:262-263,271-272)
+            wmode = (nat.FR_W_TOTAL if self.weighting.total and not self._argmax
+                     else nat.FR_W_NONTOTAL)
             alphas = [np.asarray(self.words[i].alpha, dtype=np.float32) for i in indices]
         arctic = isinstance(self.semiring, Arctic)
         bayesian = isinstance(self.semiring, Bayesian)
@@ -97,9 +107,11 @@ class ISS(Seed):
                None if alphas is None else tuple(a.tobytes() for a in alphas))
         plan = self._plans.get(key)
         if plan is None:
-            plan = nat.Plan([self.words[i].table() for i in indices],
-                            [self._depth(i) for i in indices], alphas, wmode, arctic=arctic,
-                            bayesian=bayesian)
+            # argmax: the running maxima of ALL prefixes of every word (depth = its length)
+            depths = ([len(self.words[i]) for i in indices] if self._argmax
+                      else [self._depth(i) for i in indices])
+            plan = nat.Plan([self.words[i].table() for i in indices], depths, alphas, wmode,
+                            arctic=arctic, bayesian=bayesian, letter_sum=self._argmax)
             self._plans[key] = plan
         return plan
 
@@ -151,6 +163,22 @@ class ISS(Seed):
         (K, N, T) device tensor."""
         self._check_supported()
         stop = len(self.words) if stop is None else stop
+        if self._argmax:
+            # values of every prefix, then positions + back-tracking (fr_arctic_argmax)
+            idx = tuple(range(start, stop)) if indices is None else tuple(indices)
+            plan = self._plan_indices(idx)
+            if plan.max_dim > Xd.shape[1]:
+                raise IndexError(
+                    f"a word references dimension {plan.max_dim} but the input has "
+                    f"only {Xd.shape[1]}")
+            if isinstance(lookup_d, str):
+                lookup_d = self.lookup_device(Xd)
+            V = plan.run(Xd, lookup_d, layout="KNT", groups=groups)
+            res = nat.arctic_argmax(V, [len(self.words[i]) for i in idx])
+            if out is not None:
+                out.copy_(res)
+                return out
+            return res
         plan = self._plan(start, stop) if indices is None else self._plan_indices(indices)
         if plan.max_dim > Xd.shape[1]:
             raise IndexError(
@@ -196,10 +224,10 @@ class ISS(Seed):
     def n_iterated_sums(self) -> int:
         """Number of iterated sums ``transform`` returns."""
         if self.mode == ISSMode.EXTENDED:
-            if isinstance(self.semiring, Arctic) and self.semiring._argmax:
+            if self._argmax:
                 return sum(len(w) + len(w) * (len(w) + 1) // 2 for w in self.words)
             return self._cache_plan.n_iterated_sums()
-        if isinstance(self.semiring, Arctic) and self.semiring._argmax:
+        if self._argmax:
             raise NotImplementedError(
                 "Arctic argmax is not implemented when using ISSMode.SINGLE")
         return len(self.words)

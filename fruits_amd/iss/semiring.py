@@ -67,18 +67,29 @@ class Arctic(Semiring):
     maximum and - unlike Reals - there is no shift between letters
     (fruits/iss/semiring.py:282-400).  Same HIP kernel with the scan operator and
     the letter operation exchanged; results are bit-exact (max is associative).
-    ``argmax=True`` is outside the MI355X path."""
+    ``argmax=True`` (fruits/iss/semiring.py:239-284): every prefix of the word with the
+    back-tracked positions of its maxima, ``L + L(L+1)/2`` rows - the running maxima from
+    the same kernel, positions and back-tracking by ``fr_arctic_argmax``."""
 
     def __init__(self, argmax: bool = False) -> None:
         self._argmax = argmax
 
     def iterated_sum_fast(self, Z, word, alpha, lookup, extended, total_weighting):
-        if self._argmax:
-            raise NotImplementedError("Arctic argmax is not on the MI355X path")
         Z = _check_input(Z)
         word = np.asarray(word, dtype=np.int32)
         if lookup is not None and not np.any(lookup) and (alpha is None or not np.any(alpha)):
             lookup = None
+        if self._argmax:
+            # the per-word operator: all L prefixes (non-total weights whatever the flag),
+            # then positions + back-tracking on the device
+            L = int(word.shape[0])
+            plan = nat.Plan([word], [L], None if lookup is None else [alpha],
+                            nat.FR_W_NONE if lookup is None else nat.FR_W_NONTOTAL, arctic=True,
+                            letter_sum=True)
+            Zd = nat.to_device(Z)
+            lk = None if lookup is None else nat.to_device(np.asarray(lookup, dtype=np.float64))
+            V = plan.run(Zd, lk, layout="KNT")
+            return nat.to_host(nat.arctic_argmax(V, [L]).permute(1, 0, 2).contiguous())
         return nat.iterated_sum_fast_host(Z, word, alpha, lookup, extended, total_weighting,
                                           arctic=True)
 

@@ -61,6 +61,10 @@ extern "C" {
                                     fruits/iss/semiring.py:461-571 - the letters and exp
                                     weights of Reals, a running maximum, no shift */
 
+#define FR_PLAN_ARCTIC_LETTER_SUM 8 /* with FR_PLAN_ARCTIC: the terms of one extended letter are
+                                    summed first and their sum added to the prefix - the
+                                    rounding of the argmax body (semiring.py:252-256) */
+
 /* fr_plan_info selectors */
 #define FR_INFO_ROWS 0       /* K = number of output rows (iterated sums)        */
 #define FR_INFO_NODES 1      /* scan passes the device performs                  */
@@ -325,6 +329,20 @@ int fr_coswiss_combine(const double *d_terms, int64_t n_terms, int64_t N, int64_
                        int32_t n_out, const int32_t *d_begin, const double *d_coeff,
                        const int32_t *d_desc, const double *d_trig, double *d_out,
                        int64_t out_row_stride, void *stream);
+
+/* ------------------------------------------------------------------ Arctic argmax ("next" row)
+ * Arctic(argmax=True): _arctic_argmax_single (fruits/iss/semiring.py:239-284, dispatched
+ * from Arctic._iterated_sum_fast :370-378).  The running maxima of EVERY prefix of every word
+ * come from an FR_PLAN_ARCTIC plan whose depths are the word lengths (fr_iss_run ->
+ * d_V (rows, N, T), rows = sum of L); this entry point derives the positions of the maxima
+ * (d_P, scratch of the same shape: the index at which the running maximum was last raised)
+ * and assembles the reference's rows: per word and prefix k the values, then the positions
+ * of letters 1..k+1 back-tracked from the final position of the next letter (:275-283).
+ * d_jobs (n_jobs, 3) int32 on the device, one job per (word, prefix k):
+ * {first row of the word in d_V, k, first output row of the prefix = base_w + k + k(k+1)/2};
+ * d_out (sum of L + L(L+1)/2, N, T).  Words of <= 63 letters.  Enqueues two kernels. */
+int fr_arctic_argmax(const double *d_V, int64_t rows, int64_t N, int64_t T, int32_t n_jobs,
+                     const int32_t *d_jobs, double *d_P, double *d_out, void *stream);
 
 /* ------------------------------------------------------------------ Fruit.transform epilogue
  * np.nan_to_num(result, copy=False, nan=0.0) of Fruit.transform (fruits/fruit.py:172) on the

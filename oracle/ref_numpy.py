@@ -318,6 +318,52 @@ def arctic_iterated_sum_fast(Z, word, alpha, lookup, extended, total_weighting):
     return out
 
 
+def arctic_argmax_iterated_sum_fast(Z, word, alpha, lookup):
+    """fruits/iss/semiring.py:239-284 (_arctic_argmax_single, called per series from
+    Arctic._iterated_sum_fast :370-378): every prefix k of the word, its running maximum
+    followed by the back-tracked positions of the maxima of letters 1..k+1 - L + L(L+1)/2
+    rows.  The weights enter like in the non-total body whatever ``total`` says."""
+    N, _, T = Z.shape
+    L = len(word)
+    word = np.asarray(word, dtype=np.int32).reshape(L, -1)
+    alpha = np.asarray(alpha, dtype=np.float32)
+    lookup = lookup[:N]
+    n = L + L * (L + 1) // 2
+    out = np.zeros((N, n, T))
+    for j in range(N):
+        result = np.zeros((2 * L, T))
+        tmp = np.zeros((T,))
+        for k in range(L):
+            if not np.any(word[k]):
+                continue
+            C = np.zeros(T)
+            for d, el in enumerate(word[k]):
+                C = C + el * Z[j, d, :]
+            tmp = tmp + C
+            if k > 0:
+                tmp = tmp - lookup[j] * alpha[k - 1]
+            result[2 * k, 0] = tmp[0]
+            for i in range(1, T):
+                if result[2 * k, i - 1] >= tmp[i]:
+                    result[2 * k, i] = result[2 * k, i - 1]
+                    result[2 * k + 1, i] = result[2 * k + 1, i - 1]
+                else:
+                    result[2 * k, i] = tmp[i]
+                    result[2 * k + 1, i] = i
+            if k < L - 1:
+                tmp = tmp + lookup[j] * alpha[k]
+                tmp = np.maximum.accumulate(tmp)
+        for k in range(L - 1, -1, -1):
+            index = k + k * (k + 1) // 2
+            out[j, index] = result[2 * k]
+            out[j, index + k + 1] = result[2 * k + 1]
+            for s_ in range(k, 0, -1):
+                c = int(out[j, index + s_ + 1, -1]) + 1
+                out[j, index + s_, :c] = result[2 * (s_ - 1) + 1, :c]
+                out[j, index + s_, c:] = result[2 * (s_ - 1) + 1, c - 1]
+    return out
+
+
 def bayesian_iterated_sum_fast(Z, word, alpha, lookup, extended, total_weighting):
     """fruits/iss/semiring.py:530-571 (Bayesian._iterated_sum_fast) with its bodies
     ``_bayesian_single`` (:461-493) and ``_total_weighted_bayesian_single`` (:496-527),
@@ -370,10 +416,28 @@ def iterated_sums(Z, word_rows, alpha=None, lookup=None, extended=1, total=False
 
 
 def iss_transform(X, word_strings, mode="SINGLE", alphas=None, lookup=None,
-                  total=False, semiring="Reals"):
+                  total=False, semiring="Reals", argmax=False):
     """fruits/iss/iss.py:21-67 (_calculate_ISS, one batch of all words)
     -> (K, N, T) in the reference's row order."""
     X = np.asarray(X, dtype=np.float64)
+    if argmax:
+        # iss.py:37-47: L + L(L+1)/2 rows per word, EXTENDED mode only
+        if mode != "EXTENDED":
+            raise NotImplementedError("Arctic argmax is not implemented when using ISSMode.SINGLE")
+        blocks = []
+        for i, s in enumerate(word_strings):
+            rows = parse_word(s)
+            L = len(rows)
+            if lookup is None:
+                a, lk = np.zeros(L, dtype=np.float32), np.zeros((X.shape[0], X.shape[2]))
+            else:
+                a = (np.ones(L, dtype=np.float32) if alphas is None or alphas[i] is None
+                     else np.asarray(alphas[i], dtype=np.float32))
+                lk = lookup
+            width = max(len(r) for r in rows)
+            wmat = np.array([list(r) + [0] * (width - len(r)) for r in rows], dtype=np.int32)
+            blocks.append(np.swapaxes(arctic_argmax_iterated_sum_fast(X, wmat, a, lk), 0, 1))
+        return np.concatenate(blocks, axis=0)
     if mode == "EXTENDED":
         plan = cache_plan(word_strings)
     else:

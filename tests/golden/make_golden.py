@@ -141,23 +141,29 @@ def make_weighting(spec):
 
 
 def iss_case(name, x_key, words, mode="SINGLE", alphas=None, weighting=None,
-             store_slice=None, semiring="Reals"):
+             store_slice=None, semiring="Reals", argmax=False):
     X = arrays[x_key] if isinstance(x_key, str) else x_key[1]
     ws = [fruits.words.SimpleWord(s) for s in words]
     if alphas is not None:
         for w, a in zip(ws, alphas):
             if a is not None:
                 w.alpha = a
-    iss = fruits.ISS(ws, mode=getattr(fruits.ISSMode, mode),
-                     semiring=getattr(fruits.semiring, semiring)(),
+    sr = fruits.semiring.Arctic(argmax=True) if argmax else getattr(fruits.semiring, semiring)()
+    iss = fruits.ISS(ws, mode=getattr(fruits.ISSMode, mode), semiring=sr,
                      weighting=make_weighting(weighting))
     out = iss.fit_transform(X)
     entry = {
         "name": name, "words": list(words), "mode": mode, "semiring": semiring,
         "alphas": alphas, "weighting": weighting,
         "K": int(out.shape[0]),
-        "labels": [iss.label(i) for i in range(iss.n_iterated_sums())],
     }
+    if argmax:
+        # (labels of an argmax ISS: CachePlan.get_word_string only knows the rows of the
+        # plain EXTENDED plan - the reference raises beyond them; not pinned)
+        entry["argmax"] = True
+        assert out.shape[0] == iss.n_iterated_sums()
+    else:
+        entry["labels"] = [iss.label(i) for i in range(iss.n_iterated_sums())]
     if isinstance(x_key, str):
         entry["x"] = x_key
     else:
@@ -300,6 +306,26 @@ c2a = {"seed": 0, "dist": "normal", "shape": [2048, 3, 1024]}
 iss_case("arctic_config2_ext", ("gen", gen(c2a)), W23, "EXTENDED", store_slice=[0, 2047],
          semiring="Arctic")
 manifest["iss"][-1]["x_gen"] = c2a
+
+# Arctic with argmax=True (fruits/iss/semiring.py:239-284): every prefix of every word, its
+# running maximum followed by the back-tracked positions of the maxima, EXTENDED mode only
+manifest["iss_argmax"] = []
+_n_plain = len(manifest["iss"])
+iss_case("argmax_x1_six_words", "X_1", ["[1]", "[2]", "[11]", "[12]", "[1][1]", "[1][2]"],
+         "EXTENDED", semiring="Arctic", argmax=True)
+iss_case("argmax_w23_G", "G_5_3_37", W23, "EXTENDED", semiring="Arctic", argmax=True)
+iss_case("argmax_alt_G", "G_5_3_37", ALT, "EXTENDED", semiring="Arctic", argmax=True)
+iss_case("argmax_neg_words_P", "P_4_2_33", ["[-1][-2]", "[-12][-2-21]", "[111][-2-2-2][1]"],
+         "EXTENDED", semiring="Arctic", argmax=True)
+iss_case("argmax_idx_U", "U_6_3_40", ["[12][2][33]", "[1][3]"], "EXTENDED",
+         alphas=[[.6, .2, .5], None], weighting={"kind": "Indices", "scale": 2.0},
+         semiring="Arctic", argmax=True)
+iss_case("argmax_l1_G", "G_5_3_37", ["[1][2]", "[1][2][3]", "[3]"], "EXTENDED",
+         weighting={"kind": "L1", "scale": 4.0}, semiring="Arctic", argmax=True)
+iss_case("argmax_long_U", "U_7_2_129", ["[1][2][1][2][1]", "[2][2][2]"], "EXTENDED",
+         semiring="Arctic", argmax=True)
+manifest["iss_argmax"] = manifest["iss"][_n_plain:]
+del manifest["iss"][_n_plain:]
 
 # Bayesian semiring (max, x): reference tests/signature/test_weighting.py:220-278 word sets + random
 iss_case("bayes_w23_ext_U", "U_6_3_40", W23, "EXTENDED", semiring="Bayesian")

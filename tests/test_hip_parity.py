@@ -105,9 +105,47 @@ def test_arctic_hand_computed_and_identity(fr):
     a = fr.ISS([fr.words.SimpleWord("[1][2]")], semiring=fr.semiring.Arctic()).fit_transform(-X)
     b = fr.ISS([fr.words.SimpleWord("[-1][-2]")], semiring=fr.semiring.Arctic()).fit_transform(X)
     np.testing.assert_array_equal(a, b)
-    with pytest.raises(NotImplementedError):
-        fr.ISS([fr.words.SimpleWord("[1]")], semiring=fr.semiring.Arctic(argmax=True),
-               mode=fr.ISSMode.EXTENDED).fit_transform(X)
+    with pytest.raises(NotImplementedError):   # argmax needs EXTENDED mode (iss.py:37-40)
+        fr.ISS([fr.words.SimpleWord("[1]")], semiring=fr.semiring.Arctic(argmax=True)).fit_transform(X)
+
+
+@pytest.mark.parametrize("case", G.manifest.get("iss_argmax", []), ids=lambda c: c["name"])
+def test_arctic_argmax_golden(fr, case):
+    """Arctic(argmax=True) (fruits/iss/semiring.py:239-284) against the reference's own
+    outputs: running maxima and back-tracked positions, bit for bit."""
+    X = G.x_of(case)
+    ws = [fr.words.SimpleWord(s) for s in case["words"]]
+    if case["alphas"] is not None:
+        for w, a in zip(ws, case["alphas"]):
+            if a is not None:
+                w.alpha = a
+    iss = fr.ISS(ws, mode=fr.ISSMode.EXTENDED, semiring=fr.semiring.Arctic(argmax=True),
+                 weighting=make_weighting(fr, case["weighting"]))
+    assert iss.n_iterated_sums() == case["K"]
+    out = iss.fit_transform(X)
+    np.testing.assert_array_equal(out, G[case["out"]])
+    # word by word (the generator of iss.py:152-185) and through the per-word operator
+    blocks = list(iss.batch_transform(X, batch_size=1))
+    np.testing.assert_array_equal(np.concatenate(blocks, axis=0), out)
+
+
+@pytest.mark.parametrize("T", [1, 2, 63, 1024, 1500])
+def test_arctic_argmax_random(fr, T):
+    rng = np.random.default_rng(T)
+    X = rng.standard_normal((7, 2, T)).cumsum(axis=2)
+    X[1] = np.round(X[1])            # plateaus and exact ties: `>=` keeps the earlier index
+    words = ["[1][2][-1]", "[2]", "[12][1][1][2]"]
+    iss = fr.ISS([fr.words.SimpleWord(s) for s in words], mode=fr.ISSMode.EXTENDED,
+                 semiring=fr.semiring.Arctic(argmax=True))
+    out = iss.fit_transform(X)
+    ref = orc.iss_transform(X, words, "EXTENDED", semiring="Arctic", argmax=True)
+    np.testing.assert_array_equal(out, ref)
+    # a fruit on top: sieves see values and positions alike (materialising path)
+    fruit = fr.Fruit()
+    fruit.add(iss.copy(), fr.sieving.END, fr.sieving.NPI)
+    feats = fruit.fit_transform(X)
+    assert feats.shape == (7, 2 * iss.n_iterated_sums())
+    np.testing.assert_array_equal(feats[:, 0::2], ref[:, :, -1].T)
 
 
 @pytest.mark.parametrize("T", [5, 511, 1024, 1025, 3000])

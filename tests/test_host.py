@@ -227,9 +227,14 @@ def test_iss_bookkeeping():
     fr.ISS(words, semiring=fr.semiring.Arctic())._check_supported()
     fr.ISS(words, semiring=fr.semiring.Bayesian())._check_supported()
     assert fr.ISS(words, semiring=fr.semiring.Bayesian()).label(0) == "[11] : Bayesian"
+    am = fr.ISS(words, semiring=fr.semiring.Arctic(argmax=True), mode=fr.ISSMode.EXTENDED)
+    am._check_supported()
+    # fruits/iss/iss.py:140-145: L + L(L+1)/2 rows per word
+    assert am.n_iterated_sums() == sum(len(w) + len(w) * (len(w) + 1) // 2 for w in words)
+    with pytest.raises(NotImplementedError):   # iss.py:37-40,146-149
+        fr.ISS(words, semiring=fr.semiring.Arctic(argmax=True)).n_iterated_sums()
     with pytest.raises(NotImplementedError):
-        fr.ISS(words, semiring=fr.semiring.Arctic(argmax=True),
-               mode=fr.ISSMode.EXTENDED)._check_supported()
+        fr.ISS(words, semiring=fr.semiring.Arctic(argmax=True))._check_supported()
     assert fr.ISS(words, semiring=fr.semiring.Arctic()).label(0) == "[11] : Arctic"
     assert ext.word_batches(4, 8, 1) == [(i, i + 1) for i in range(15)]
     assert ext.word_batches(4, 8) == [(0, 15)]

@@ -66,6 +66,18 @@ def test_iss_cases(case):
     np.testing.assert_allclose(out, G[case["out"]], **RT)
 
 
+@pytest.mark.parametrize("case", G.manifest.get("iss_argmax", []), ids=lambda c: c["name"])
+def test_arctic_argmax_cases(case):
+    """Arctic(argmax=True), fruits/iss/semiring.py:239-284: values and back-tracked positions
+    of the maxima, bit for bit (max and integer positions are exact)."""
+    X = G.x_of(case)
+    lookup, _ = _lookup(case, X)
+    out = orc.iss_transform(X, case["words"], case["mode"], case["alphas"], lookup,
+                            False, "Arctic", argmax=True)
+    assert out.shape[0] == case["K"]
+    np.testing.assert_array_equal(out, G[case["out"]])
+
+
 def test_operator_entry():
     Z = G["U_6_3_40"]
     word = np.array(orc.parse_word("[12][2][33]"), dtype=np.int32)
