@@ -34,7 +34,8 @@ EXPORTS = [
     "fr_pipeline_workspace_bytes", "fr_pipeline_run", "fr_pipeline_set_quantiles",
     "fr_select_ranks", "fr_coswiss_combine", "fr_plan_create_coswiss", "fr_nan_to_num",
     "fr_plan_prepare", "fr_pipeline_prepare", "fr_plan_fits", "fr_release_scratch",
-    "fr_pipeline_set_preparation", "fr_arctic_argmax",
+    "fr_pipeline_set_preparation", "fr_arctic_argmax", "fr_coswiss_set_dropout",
+    "fr_coswiss_set_input_stride", "fr_coswiss_ffn",
 ]
 
 _lib = None
@@ -314,6 +315,32 @@ class CosPlan(Plan):
         self._h = C.c_void_p(h)
         self.weighting = FR_W_NONE
         self.n_words = W
+
+
+def coswiss_set_dropout(plan: "CosPlan", indices, T: int) -> None:
+    """fr_coswiss_set_dropout: ``indices`` (W, F, Lmax, rate) int32 as drawn by CosWISS._fit;
+    ``None`` switches the mask off."""
+    if indices is None:
+        check(lib().fr_coswiss_set_dropout(plan._h, None, C.c_int32(0), C.c_int32(0),
+                                           C.c_int64(max(int(T), 1))), "fr_coswiss_set_dropout")
+        return
+    idx = np.ascontiguousarray(indices, dtype=np.int32)
+    check(lib().fr_coswiss_set_dropout(plan._h, idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       C.c_int32(idx.shape[2]), C.c_int32(idx.shape[3]),
+                                       C.c_int64(int(T))), "fr_coswiss_set_dropout")
+
+
+def coswiss_ffn(Xd, A, b, Cm, out):
+    """fr_coswiss_ffn: out (N, D, T) = C relu(A x + b) per time step; A (hidden, D), b
+    (hidden), Cm (D, hidden) host arrays."""
+    N, D, T = (int(v) for v in Xd.shape)
+    Ad = to_device(np.ascontiguousarray(A, dtype=np.float64))
+    bd = to_device(np.ascontiguousarray(b, dtype=np.float64))
+    Cd = to_device(np.ascontiguousarray(Cm, dtype=np.float64))
+    check(lib().fr_coswiss_ffn(dptr(Xd), C.c_int64(N), C.c_int64(D), C.c_int64(T), dptr(Ad),
+                               dptr(bd), dptr(Cd), C.c_int32(int(A.shape[0])), dptr(out),
+                               stream_ptr()), "fr_coswiss_ffn")
+    return out
 
 
 class Pipeline:

@@ -413,6 +413,7 @@ void fr_plan_destroy(fr_plan_t *plan) {
   if (!plan) return;
   if (plan->p) {
     if (plan->p->cos) {
+      if (plan->p->cos->d_mask) (void)hipFree(plan->p->cos->d_mask);
       if (plan->p->cos->d_blob) (void)hipFree(plan->p->cos->d_blob);
       delete plan->p->cos;
     }
@@ -538,6 +539,14 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     a.cw_W = c.W;
     a.cw_F = c.F;
     a.cw_total = c.total ? 1 : 0;
+    if (c.d_mask) {
+      if (c.mask_T != T)
+        return fail(FR_E_ARG, w + ": the dropout mask was set for series of length " +
+                                  std::to_string(c.mask_T));
+      a.cw_mask = static_cast<const double *>(c.d_mask);
+      a.cw_Lmax = c.Lmax;
+    }
+    a.cw_x_unit_stride = c.x_unit_stride;
     a.packed = (T <= 384 && env_int("FRUITS_HIP_PACKED", 1) != 0) ? 1 : 0;
     a.vec_ok = (T % 2 == 0) && aligned16(d_X) && aligned16(trig) &&
                (fu || (aligned16(d_out) && (out_k_stride % 2 == 0) && (out_n_stride % 2 == 0)));
@@ -1226,6 +1235,69 @@ int fr_standardize(const double *d_X, int64_t rows, int64_t T, int32_t div_std, 
   if (!d_X || !d_out) return fail(FR_E_ARG, "fr_standardize: null device pointer");
   hipError_t e = fr::launch_standardize(d_X, rows, T, div_std, eps, d_out, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "standardize launch");
+  return FR_OK;
+}
+
+int fr_coswiss_set_dropout(fr_plan_t *plan, const int32_t *h_indices, int32_t Lmax, int32_t rate,
+                           int64_t T) {
+  if (!plan || !plan->p || !plan->p->cos || Lmax < 0 || rate < 0 || T < 1 ||
+      (rate > 0 && Lmax > 0 && !h_indices))
+    return fail(FR_E_ARG, "fr_coswiss_set_dropout: bad argument");
+  fr::Plan &p = *plan->p;
+  fr::CosProgram &c = *p.cos;
+  std::lock_guard<std::mutex> lock(p.mu);
+  if (c.d_mask) (void)hipFree(c.d_mask);
+  c.d_mask = nullptr;
+  c.Lmax = 0;
+  c.mask_T = 0;
+  if (Lmax == 0) return FR_OK;   // dropout off
+  if (Lmax < p.levels)
+    return fail(FR_E_ARG, "fr_coswiss_set_dropout: Lmax is shorter than the longest word");
+  const size_t rows = (size_t)c.W * c.F * Lmax;
+  std::vector<double> mask(rows * (size_t)T, 1.0);
+  for (size_t r = 0; r < rows; ++r)
+    for (int i = 0; i < rate; ++i) {
+      const int32_t idx = h_indices[r * rate + i];
+      if (idx < 0 || idx >= T)
+        return fail(FR_E_INDEX, "fr_coswiss_set_dropout: index " + std::to_string(idx) +
+                                    " is out of bounds for series of length " + std::to_string(T));
+      mask[r * (size_t)T + idx] = 0.0;
+    }
+  int rc = claim_device(p, "fr_coswiss_set_dropout");
+  if (rc != FR_OK) return rc;
+  HIP_TRY(hipMalloc(&c.d_mask, mask.size() * 8));
+  hipError_t e = hipMemcpy(c.d_mask, mask.data(), mask.size() * 8, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(c.d_mask);
+    c.d_mask = nullptr;
+    return hip_fail(e, "hipMemcpy(dropout mask)");
+  }
+  c.Lmax = Lmax;
+  c.mask_T = T;
+  return FR_OK;
+}
+
+int fr_coswiss_set_input_stride(fr_plan_t *plan, int64_t unit_stride) {
+  if (!plan || !plan->p || !plan->p->cos || unit_stride < 0)
+    return fail(FR_E_ARG, "fr_coswiss_set_input_stride: bad argument");
+  plan->p->cos->x_unit_stride = unit_stride;
+  return FR_OK;
+}
+
+int fr_coswiss_ffn(const double *d_X, int64_t N, int64_t D, int64_t T, const double *d_A,
+                   const double *d_b, const double *d_C, int32_t hidden, double *d_Z,
+                   void *stream) {
+  if (N < 0 || D < 1 || T < 0 || hidden < 1) return fail(FR_E_ARG, "fr_coswiss_ffn: bad shape");
+  if (N == 0 || T == 0) return FR_OK;
+  if (!d_X || !d_A || !d_b || !d_C || !d_Z)
+    return fail(FR_E_ARG, "fr_coswiss_ffn: null device pointer");
+  hipError_t e = fr::launch_coswiss_ffn(d_X, N, D, T, d_A, d_b, d_C, hidden, d_Z,
+                                        (hipStream_t)stream);
+  if (e == hipErrorInvalidValue) {
+    (void)hipGetLastError();
+    return fail(FR_E_LIMIT, "fr_coswiss_ffn: at most 64 hidden units and 16 input dimensions");
+  }
+  if (e != hipSuccess) return hip_fail(e, "coswiss ffn launch");
   return FR_OK;
 }
 

@@ -214,7 +214,7 @@ __device__ __forceinline__ void cos_combine(const CosState<C, S> &st, double (&u
 template <class C, int S>
 __device__ __forceinline__ void coswiss_unit(WalkCtx &cx, const double *xrow, const double *trig,
                                              int lb, int le, bool total, int k_out,
-                                             double *tot_all) {
+                                             double *tot_all, const double *mask = nullptr) {
   constexpr int EP = C::EP;
   const IssArgs &a = *cx.a;
   CosState<C, S> st;
@@ -253,6 +253,14 @@ __device__ __forceinline__ void coswiss_unit(WalkCtx &cx, const double *xrow, co
 #pragma unroll
         for (int i = 0; i < EP; ++i) s[i] = s[i] * v[i];
       }
+    }
+    if (mask != nullptr) {
+      // dropout (cos.py:80): the summand of letter k is zeroed at the drawn indices before
+      // its cumsum - a select, so that a dropped inf / nan is an exact 0 like in the reference
+      double keep[EP];
+      load_global_row<C>(cx, mask + (int64_t)k * a.T, keep);
+#pragma unroll
+      for (int i = 0; i < EP; ++i) s[i] = keep[i] != 0.0 ? s[i] : 0.0;
     }
     const int slot = k * (S + 1);
     st.last = k == L - 1;
@@ -312,8 +320,9 @@ __global__ __launch_bounds__(kWalkThreads) void coswiss_kernel(const IssArgs a) 
         cx.feat_row = a.feats + n * a.feat_stride;
         cx.cnt_row = a.cnt + n * a.feat_stride;
       }
-      coswiss_unit<C, S>(cx, a.X + n * a.D * a.T + t0, a.aux + (int64_t)f * 2 * a.T + t0, lb, le,
-                         a.cw_total != 0, j, tot_all);
+      coswiss_unit<C, S>(cx, a.X + (int64_t)j * a.cw_x_unit_stride + n * a.D * a.T + t0,
+                         a.aux + (int64_t)f * 2 * a.T + t0, lb, le, a.cw_total != 0, j, tot_all,
+                         a.cw_mask ? a.cw_mask + (int64_t)j * a.cw_Lmax * a.T + t0 : nullptr);
     }
   }
 }
@@ -353,8 +362,9 @@ __global__ __launch_bounds__(kWalkThreads) void coswiss_packed_kernel(const IssA
       cx.feat_row = a.feats + n * a.feat_stride;
       cx.cnt_row = a.cnt + n * a.feat_stride;
     }
-    coswiss_unit<C, S>(cx, a.X + n * a.D * a.T, a.aux + (int64_t)f * 2 * a.T, lb, le,
-                       a.cw_total != 0, j, nullptr);
+    coswiss_unit<C, S>(cx, a.X + (int64_t)j * a.cw_x_unit_stride + n * a.D * a.T,
+                       a.aux + (int64_t)f * 2 * a.T, lb, le, a.cw_total != 0, j, nullptr,
+                       a.cw_mask ? a.cw_mask + (int64_t)j * a.cw_Lmax * a.T : nullptr);
   }
 }
 

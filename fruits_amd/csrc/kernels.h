@@ -64,6 +64,13 @@ struct IssArgs {
   const int32_t *cw_letter_begin;
   const int32_t *cw_fac_begin;
   int32_t cw_W, cw_F, cw_total;
+  // randomised CosWISS variants (fruits/iss/cos.py:51-164): cw_mask (W, F, cw_Lmax, T) holds
+  // 0.0 where the summand of letter k is dropped before its cumsum (dropout), else nullptr;
+  // cw_x_unit_stride != 0: unit j = word * F + freq reads its own input at X + j * stride
+  // (the ffn-transformed copies), else all units share X
+  const double *cw_mask;
+  int64_t cw_x_unit_stride;
+  int32_t cw_Lmax;
   uint32_t k_stride_bytes32; // out_k_stride * 8 when that fits 32 bits (and is > 0), else 0
   int32_t *resident_out;    // HOST pointer; non-null: the launcher stores the number of resident
                             // workgroups of the kernel it would launch there and launches nothing
@@ -108,6 +115,9 @@ hipError_t launch_pre_transform(const double *A, int64_t N, int64_t T, int64_t a
                                 double *out, hipStream_t st);
 constexpr int kCosMaxExponent = 4;
 hipError_t launch_coswiss(IssArgs &a, int exponent, hipStream_t st);
+hipError_t launch_coswiss_ffn(const double *X, int64_t N, int64_t D, int64_t T, const double *A,
+                              const double *b, const double *Cm, int hidden, double *Z,
+                              hipStream_t st);
 hipError_t launch_trig_tables(const float *freqs, int F, int64_t T, double *out, hipStream_t st);
 hipError_t launch_coswiss_combine(const double *A, int64_t N, int64_t T, int n_out,
                                   const int32_t *begin, const double *coeff, const int32_t *desc,

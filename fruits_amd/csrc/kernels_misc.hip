@@ -669,6 +669,48 @@ hipError_t launch_coswiss(IssArgs &a, int exponent, hipStream_t st) {
   }
 }
 
+// _ffn of fruits/iss/cos.py:93-113 for one (word, frequency): per time step
+// Z = C relu(A x + b), sums over the input / hidden dimension in index order (numba's
+// np.sum), Y * (Y > 0) as the ReLU.  One thread per (series, time step).
+constexpr int kFfnMaxHidden = 64, kFfnMaxDims = 16;
+__global__ void coswiss_ffn_kernel(const double *__restrict__ X, int64_t N, int64_t D, int64_t T,
+                                   const double *__restrict__ A, const double *__restrict__ b,
+                                   const double *__restrict__ Cm, int hidden,
+                                   double *__restrict__ Z) {
+#pragma clang fp contract(off)
+  const int64_t total = N * T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / T, t = i - n * T;
+    double x[kFfnMaxDims], y[kFfnMaxHidden];
+    for (int d = 0; d < D; ++d) x[d] = X[(n * D + d) * T + t];
+    for (int h = 0; h < hidden; ++h) {
+      double acc = 0.0;
+      for (int d = 0; d < D; ++d) acc = acc + A[h * D + d] * x[d];
+      const double v = acc + b[h];
+      y[h] = v * (v > 0.0 ? 1.0 : 0.0);
+    }
+    for (int d = 0; d < D; ++d) {
+      double acc = 0.0;
+      for (int h = 0; h < hidden; ++h) acc = acc + Cm[d * hidden + h] * y[h];
+      Z[(n * D + d) * T + t] = acc;
+    }
+  }
+}
+
+hipError_t launch_coswiss_ffn(const double *X, int64_t N, int64_t D, int64_t T, const double *A,
+                              const double *b, const double *Cm, int hidden, double *Z,
+                              hipStream_t st) {
+  const int64_t total = N * T;
+  if (total <= 0) return hipSuccess;
+  if (hidden < 1 || hidden > kFfnMaxHidden || D < 1 || D > kFfnMaxDims) return hipErrorInvalidValue;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(coswiss_ffn_kernel, dim3((unsigned)blocks), dim3(256), 0, st, X, N, D, T, A, b,
+                     Cm, hidden, Z);
+  return hipGetLastError();
+}
+
 // sin / cos tables of fruits/iss/cos.py:23-24; the float32 frequency is promoted to
 // double before the product with T-1 (numba's typing of the reference's f4 argument)
 __global__ void trig_tables_kernel(const float *__restrict__ freqs, int F, int64_t T,

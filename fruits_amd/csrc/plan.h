@@ -88,6 +88,11 @@ struct CosProgram {
   void *d_blob = nullptr;
   const int32_t *d_letter_begin = nullptr, *d_fac_begin = nullptr, *d_factors = nullptr;
   const float *d_freqs = nullptr;
+  // randomised variants: dropout mask (W, F, Lmax, mask_T) of 1.0 / 0.0, per-unit inputs
+  void *d_mask = nullptr;
+  int Lmax = 0;
+  int64_t mask_T = 0;
+  int64_t x_unit_stride = 0;
 };
 
 struct Plan {

@@ -370,6 +370,8 @@ class FruitSlice:
             # the factorised CosWISS kernels fuse; the term-by-term path reduces first
             if type(self._iss[0]) is not CosWISS or not self._iss[0]._native():
                 return False
+            if self._iss[0]._ffn_size is not None:
+                return False     # every (word, frequency) reads its own transformed input
         for sv in self._sieves:
             if type(sv) not in (NPI, MPI, END) or sv._has_float_cuts():
                 return False
@@ -393,11 +395,17 @@ class FruitSlice:
             from .sieving.segment import END
             iss = self._iss[0]
             iss._check_supported()
+            if hasattr(iss, "_arm_plan"):     # CosWISS dropout: the plan carries the mask
+                iss._check_supported()
             if indices is None:
                 plan = iss._plan(0, len(iss.words))
                 rows = range(plan.rows)
+                if hasattr(iss, "_arm_plan"):
+                    iss._arm_plan(plan, tuple(range(len(iss.words))), T)
             else:
                 plan = iss._plan_indices(indices)
+                if hasattr(iss, "_arm_plan"):
+                    iss._arm_plan(plan, tuple(indices), T)
                 first = np.concatenate([[0], np.cumsum(
                     [iss._depth(i) for i in range(len(iss.words))])]).astype(int)
                 rows = [r for i in indices for r in range(first[i], first[i + 1])]

@@ -1,5 +1,5 @@
-"""Cosine weighted ISS (mirrors fruits/iss/cos.py, without the randomised ffn /
-dropout variants).
+"""Cosine weighted ISS (mirrors fruits/iss/cos.py, including the randomised ffn and
+dropout variants on the factorised kernels).
 
 ``cos(pi*(i_k - i_{k+1})/(f*(T-1)))**s`` expands into products of powers of
 ``sin`` and ``cos`` of the single time steps (fruits/iss/cos.py:265-287), so every
@@ -51,9 +51,35 @@ class CosWISS(ISS):
         return self._ffn_size is not None or self._dropout is not None
 
     def _check_supported(self) -> None:
-        if self._ffn_size is not None or self._dropout is not None:
+        if (self._ffn_size is not None or self._dropout is not None) and not self._native():
             raise NotImplementedError(
-                "the randomised ffn / dropout variants of CosWISS are not on the MI355X path")
+                "the randomised ffn / dropout variants of CosWISS need the factorised kernels "
+                f"(exponent <= {nat.CosPlan.MAX_EXPONENT})")
+        if self._ffn_size is not None and not hasattr(self, "_A"):
+            raise RuntimeError("Missing call of self.fit()")
+        if self._dropout is not None and self._ffn_size is None \
+                and not hasattr(self, "_dropout_indices"):
+            raise RuntimeError("Missing call of self.fit()")
+
+    def _fit(self, X: np.ndarray) -> None:
+        """Draws the random state exactly like the reference (fruits/iss/cos.py:248-263), from
+        numpy's global generator and in the same order, so a seeded run picks the same
+        weights and indices."""
+        if (d := self._ffn_size) is not None:
+            W, F = len(self.words), len(self._freqs)
+            self._A = np.random.random((W, F, d, X.shape[1]))
+            self._b = np.random.random((W, F, d))
+            self._C = np.random.random((W, F, X.shape[1], d))
+        if (d := self._dropout) is not None:
+            rate = int(d * X.shape[2])
+            self._dropout_indices = np.array([
+                [[np.random.choice(X.shape[2], size=(rate,), replace=False)
+                  for _ in range(max(map(len, self.words)))]
+                 for _ in range(len(self._freqs))]
+                for _ in range(len(self.words))
+            ], dtype=np.int32)
+            self._dropout_T = int(X.shape[2])
+        self._plans = {}
 
     # ------------------------------------------------------------------ host tables
     def _get_weightings(self, word: Word) -> np.ndarray:
@@ -129,13 +155,7 @@ class CosWISS(ISS):
                 and os.environ.get("FRUITS_AMD_COSWISS_TERMS", "0") != "1")
 
     def _plan(self, start: int, stop: int) -> nat.Plan:
-        key = ("cos", start, stop)
-        plan = self._plans.get(key)
-        if plan is None:
-            plan = nat.CosPlan([self.words[i].table() for i in range(start, stop)],
-                               self._freqs, self._exponent, self._total_weighting)
-            self._plans[key] = plan
-        return plan
+        return self._plan_indices(tuple(range(start, stop)))
 
     def _plan_indices(self, indices) -> nat.Plan:
         """Program of an arbitrary subset of the words (a rank's share of a word-sharded
@@ -148,6 +168,18 @@ class CosWISS(ISS):
                                self._exponent, self._total_weighting)
             self._plans[key] = plan
         return plan
+
+    def _arm_plan(self, plan, idx, T: int) -> None:
+        """Hands the dropout indices of the words ``idx`` to their plan (a device mask) -
+        before a run of the plan itself or of a fused pipeline built on it."""
+        if self._dropout is None or self._ffn_size is not None:
+            return
+        if T != self._dropout_T:
+            raise IndexError(f"the dropout indices were drawn for series of length "
+                             f"{self._dropout_T}, the input has {T}")
+        if getattr(plan, "_dropout_set", None) is not self._dropout_indices:
+            nat.coswiss_set_dropout(plan, self._dropout_indices[list(idx)], T)
+            plan._dropout_set = self._dropout_indices
 
     def _n_terms(self, w: int) -> int:
         p = len(self.words[w]) + 1 if self._total_weighting else len(self.words[w])
@@ -198,10 +230,27 @@ class CosWISS(ISS):
         if out.numel() == 0 or n_words == 0:
             return out
         if self._native():
+            idx = tuple(range(start, stop)) if indices is None else tuple(indices)
+            if self._ffn_size is not None:
+                # _ffn_coswiss (cos.py:116-137; batch_transform tests ffn first, :306-314):
+                # every (word, frequency) has its own transformed input - word by word, the
+                # F copies stacked, unit f of the word's plan reading copy f
+                Z = t.empty((F, N, D, T), dtype=t.float64, device=Xd.device)
+                for i, w in enumerate(idx):
+                    plan = self._plan_indices((w,))
+                    if plan.max_dim > D:
+                        raise IndexError(f"a word references dimension {plan.max_dim} but "
+                                         f"the input has only {D}")
+                    for f in range(F):
+                        nat.coswiss_ffn(Xd, self._A[w, f], self._b[w, f], self._C[w, f], Z[f])
+                    nat.check(nat.lib().fr_coswiss_set_input_stride(plan._h, N * D * T))
+                    plan.run(Z[0], None, out=out[i * F:(i + 1) * F], layout="KNT")
+                return out
             plan = self._plan(start, stop) if indices is None else self._plan_indices(indices)
             if plan.max_dim > D:
                 raise IndexError(
                     f"a word references dimension {plan.max_dim} but the input has only {D}")
+            self._arm_plan(plan, idx, T)
             return plan.run(Xd, None, out=out, layout="KNT")
         plan, begin_d, coeff_d, desc_d = self._program(start, stop, D)
         trig = t.from_numpy(self._trig(T)).to(Xd.device)              # (F, 2, T)

@@ -313,6 +313,26 @@ fr_plan_t *fr_plan_create_coswiss(int32_t W, const int32_t *exps, const int32_t 
                                   const int32_t *Dw, int32_t n_freqs, const float *freqs,
                                   int32_t exponent, int32_t total_weighting);
 
+/* The randomised variants of CosWISS (fruits/iss/cos.py:51-164; state drawn by
+ * CosWISS._fit :248-263).
+ * dropout: _leaky_coswiss_single zeroes the summand of letter k at dropout[k] before its
+ *   cumsum (:80).  h_indices (W, n_freqs, Lmax, rate) int32 HOST array =
+ *   CosWISS._dropout_indices; T = series length the indices were drawn for.  The plan keeps
+ *   a device mask; fr_iss_run / fr_pipeline_run then apply it (Lmax = 0 switches it off).
+ *   Allocates and synchronises (call it after fit, outside a capture).
+ * ffn: _ffn_coswiss sends the input of every (word, frequency) through _ffn first (:93-113,
+ *   :128-135): fr_coswiss_ffn computes Z = C relu(A x + b) per time step for ONE (word,
+ *   frequency) (d_A (hidden, D), d_b (hidden), d_C (D, hidden), d_Z (N, D, T); <= 64
+ *   hidden units, <= 16 dimensions; enqueues one kernel), and
+ *   fr_coswiss_set_input_stride(plan, s) makes unit j = word * n_freqs + freq of the plan
+ *   read its input at d_X + j * s (s = N*D*T for the stacked Z's; 0 = all units share d_X). */
+int fr_coswiss_set_dropout(fr_plan_t *plan, const int32_t *h_indices, int32_t Lmax, int32_t rate,
+                           int64_t T);
+int fr_coswiss_set_input_stride(fr_plan_t *plan, int64_t unit_stride);
+int fr_coswiss_ffn(const double *d_X, int64_t N, int64_t D, int64_t T, const double *d_A,
+                   const double *d_b, const double *d_C, int32_t hidden, double *d_Z,
+                   void *stream);
+
 /* The reference's own formulation, term by term, for exponents beyond the kernels above:
  * the cosine weighted ISS (fruits/iss/cos.py:11-49) expands cos(a-b)^s into products of
  * sin / cos powers (cos.py:265-287); every product ("term") is an ordinary Reals ISS of

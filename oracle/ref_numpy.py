@@ -491,17 +491,45 @@ def coswiss_trig(T, freq):
     return np.sin(ang), np.cos(ang)
 
 
-def coswiss_transform(X, word_strings, freqs, exponent=2, total=False):
+def coswiss_ffn(X, A, b, C):
+    """fruits/iss/cos.py:93-113 (_ffn) for a batch: per time step a two-layer network with
+    a ReLU, Z = C relu(A x + b); the sums run over the input / hidden dimension in index
+    order (numba's np.sum is a sequential loop)."""
+    N, D, T = X.shape
+    Y = np.zeros((N, A.shape[0], T))
+    for d in range(A.shape[0]):
+        acc = np.zeros((N, T))
+        for i in range(D):
+            acc = acc + A[d, i] * X[:, i, :]
+        Y[:, d, :] = acc + b[d]
+    Y = Y * (Y > 0)
+    Z = np.zeros((N, C.shape[0], T))
+    for d in range(C.shape[0]):
+        acc = np.zeros((N, T))
+        for i in range(C.shape[1]):
+            acc = acc + C[d, i] * Y[:, i, :]
+        Z[:, d, :] = acc
+    return Z
+
+
+def coswiss_transform(X, word_strings, freqs, exponent=2, total=False, ffn=None,
+                      dropout_indices=None):
     """fruits/iss/cos.py:11-49,167-181,289-330 (_coswiss_single, _coswiss,
-    CosWISS.batch_transform without ffn / dropout) -> (W*F, N, T), rows word-major."""
+    CosWISS.batch_transform) -> (W*F, N, T), rows word-major.  ``ffn`` = (A, b, C) of
+    CosWISS._fit (:250-257): the input of (word, frequency) is first sent through
+    ``_ffn`` (:93-113, :128-135); ``dropout_indices`` (W, F, Lmax, rate) (:258-263): the
+    summand of letter k is zeroed at these indices before its cumsum (:80)."""
     N, _, T = X.shape
     out = np.zeros((len(word_strings) * len(freqs), N, T))
+    X_in = X
     for w, ws in enumerate(word_strings):
         word = parse_word(ws)
         L = len(word)
         Wt = coswiss_weightings(L, exponent, total)
         for f, freq in enumerate(freqs):
             sin_w, cos_w = coswiss_trig(T, freq)
+            if ffn is not None:
+                X = coswiss_ffn(X_in, ffn[0][w, f], ffn[1][w, f], ffn[2][w, f])
             res = np.zeros((N, T))
             for i in range(Wt.shape[0]):
                 tmp = np.ones((N, T))
@@ -513,6 +541,8 @@ def coswiss_transform(X, word_strings, freqs, exponent=2, total=False):
                         tmp = tmp * sin_w
                     for _ in range(Wt[i, 2 * k + 2]):
                         tmp = tmp * cos_w
+                    if dropout_indices is not None:
+                        tmp[:, dropout_indices[w, f, k]] = 0
                     tmp = np.cumsum(tmp, axis=1)
                 if Wt.shape[1] == 2 * L + 3:
                     for _ in range(Wt[i, 2 * L + 1]):

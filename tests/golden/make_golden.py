@@ -368,6 +368,37 @@ cos_case("e2_total_multi", "U_5_3_65", ["[1]", "[1][2]", "[11][2][3]"], [0.25, 1
          exponent=2, total_weighting=True)
 cos_case("e3", "U_5_3_65", ["[1][-2]", "[3][1][1]"], [0.5], exponent=3)
 
+# the randomised variants (fruits/iss/cos.py:51-164,248-263): the weights / dropped indices
+# drawn by CosWISS._fit from numpy's global generator are stored with the outputs
+manifest["coswiss_random"] = []
+
+
+def cos_random_case(name, x_key, words, freqs, np_seed, **kw):
+    X = arrays[x_key]
+    cw = fruits.CosWISS([fruits.words.SimpleWord(s) for s in words], freqs, **kw)
+    np.random.seed(np_seed)
+    cw.fit(X)
+    out = cw.transform(X)
+    entry = {"name": name, "x": x_key, "words": list(words), "freqs": list(freqs), "kw": kw,
+             "np_seed": np_seed, "out": put(f"cosr/{name}", out)}
+    if kw.get("ffn_size") is not None:
+        entry["A"], entry["b"], entry["C"] = (put(f"cosr/{name}_A", cw._A),
+                                              put(f"cosr/{name}_b", cw._b),
+                                              put(f"cosr/{name}_C", cw._C))
+    if kw.get("dropout") is not None:
+        entry["dropout_indices"] = put(f"cosr/{name}_drop", cw._dropout_indices)
+    manifest["coswiss_random"].append(entry)
+
+
+cos_random_case("drop_e2", "U_5_3_65", ["[1][2]", "[2][13]", "[1][2][3]"], [0.5, 0.25], 11,
+                exponent=2, dropout=0.1)
+cos_random_case("drop_e1_total", "U_5_3_65", ["[1]", "[12][2][33]"], [0.5], 12, exponent=1,
+                total_weighting=True, dropout=0.2)
+cos_random_case("ffn3_e2", "U_5_3_65", ["[1][2]", "[2][13]"], [0.5, 2.0], 13, exponent=2,
+                ffn_size=3)
+cos_random_case("ffn9_e1_total", "U_5_3_65", ["[1][23]", "[3]"], [0.25], 14, exponent=1,
+                total_weighting=True, ffn_size=9)
+
 # per-word operator (iterated_sum_fast, fruits/iss/semiring.py:203-219)
 Z = arrays["U_6_3_40"]
 word = fruits.words.SimpleWord("[12][2][33]")

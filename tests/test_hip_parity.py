@@ -787,7 +787,7 @@ def test_capture_without_prior_eager_run(fr):
     g.replay()
     torch.cuda.synchronize()
     ref = orc_np.iss_transform(X, [str(w) for w in words], "EXTENDED")
-    assert rowwise_close(out.cpu().numpy(), ref)
+    rowwise_close(out.cpu().numpy(), ref)
     np.testing.assert_allclose(feats.cpu().numpy(), fruit.transform(X), rtol=1e-12)
     # outside a capture the unprepared plan uploads by itself
     other.run(Xd, None, out=oout)
@@ -815,8 +815,64 @@ def test_end_cut_out_of_range_raises(fr):
     np.testing.assert_allclose(fruit.transform(X), ref[:, [0, 0, 49, 49]], rtol=1e-12)
 
 
+@pytest.mark.parametrize("case", G.manifest.get("coswiss_random", []), ids=lambda c: c["name"])
+def test_coswiss_random_variants_golden(fr, case):
+    """The ffn / dropout variants (fruits/iss/cos.py:51-164) against the reference's outputs:
+    a seeded fit draws the same weights / indices as the reference's (same generator calls in
+    the same order), the transform agrees to 1e-6 (observed ~1e-15; the goldens come from
+    numpy's pairwise np.sum, the kernel follows numba's sequential one)."""
+    kw = case["kw"]
+    X = G[case["x"]]
+    cw = fr.CosWISS([fr.words.SimpleWord(s) for s in case["words"]], case["freqs"], **kw)
+    assert cw.requires_fitting
+    with pytest.raises(RuntimeError):
+        cw.transform(X)
+    np.random.seed(case["np_seed"])
+    cw.fit(X)
+    if "A" in case:
+        for name, mine in (("A", cw._A), ("b", cw._b), ("C", cw._C)):
+            np.testing.assert_array_equal(mine, G[case[name]])
+    if "dropout_indices" in case:
+        np.testing.assert_array_equal(cw._dropout_indices, G[case["dropout_indices"]])
+    out = cw.transform(X)
+    ref = G[case["out"]]
+    assert out.shape == ref.shape
+    rowwise_close(out, ref)
+    np.testing.assert_allclose(out, ref, rtol=RTOL, atol=1e-12)
+    blocks = list(cw.batch_transform(X, batch_size=1))
+    np.testing.assert_array_equal(np.concatenate(blocks, axis=0), out)
+
+
+@pytest.mark.parametrize("T", [96, 1024, 1100])
+def test_coswiss_dropout_fused_and_long(fr, monkeypatch, T):
+    """Dropout through the fused pipeline (packed, cooperative and multi-chunk kernels)
+    against the materialising path and the oracle."""
+    rng = np.random.default_rng(T)
+    X = rng.standard_normal((10, 2, T)).cumsum(axis=2) / 4.0
+    words = ["[1]", "[1][2]", "[2][1][1]"]
+    cw = fr.CosWISS([fr.words.SimpleWord(s) for s in words], [0.25, 0.5], exponent=2,
+                    total_weighting=True, dropout=0.15)
+    fruit = fr.Fruit()
+    fruit.add(cw, fr.sieving.NPI, fr.sieving.END)
+    np.random.seed(3)
+    fruit.fit(X)
+    fitted = fruit.get_slice().get_iss()[0]
+    assert fruit.get_slice()._fused(T) is not None
+    fused = fruit.transform(X)
+    monkeypatch.setenv("FRUITS_AMD_FUSED", "0")
+    fruit.get_slice()._fused_cache = {}
+    plain = fruit.transform(X)
+    ref = orc.coswiss_transform(X, words, [0.25, 0.5], 2, True,
+                                dropout_indices=fitted._dropout_indices)
+    np.testing.assert_allclose(fused[:, 1::2], ref[:, :, -1].T, rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(plain[:, 1::2], ref[:, :, -1].T, rtol=RTOL, atol=1e-9)
+    rowwise_close(fitted.transform(X), ref)
+    with pytest.raises(IndexError):
+        fitted.transform(X[:, :, :T - 1].copy())
+
+
 def test_coswiss_unsupported(fr):
-    cw = fr.CosWISS([fr.words.SimpleWord("[1]")], [0.5], dropout=0.5)
+    cw = fr.CosWISS([fr.words.SimpleWord("[1]")], [0.5], dropout=0.5, exponent=7)
     with pytest.raises(NotImplementedError):
         cw.transform_device(None)
     with pytest.raises(ValueError):

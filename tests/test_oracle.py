@@ -127,6 +127,19 @@ def test_fruit(case):
             G[case["out_test"]], **RT)
 
 
+@pytest.mark.parametrize("case", G.manifest.get("coswiss_random", []), ids=lambda c: c["name"])
+def test_coswiss_random_variants(case):
+    """ffn / dropout CosWISS (fruits/iss/cos.py:51-164) with the weights / indices the
+    reference's fit drew; the ffn sums follow numba's sequential np.sum while the goldens
+    come from the un-jitted run (numpy's pairwise order): 1e-12 instead of bit equality."""
+    kw = case["kw"]
+    ffn = (G[case["A"]], G[case["b"]], G[case["C"]]) if "A" in case else None
+    drop = G[case["dropout_indices"]] if "dropout_indices" in case else None
+    out = orc.coswiss_transform(G[case["x"]], case["words"], case["freqs"], kw.get("exponent", 2),
+                                kw.get("total_weighting", False), ffn=ffn, dropout_indices=drop)
+    np.testing.assert_allclose(out, G[case["out"]], rtol=1e-11, atol=1e-12)
+
+
 @pytest.mark.parametrize("case", G.manifest.get("coswiss", []), ids=lambda c: c["name"])
 def test_coswiss(case):
     kw = case["kw"]
