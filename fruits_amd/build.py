@@ -75,12 +75,14 @@ def needs_build() -> bool:
 
 
 def build_native(force: bool = False, verbose: bool = False, jobs: int = 0,
-                 variant: str = "", defines=()) -> str:
+                 variant: str = "", defines=(), only=()) -> str:
     """``variant`` / ``defines``: an experiment library next to the product one
     (``libfruits_hip.<variant>.so``, selected at run time with FRUITS_HIP_LIB), built
-    with extra ``-D`` flags; its objects carry the variant in their names."""
+    with extra ``-D`` flags; its objects carry the variant in their names.  ``only``:
+    unit names rebuilt with the flags - the rest are the product's objects."""
     if variant:
-        return _build(LIB[:-3] + f".{variant}.so", f"v{variant}", list(defines), True, verbose, jobs)
+        return _build(LIB[:-3] + f".{variant}.so", f"v{variant}", list(defines), True, verbose, jobs,
+                      only=tuple(only))
     if not force and not needs_build():
         return LIB
     tag = "t" if os.environ.get("FRUITS_HIP_TIMING_BUILD") else "p"
@@ -90,7 +92,8 @@ def build_native(force: bool = False, verbose: bool = False, jobs: int = 0,
     return lib
 
 
-def _build(lib_path: str, tag: str, defines, force: bool, verbose: bool, jobs: int) -> str:
+def _build(lib_path: str, tag: str, defines, force: bool, verbose: bool, jobs: int,
+           only=()) -> str:
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
@@ -102,6 +105,8 @@ def _build(lib_path: str, tag: str, defines, force: bool, verbose: bool, jobs: i
     def compile_one(unit):
         name, src, extra = unit
         srcp = os.path.join(CSRC, src)
+        if only and name not in only:
+            return os.path.join(OBJ, f"{name}.p.o")      # the product's object
         obj = os.path.join(OBJ, f"{name}.{tag}.o")
         if (not force and os.path.exists(obj)
                 and os.path.getmtime(obj) > max(os.path.getmtime(srcp), hdr_t)):
@@ -124,11 +129,13 @@ def _build(lib_path: str, tag: str, defines, force: bool, verbose: bool, jobs: i
 
 
 if __name__ == "__main__":
-    variant, defines = "", []
+    variant, defines, only = "", [], []
     for arg in sys.argv[1:]:
         if arg.startswith("--variant="):
             variant = arg.split("=", 1)[1]
+        elif arg.startswith("--only="):
+            only = arg.split("=", 1)[1].split(",")
         elif arg.startswith("-D"):
             defines.append(arg[2:])
     print(build_native(force="--force" in sys.argv, verbose="-v" in sys.argv, variant=variant,
-                       defines=defines))
+                       defines=defines, only=only))

@@ -249,32 +249,29 @@ int64_t query_resident(const fr::Plan &p, int64_t N, int64_t T, bool fused, bool
   return resident;
 }
 
-// Groups per series for the contiguous-span schedule of the cooperative kernel (walk.h):
-// a unit is (series, group of root sub-tries); every unit stages the series' rows again, so
-// groups only pay (a) while the batch alone cannot fill the chip and (b) when the batch is
-// a little more than one resident round, where whole series leave a third of the workgroups
-// with twice the work.  Measured on config 2 (tools/tune2.py, FRUITS_HIP_GROUPS = 1, 2, 3,
-// 6, 9 against N = 64 ... 4096): (a) the fastest choice is the smallest G with N * G >= ~3
-// workgroups per CU (N = 64: G = 6, 256: 3, 512: 2, >= 768: 1) - more units than that cost
-// more in stagings than the finer balance gains (N = 1000: G = 1 30.5 us, G = 2 35.6 us);
-// (b) N = 2048 on 1536 resident workgroups: G = 3 (4 units each) 69.9 us against 74.1 us
-// with whole series (1 or 2 each), at 50 MB more staging reads out of the L2 / Infinity
-// Cache; from two full rounds on every choice is within 2.5 %.
-int choose_groups_spans(const fr::Plan &p, int64_t N, int64_t resident) {
+// Groups per series for the cooperative kernel (walk.h): a unit is (series, group of root
+// sub-tries) and stages the series' rows itself, so groups only pay where finer units help.
+// Measured on config 2 and its 48-word tiling (tools/gpu_sched.sh: FRUITS_HIP_GROUPS = 1, 2,
+// 3, 6, 9 against N = 64 ... 8192, `resident` = one round of workgroups, 1536 for these
+// kernels):
+//   N < resident        the batch alone cannot fill the chip: ceil(resident / N) groups, at
+//                       most 6 (N = 64: G = 6 7.5 us vs 15.7 with 1; 256: 3; 512: 3; 768 and
+//                       1000: 2)
+//   N < 2 x resident    whole series (N = 1536: 41.7 us, G = 3 46.9; N = 2048: 64.5, G = 3 73.2)
+//   beyond              small plans (<= 32 nodes): 3 groups - finer units even out the last
+//                       rounds and their restaging hits the XCD's L2 (N = 4096: 135.5 vs
+//                       146.6 us, N = 8192: 272 vs 291 us); larger plans keep whole series
+//                       (config 3 / 4 / 5: no difference measured)
+int choose_groups_walk(const fr::Plan &p, int64_t N, int64_t resident) {
   const int U = p.units();
   if (U <= 1 || N <= 0) return 1;
-  const int Gmax = std::min(U, kSpanGroupsMax);
-  const int64_t target = 3 * (int64_t)fr::device_cu_count();
-  if (N < target) return (int)std::max<int64_t>(1, std::min<int64_t>((target + N - 1) / N, Gmax));
-  if (resident <= 0 || N >= 2 * resident) return 1;
-  auto imbalance = [&](int64_t units) {   // most loaded span / mean span, in units
-    const int64_t per = (units + resident - 1) / resident;
-    return (double)per * (double)resident / (double)units;
-  };
-  if (imbalance(N) <= 1.2) return 1;
-  for (int G = 2; G <= Gmax; ++G)
-    if (imbalance(N * G) <= 1.05) return G;
-  return 1;
+  if (resident <= 0) return choose_groups(p, N, 0);
+  if (N < resident) {
+    const int64_t G = std::min<int64_t>((resident + N - 1) / N, 6);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(G, U));
+  }
+  if (N < 2 * resident || p.nodes.size() > 32) return 1;
+  return std::min(U, 3);
 }
 
 // One-time uploads for the node order a run of this (N, T, groups) asks for.
@@ -288,12 +285,12 @@ int prepare_plan(fr::Plan &p, int64_t N, int64_t T, int32_t groups, bool fused, 
                                 std::to_string(p.rows_staged()) +
                                 " rows per time chunk, more than the LDS holds - split the word list");
   std::vector<int> Gs;
-  const bool spans = !shape.packed && groups <= 0 && env_int("FRUITS_HIP_GROUPS", 0) <= 0;
-  if (spans) {
+  const bool auto_groups = !shape.packed && groups <= 0 && env_int("FRUITS_HIP_GROUPS", 0) <= 0;
+  if (auto_groups) {
     // (the choice depends on the kernel instance - fused or not, 16-byte aligned or not -
     // which is only known when the pointers are: upload what either would ask for)
-    Gs.push_back(choose_groups_spans(p, N, query_resident(p, N, T, fused, true)));
-    if (!fused) Gs.push_back(choose_groups_spans(p, N, query_resident(p, N, T, false, false)));
+    Gs.push_back(choose_groups_walk(p, N, query_resident(p, N, T, fused, true)));
+    if (!fused) Gs.push_back(choose_groups_walk(p, N, query_resident(p, N, T, false, false)));
   } else {
     Gs.push_back(shape.G);
   }
@@ -589,12 +586,12 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
                                 std::to_string(p.alphas.size()) +
                                 " distinct alphas), more than the LDS holds - split the word list");
   const bool packed = !wave_rows && shape.packed;
-  const bool spans = !wave_rows && !packed && groups <= 0 && env_int("FRUITS_HIP_GROUPS", 0) <= 0;
-  const int64_t resident = spans ? query_resident(p, N, T, fu != nullptr, vec_ok_pre) : 0;
+  const bool auto_groups = !wave_rows && !packed && groups <= 0 && env_int("FRUITS_HIP_GROUPS", 0) <= 0;
+  const int64_t resident = auto_groups ? query_resident(p, N, T, fu != nullptr, vec_ok_pre) : 0;
   fr::GroupedProgram *gpp = nullptr;
   {
     std::lock_guard<std::mutex> lock(p.mu);
-    const int G = wave_rows ? 4 : (spans ? choose_groups_spans(p, N, resident) : shape.G);
+    const int G = wave_rows ? 4 : (auto_groups ? choose_groups_walk(p, N, resident) : shape.G);
     gpp = &fr::grouped(p, G);   // (map nodes are stable: the reference outlives the lock)
     int rc = ensure_device_program(p, *gpp, st, who);
     if (rc != FR_OK) return rc;
@@ -646,6 +643,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   a.letter_sum = p.letter_sum ? 1 : 0;
   a.k_stride_bytes32 = (out_k_stride > 0 && out_k_stride < (int64_t(1) << 29))
                            ? (uint32_t)(out_k_stride * 8) : 0u;
+  a.xcd_map = (a.G > 1 && N % 8 == 0) ? 1 : 0;
   a.carry_slots = carry_slots_for(p, gp.groups);
   a.carry_in_lds = carries_fit_lds(p, T, gp.groups) ? 1 : 0;
   if (fu) {

@@ -43,7 +43,7 @@ struct IssArgs {
   int32_t total_nodes;
   int32_t vec_ok;           // 16-byte accesses are aligned
   int32_t nchunks;
-  int32_t xcd_map;          // (unused since the contiguous-span schedule)
+  int32_t xcd_map;          // strided schedule: the groups of one series share an XCD
   int32_t persistent;       // grid = one resident round of workgroups
   int32_t carry_slots;      // 3 * (records of the program): LDS carry slots
   int32_t carry_in_lds;     // multi-chunk carries fit in LDS

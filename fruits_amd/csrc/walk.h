@@ -758,15 +758,14 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
   const unsigned long long t_begin = cx.last;
   const unsigned long long real_begin = __builtin_amdgcn_s_memrealtime();  // 100 MHz, global
 #endif
-  // Persistent workgroups: the grid holds (at most) one resident round of workgroups.
-  // A unit is (series n, group g of root sub-tries), numbered u = n * G + g, and
-  // workgroup b walks the CONTIGUOUS span [b * units / grid, (b + 1) * units / grid):
-  // every workgroup gets the same number of units (+-1), the groups of one series that
-  // fall into a span share ONE staging of its rows, and a span that crosses into the next
-  // series restages in the middle of its work, when the other workgroups of the CU cover
-  // the read latency.  The host keeps G = 1 unless the batch alone cannot fill the chip
-  // (capi.cpp, choose_groups_spans).  TEAM = 1: a unit is a series, its G = TEAMS groups
-  // go to the 4 waves, strided over the grid.
+  // Persistent workgroups: the grid holds (at most) one resident round of workgroups and
+  // each walks units b, b + grid, ...  A unit is (series n, group g of root sub-tries).
+  // Workgroups are dealt round-robin over the 8 XCDs, so with the xcd_map numbering all
+  // groups of one series meet in one XCD's L2 (speed only, never correctness).  In the
+  // first round the resident workgroups write CONSECUTIVE series of every output plane.
+  // (Round 2 tried contiguous spans of units per workgroup - even spans, one staging shared
+  // by the groups of a series: 5-10 % slower at every batch size)
+  // TEAM = 1: a unit is a series, its G = TEAMS groups go to the 4 waves.
   int sink = 0;  // next-series prefetch (see below): one word per 128-byte line of the rows
   int pf_val = 0, pf_off = -1;
   if constexpr (C::TEAM != 1 && C::MODE == 0) {
@@ -777,38 +776,28 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
       if (src >= 0) pf_off = src * (int)a.T + line * 16;
     }
   }
-  int u, u_end, u_step;  // (the host checks N * G < 2^31)
-  if constexpr (C::TEAM == 1) {
-    u = blockIdx.x;
-    u_end = (int)a.N;
-    u_step = gridDim.x;
-  } else {
-    const int64_t units = a.N * a.G;
-    u = (int)((units * (int64_t)blockIdx.x) / (int64_t)gridDim.x);
-    u_end = (int)((units * ((int64_t)blockIdx.x + 1)) / (int64_t)gridDim.x);
-    u_step = 0;  // advanced by the groups walked per series
-  }
-  while (u < u_end) {
+  const int u_end = C::TEAM == 1 ? (int)a.N : (int)(a.N * a.G);  // (the host checks < 2^31)
+  for (int u = blockIdx.x; u < u_end; u += gridDim.x) {
     int64_t n;
-    int g0, g1;  // groups [g0, g1) of series n
+    int g0;
     if constexpr (C::TEAM == 1) {
       n = u;
       g0 = cx.team;
-      g1 = g0 + 1;
+    } else if (a.xcd_map) {
+      const int q = u >> 3, r = u & 7;
+      n = (int64_t)(q / a.G) * 8 + r;
+      g0 = q % a.G;
     } else {
       const int ni = u / a.G;
       n = ni;
       g0 = u - ni * a.G;
-      const int series_end = (ni + 1) * a.G;
-      g1 = g0 + ((series_end < u_end ? series_end : u_end) - u);
-      u_step = g1 - g0;
     }
     const int node_begin = as_const(a.group_begin)[g0];
     if constexpr (C::MULTI == 1)
       cx.carry = lds + (int64_t)a.R * C::CHUNK + 4 * C::NW;
     else
       cx.carry = a.carry ? a.carry + n * (kCarrySlots * (int64_t)a.total_nodes) : nullptr;
-    cx.pc_begin = node_begin;  // LDS carry slots are indexed from the span's first record
+    cx.pc_begin = node_begin;  // LDS carry slots are indexed from the group's first record
     for (int64_t chunk = 0; chunk < a.nchunks; ++chunk) {
       const int64_t t0 = chunk * C::CHUNK;
       cx.t0 = t0;
@@ -902,31 +891,32 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
       __syncthreads();
       if constexpr (C::TEAM != 1 && C::MODE == 0) {
         if (a.prefetch_next && a.nchunks == 1) {
-          // Touch one word per 128-byte line of the rows of the NEXT series of this span, so
+          // Touch one word per 128-byte line of the rows of this workgroup's NEXT unit, so
           // that its staging - issued when the memory system is full of this kernel's
           // stores - finds them in the L2 / Infinity Cache.  The loaded value is only
           // consumed behind the next staging wait (no extra stall).
           sink += pf_val;
           pf_val = 0;
-          // (lines touched a long walk ahead are evicted before they are used: walks of
-          // more than prefetch_next nodes do not prefetch)
-          const int n_rec = as_const(a.group_begin)[g1] - node_begin;
-          if (u + u_step < u_end && n_rec <= a.prefetch_next && pf_off >= 0)
-            pf_val = *reinterpret_cast<const int *>(a.X + (n + 1) * a.D * a.T + pf_off);
+          // (lines touched a whole long unit ahead are evicted before they are used:
+          // units of more than prefetch_next nodes do not prefetch)
+          const int n_rec = as_const(a.group_begin)[g0 + 1] - node_begin;
+          const int un = u + (int)gridDim.x;
+          if (un < u_end && n_rec <= a.prefetch_next && pf_off >= 0) {
+            const int64_t n_next =
+                a.xcd_map ? (int64_t)((un >> 3) / a.G) * 8 + (un & 7) : (int64_t)(un / a.G);
+            pf_val = *reinterpret_cast<const int *>(a.X + n_next * a.D * a.T + pf_off);
+          }
         }
       }
       STAMP(cx, 6);  // staging
       double ones[C::EP];  // identity of the semiring's product: 1 (Reals, Bayesian), 0 (Arctic)
 #pragma unroll
       for (int i = 0; i < C::EP; ++i) ones[i] = C::SEMI != 1 ? 1.0 : 0.0;
-      for (int g = g0; g < g1; ++g) {
-        int pc = as_const(a.group_begin)[g];
-        Rec cur = load_rec(a.recs, pc);
-        walk<C, 0>(cx, cur, pc, ones);
-      }
+      int pc = node_begin;
+      Rec cur = load_rec(a.recs, pc);
+      walk<C, 0>(cx, cur, pc, ones);
     }
     first_unit = false;
-    u += u_step;
   }
   if (sink + pf_val == 0x7fffffff) a.out[0] = (double)sink;  // keeps the prefetch loads alive
 #ifdef FRUITS_HIP_TIMING_BUILD
@@ -959,8 +949,10 @@ static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
   if (units > 0x7fffffffLL) return hipErrorInvalidValue;  // unit indices are 32-bit in the kernel
   int64_t blocks = units;
   if (a.persistent) {
-    // at most one resident round of workgroups; each walks a contiguous span of units
-    const int64_t resident = (int64_t)per_cu * device_cu_count();
+    // at most one resident round of workgroups (a multiple of 8 for the XCD numbering)
+    int64_t resident = (int64_t)per_cu * device_cu_count();
+    resident -= resident % 8;
+    if (resident < 8) resident = 8;
     if (a.resident_out != nullptr) {  // the host only asks how many workgroups are resident
       *a.resident_out = (int32_t)resident;
       return hipSuccess;

@@ -11,7 +11,11 @@ N, D, T = [int(v) for v in os.environ.get("TUNE_SHAPE", "2048,3,1024").split(","
 wspec = os.environ.get("TUNE_WORDS", "2,3")
 ww, wd = [int(v) for v in wspec.split(",")]
 words = fr.words.of_weight(ww, dim=wd)
-iss = fr.ISS(words, mode=fr.ISSMode.EXTENDED)
+if os.environ.get("TUNE_TILE48"):       # the metric's "48 weight-2 words": words[i % 15], SINGLE mode
+    words = [words[i % len(words)] for i in range(48)]
+    iss = fr.ISS(words)
+else:
+    iss = fr.ISS(words, mode=fr.ISSMode.EXTENDED)
 plan = iss._plan(0, len(words))
 K = plan.rows
 X = np.random.default_rng(0).standard_normal((N, D, T))
