@@ -27,7 +27,7 @@ FR_E_ARG, FR_E_DIM, FR_E_HIP, FR_E_NOMEM, FR_E_LIMIT, FR_E_INDEX = -1, -2, -3, -
 EXPORTS = [
     "fr_last_error", "fr_version", "fr_device_count", "fr_malloc", "fr_free",
     "fr_memcpy_h2d", "fr_memcpy_d2h", "fr_stream_sync", "fr_plan_create",
-    "fr_plan_destroy", "fr_plan_info", "fr_plan_dump", "fr_plan_workspace_bytes",
+    "fr_plan_destroy", "fr_plan_info", "fr_plan_dump", "fr_plan_records", "fr_plan_static_schedule", "fr_plan_workspace_bytes",
     "fr_iss_run", "fr_iterated_sum_fast_host", "fr_increments",
     "fr_pathlen_lookup", "fr_sieve", "fr_pre_transform", "fr_standardize",
     "fr_pipeline_create", "fr_pipeline_destroy", "fr_pipeline_info",
@@ -75,6 +75,10 @@ def lib():
     L.fr_plan_info.restype = C.c_int64
     L.fr_plan_info.argtypes = [C.c_void_p, C.c_int32]
     L.fr_plan_dump.restype = C.c_int32
+    L.fr_plan_records.restype = C.c_int32
+    L.fr_plan_static_schedule.restype = C.c_int32
+    L.fr_plan_static_schedule.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+    L.fr_plan_records.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
     L.fr_plan_workspace_bytes.restype = C.c_int64
     L.fr_plan_workspace_bytes.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
     L.fr_pipeline_create.restype = C.c_void_p
@@ -243,6 +247,27 @@ class Plan:
         got = lib().fr_plan_dump(self._h, buf.ctypes.data_as(C.POINTER(C.c_int32)),
                                  C.c_int32(buf.size))
         return buf[:got]
+
+    def records(self, groups: int = 1) -> np.ndarray:
+        """The device program for ``groups`` groups per series: (records, 16) int32."""
+        n = int(lib().fr_plan_records(self._h, groups, None, 0))
+        buf = np.zeros((max(n, 1), 16), dtype=np.int32)
+        check(lib().fr_plan_records(self._h, groups, buf.ctypes.data, buf.size))
+        return buf[:n]
+
+    def static_schedule(self, groups: int = 1):
+        """(header dict, (entries, 16) int32) of the plan's static schedule, or None."""
+        n = int(lib().fr_plan_static_schedule(self._h, groups, None, 0))
+        if n <= 0:
+            return None
+        buf = np.zeros(32 + n * 16, dtype=np.int32)
+        check(lib().fr_plan_static_schedule(self._h, groups, buf.ctypes.data, buf.size))
+        rows, G = int(buf[1]), int(buf[3])
+        head = {"entries": n, "rows": rows, "frames": int(buf[2]), "groups": G,
+                "row_src": [int(v) for v in buf[4:4 + rows]],
+                "group_begin": [int(v) for v in buf[8:8 + G]],
+                "group_rows": [int(v) for v in buf[16:16 + G]]}
+        return head, buf[32:].reshape(n, 16)
 
     def workspace_bytes(self, N: int, T: int, lookup_rows: int) -> int:
         return int(lib().fr_plan_workspace_bytes(self._h, N, T, lookup_rows))

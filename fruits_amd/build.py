@@ -18,14 +18,15 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libfruits_hip.so")
 HEADERS = ["kernels.h", "plan.h", "walk.h", "walk_scan.h", "coswiss.h", "walk_packed.h",
-           "launch_cache.h",
+           "launch_cache.h", "static_programs.h",
            os.path.join("..", "..", "include", "fruits_hip.h")]
 
 
 def units():
     """(object name, source, extra flags)"""
     out = [("kernels_misc", "kernels_misc.hip", []), ("plan", "plan.cpp", []),
-           ("capi", "capi.cpp", []), ("walk_team1", "walk_inst.hip", ["-DWALK_TEAM1"])]
+           ("capi", "capi.cpp", []),
+           ("walk_static_reg", "walk_static_inst.hip", ["-DSTATIC_REGISTRY"]), ("walk_team1", "walk_inst.hip", ["-DWALK_TEAM1"])]
     for mode in (0, 1):
         for lv in (2, 4, 6, 8):
             out.append((f"walk_m{mode}_l{lv}", "walk_inst.hip",
@@ -34,7 +35,22 @@ def units():
         out.append((f"walk_packed_m{mode}", "walk_packed_inst.hip", [f"-DWALK_MODE={mode}"]))
     for s in (1, 2, 3, 4):
         out.append((f"coswiss_s{s}", "coswiss_inst.hip", [f"-DCOS_S={s}"]))
+    for i in range(static_program_count()):
+        # no a*b+c contraction: the interpreter cannot fuse a letter's product with the first
+        # add of the scan (the product sits behind a branch on the letter's length) and the
+        # reference rounds it too - the static kernels stay bit-identical to both
+        out.append((f"walk_static_{i}", "walk_static_inst.hip",
+                    [f"-DSTATIC_PROG={i}", "-ffp-contract=off"]))
     return out
+
+
+def static_program_count() -> int:
+    """Number of pre-generated static walk programs (csrc/static_programs.h, gen_static.py)."""
+    with open(os.path.join(CSRC, "static_programs.h")) as f:
+        for line in f:
+            if line.startswith("// programs:"):
+                return int(line.split(":")[1])
+    return 0
 
 
 def hipcc() -> str:

@@ -457,6 +457,44 @@ int32_t fr_plan_dump(const fr_plan_t *plan, int32_t *buf, int32_t cap) {
   return n;
 }
 
+int32_t fr_plan_records(fr_plan_t *plan, int32_t groups, int32_t *buf, int64_t cap_words) {
+  if (!plan || !plan->p || plan->p->cos) return fail(FR_E_ARG, "fr_plan_records: not a trie plan");
+  fr::Plan &p = *plan->p;
+  std::lock_guard<std::mutex> lock(p.mu);
+  const fr::GroupedProgram &gp = fr::grouped(p, groups);
+  const int64_t n = (int64_t)gp.recs.size();
+  if (buf != nullptr && cap_words >= n * 16)
+    std::memcpy(buf, gp.recs.data(), (size_t)n * 64);
+  return (int32_t)n;
+}
+
+int32_t fr_plan_static_schedule(fr_plan_t *plan, int32_t groups, int32_t *buf, int64_t cap_words) {
+  if (!plan || !plan->p) return fail(FR_E_ARG, "fr_plan_static_schedule: null plan");
+  fr::Plan &p = *plan->p;
+  std::lock_guard<std::mutex> lock(p.mu);
+  const fr::StaticSchedule sc = fr::static_schedule(p, groups);
+  if (!sc.ok) return 0;
+  const int64_t n = (int64_t)sc.entries.size();
+  // header (32 words): entries, rows, frames, groups, row sources [4..8), group_begin
+  // [8..16), rows read by each group [16..24); then the entries
+  const int64_t words = 32 + n * 16;
+  if (sc.groups > 8) return 0;
+  if (buf != nullptr && cap_words >= words) {
+    std::memset(buf, 0, 128);
+    buf[0] = (int32_t)n;
+    buf[1] = sc.rows;
+    buf[2] = sc.frames;
+    buf[3] = sc.groups;
+    for (int r = 0; r < sc.rows; ++r) buf[4 + r] = sc.row_src[r];
+    for (int g = 0; g < sc.groups; ++g) {
+      buf[8 + g] = sc.group_begin[g];
+      buf[16 + g] = sc.group_rows[g];
+    }
+    std::memcpy(buf + 32, sc.entries.data(), (size_t)n * 64);
+  }
+  return (int32_t)n;
+}
+
 int64_t fr_plan_workspace_bytes(const fr_plan_t *plan, int64_t N, int64_t T, int64_t lookup_rows) {
   if (!plan || !plan->p || N < 0 || T < 0 || lookup_rows < 0)
     return fail(FR_E_ARG, "fr_plan_workspace_bytes: bad argument");
@@ -589,12 +627,29 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   const bool auto_groups = !wave_rows && !packed && groups <= 0 && env_int("FRUITS_HIP_GROUPS", 0) <= 0;
   const int64_t resident = auto_groups ? query_resident(p, N, T, fu != nullptr, vec_ok_pre) : 0;
   fr::GroupedProgram *gpp = nullptr;
+  int static_prog = 0;
   {
     std::lock_guard<std::mutex> lock(p.mu);
-    const int G = wave_rows ? 4 : (auto_groups ? choose_groups_walk(p, N, resident) : shape.G);
+    // A pre-compiled static program (walk_static_inst.hip) runs plans whose records equal one
+    // of the standard word sets': materialising, one aligned 1024-element chunk, unweighted
+    // Reals, the group count its schedule was generated for.  It reads no device tables, so
+    // nothing is uploaded for it (and a run of it is capturable without fr_plan_prepare).
+    if (p.static_prog < 0) {
+      const fr::GroupedProgram &g1 = fr::grouped(p, 1);
+      p.static_prog = fr::static_program_for(g1.recs.data(), (int)g1.recs.size(), &p.static_groups);
+    }
+    const int asked = groups > 0 ? groups : env_int("FRUITS_HIP_GROUPS", 0);
+    if (p.static_prog > 0 && !fu && !packed && !wave_rows && vec_ok_pre && p.weighting == 0 &&
+        p.semiring == fr::kSemiReals && T > 512 && T <= 1024 && N > 0 &&
+        (asked <= 0 || asked == p.static_groups) && env_int("FRUITS_HIP_STATIC", 1) != 0)
+      static_prog = p.static_prog;
+    const int G = static_prog ? p.static_groups
+                              : (wave_rows ? 4 : (auto_groups ? choose_groups_walk(p, N, resident) : shape.G));
     gpp = &fr::grouped(p, G);   // (map nodes are stable: the reference outlives the lock)
-    int rc = ensure_device_program(p, *gpp, st, who);
-    if (rc != FR_OK) return rc;
+    if (!static_prog) {
+      int rc = ensure_device_program(p, *gpp, st, who);
+      if (rc != FR_OK) return rc;
+    }
   }
   fr::GroupedProgram &gp = *gpp;
 
@@ -661,6 +716,10 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
       a.n_prep = fu->n_prep;
     }
   }
+  a.static_prog = static_prog;
+  // static programs of several groups run one short-lived workgroup per unit: the hardware
+  // dispatcher balances them and keeps the write front compact
+  if (static_prog && a.G > 1) a.persistent = 0;
   hipError_t e = fr::launch_iss_walk(a, p.levels, st);
   if (e != hipSuccess) return hip_fail(e, "iss_walk launch");
   return FR_OK;

@@ -71,6 +71,7 @@ struct IssArgs {
   const double *cw_mask;
   int64_t cw_x_unit_stride;
   int32_t cw_Lmax;
+  int32_t static_prog;      // != 0: the records equal pre-compiled static program #n (walk_static_inst.hip)
   uint32_t k_stride_bytes32; // out_k_stride * 8 when that fits 32 bits (and is > 0), else 0
   int32_t *resident_out;    // HOST pointer; non-null: the launcher stores the number of resident
                             // workgroups of the kernel it would launch there and launches nothing
@@ -88,6 +89,7 @@ struct IssArgs {
 int walk_chunk_elems(int64_t T);
 bool wave_rows_supported(int64_t T, int levels, bool vec_ok);
 bool packed_supported(int64_t T, int levels, int semiring);
+int static_program_for(const NodeRec *recs, int n, int *groups);
 hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st);
 hipError_t launch_mpi_finalize(double *feats, const double *cnt, int64_t N, int64_t stride,
                                const int32_t *cols, int n_cols, const int32_t *pairs, int n_pairs,

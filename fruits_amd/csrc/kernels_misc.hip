@@ -613,6 +613,7 @@ bool wave_rows_supported(int64_t T, int levels, bool vec_ok) {
 DECL_INST(0, 2) DECL_INST(0, 4) DECL_INST(0, 6) DECL_INST(0, 8)
 DECL_INST(1, 2) DECL_INST(1, 4) DECL_INST(1, 6) DECL_INST(1, 8)
 hipError_t walk_inst_team1(const IssArgs &, int, int, hipStream_t);
+hipError_t walk_static_launch(const IssArgs &, hipStream_t);
 hipError_t walk_packed_inst_m0(const IssArgs &, int, hipStream_t);
 hipError_t walk_packed_inst_m1(const IssArgs &, int, hipStream_t);
 
@@ -644,6 +645,7 @@ hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st) {
     if (levels <= 6) return walk_inst_m1_l6(a, chunk, st);
     return walk_inst_m1_l8(a, chunk, st);
   }
+  if (a.static_prog != 0) return walk_static_launch(a, st);
   if (levels <= 2) return walk_inst_m0_l2(a, chunk, st);
   if (levels <= 4) return walk_inst_m0_l4(a, chunk, st);
   if (levels <= 6) return walk_inst_m0_l6(a, chunk, st);

@@ -360,4 +360,120 @@ GroupedProgram &grouped(Plan &p, int G) {
   return p.programs.emplace(G, std::move(gp)).first->second;
 }
 
+// Static schedule: see plan.h / walk.h.  Greedy list scheduling per group - among the nodes
+// whose parent is done and whose rows are all staged, take children of open frames first
+// (frames close early), then plan order; when nothing is ready, complete the row that
+// readies the most nodes.  So the first nodes of a unit run on the first row alone while the
+// loads of the other rows are still in flight.
+static bool schedule_group(const NodeRec *recs, int n, int R, bool prefetch,
+                           std::vector<NodeRec> &out, int &frames_hi, int &need_mask) {
+  std::vector<int> parent(n, -1), pending(n, 0), need(n, 0), last_at(kMaxLevels + 1, -1);
+  int need_all = 0;
+  for (int i = 0; i < n; ++i) {
+    const NodeRec &r = recs[i];
+    const int lv = r.w[0] & 0xff, fl = r.w[0] >> 8;
+    if ((fl & F_SLOW) || r.w[6] > kRecInlineEmits || r.w[1] > kRecInlineFactors || lv >= kMaxLevels)
+      return false;
+    parent[i] = (fl & F_CHAIN) ? last_at[lv] : (lv > 0 ? last_at[lv - 1] : -1);
+    last_at[lv] = i;
+    if (parent[i] >= 0) ++pending[parent[i]];
+    for (int j = 0; j < r.w[1]; ++j) need[i] |= 1 << (r.w[2 + j] & FAC_ROW_MASK);
+    need_all |= need[i];
+  }
+  need_mask = need_all;
+  std::vector<int> frame(n, -1);
+  std::vector<char> done(n, 0);
+  bool frame_used[kStaticMaxFrames] = {false, false, false, false};
+  int staged = 0, left = n;
+  while (left > 0) {
+    int pick = -1, pick_rank = -1;
+    int free_frames = 0;
+    for (int f = 0; f < kStaticMaxFrames; ++f) free_frames += frame_used[f] ? 0 : 1;
+    for (int i = 0; i < n; ++i) {
+      if (done[i] || (need[i] & ~staged) != 0) continue;
+      if (parent[i] >= 0 && !done[parent[i]]) continue;
+      // a node with children opens a frame: its parent's frame is free again when this is
+      // the parent's last child
+      const bool frees_parent = parent[i] >= 0 && pending[parent[i]] == 1;
+      if (pending[i] > 0 && free_frames == 0 && !frees_parent) continue;
+      const int rank = parent[i] >= 0 ? 2 : 1;   // children of open frames first
+      if (rank > pick_rank) {
+        pick = i;
+        pick_rank = rank;
+      }
+    }
+    if (pick < 0) {
+      int best = -1, best_gain = -1;
+      for (int r = 0; r < R; ++r) {
+        if ((staged & (1 << r)) || !(need_all & (1 << r))) continue;
+        int gain = 0;
+        for (int i = 0; i < n; ++i)
+          if (!done[i] && (need[i] & ~(staged | (1 << r))) == 0) ++gain;
+        if (gain > best_gain) {
+          best = r;
+          best_gain = gain;
+        }
+      }
+      if (best < 0) return false;   // every row staged and still nothing ready: out of frames
+      NodeRec e{};
+      e.w[0] = kSchedStage;
+      e.w[1] = best;
+      out.push_back(e);
+      staged |= 1 << best;
+      if (prefetch && staged == need_all) {   // the row registers are free from here on
+        NodeRec pf{};
+        pf.w[0] = kSchedPrefetch;
+        out.push_back(pf);
+      }
+      continue;
+    }
+    NodeRec e = recs[pick];
+    const int par = parent[pick];
+    e.w[14] = par >= 0 ? frame[par] : -1;
+    if (par >= 0 && --pending[par] == 0) frame_used[frame[par]] = false;
+    e.w[15] = -1;
+    if (pending[pick] > 0) {
+      int f = 0;
+      while (f < kStaticMaxFrames && frame_used[f]) ++f;
+      if (f == kStaticMaxFrames) return false;
+      frame_used[f] = true;
+      frame[pick] = f;
+      e.w[15] = f;
+      frames_hi = std::max(frames_hi, f + 1);
+    }
+    out.push_back(e);
+    done[pick] = 1;
+    --left;
+  }
+  NodeRec end{};
+  end.w[0] = kRecSentinelLevel;
+  out.push_back(end);
+  return true;
+}
+
+StaticSchedule static_schedule(Plan &p, int G) {
+  StaticSchedule sc;
+  if (p.cos || p.aux_tables() != 0 || p.letter_sum || p.nodes.empty() ||
+      (int)p.nodes.size() > kStaticMaxNodes || p.rows_staged() > kStaticMaxRows)
+    return sc;
+  const GroupedProgram &gp = grouped(p, G);
+  const int R = p.rows_staged();
+  int frames_hi = 1;
+  for (int g = 0; g < gp.groups; ++g) {
+    const int b = gp.group_begin[g], n = gp.group_begin[g + 1] - 1 - b;   // without the sentinel
+    int mask = 0;
+    sc.group_begin.push_back((int32_t)sc.entries.size());
+    // the next unit of a workgroup is another group when G > 1: no prefetch entry then
+    if (!schedule_group(gp.recs.data() + b, n, R, gp.groups == 1, sc.entries, frames_hi, mask))
+      return sc;
+    sc.group_rows.push_back(mask);
+  }
+  sc.groups = gp.groups;
+  sc.rows = R;
+  sc.frames = frames_hi;
+  sc.row_src = p.row_src;
+  sc.ok = true;
+  return sc;
+}
+
 }  // namespace fr

@@ -123,6 +123,7 @@ struct Plan {
   bool multiplicative() const { return semiring != kSemiArctic; }
   int dims_used = 0;
   std::map<int, GroupedProgram> programs;  // per G
+  int static_prog = -1, static_groups = 0;  // pre-compiled static program (1 + index; 0: none; -1: not looked up)
   int device = -1;     // HIP device the uploaded tables live on (-1: nothing uploaded yet)
   std::mutex mu;       // guards `programs`, `cos->d_blob` and `device` (uploads at run time)
 
@@ -137,6 +138,22 @@ Plan *build_plan(int W, const int32_t *exps, const int32_t *L, const int32_t *Dw
 // CosWISS program of W simple words x F frequencies (rows word-major, cos.py:167-181).
 Plan *build_coswiss_plan(int W, const int32_t *exps, const int32_t *L, const int32_t *Dw, int F,
                          const float *freqs, int exponent, int total, std::string &err);
+// Schedule of a static program (walk.h, walk_static): the whole plan as one group, nodes in
+// an order that needs the staged rows as late as possible, register frames named explicitly.
+constexpr int kSchedStage = 0xfe;      // entry kind: complete staged row w[1]
+constexpr int kSchedPrefetch = 0xfd;   // entry kind: load the next unit's rows (registers are free)
+constexpr int kStaticMaxRows = 4;      // staged rows held in registers while in flight
+constexpr int kStaticMaxFrames = 4;    // open prefixes
+constexpr int kStaticMaxNodes = 32;
+struct StaticSchedule {
+  bool ok = false;                     // the plan qualifies (small, unweighted, inline letters)
+  int groups = 0, rows = 0, frames = 0;
+  std::vector<NodeRec> entries;        // per group: node / stage entries, then a sentinel
+  std::vector<int32_t> group_begin;    // first entry of every group
+  std::vector<int32_t> group_rows;     // bit r: the group reads staged row r
+  std::vector<int32_t> row_src;
+};
+StaticSchedule static_schedule(Plan &p, int G);
 // Node order for G groups (LPT assignment of units to groups), cached in the plan.
 GroupedProgram &grouped(Plan &p, int G);
 

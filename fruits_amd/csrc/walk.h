@@ -92,6 +92,8 @@ struct WalkCtx {
   int tid, lane, wave, team;   // wave = index inside the team
   int pc_begin;                // first record of the group being walked
   int buf;
+  int next_unit;               // static programs: the series whose rows are loaded next
+  bool have_rows;              // static programs: the unit's rows are already in registers
   bool first_chunk;
   bool full_chunk;      // every element of the chunk is < T (no per-lane bounds checks)
 #ifdef FRUITS_HIP_TIMING_BUILD
@@ -711,6 +713,184 @@ __device__ __forceinline__ void walk(WalkCtx &cx, Rec &cur, int &pc,
   }
 }
 
+// ---------------------------------------------------------------- static programs
+// The same walk with the program as a COMPILE-TIME constant: PG::w holds a SCHEDULE,
+// 16 words per entry like a NodeRec, of one group (the whole plan):
+//   node entries     the NodeRec of the node; w[14] / w[15] = the register frame its prefix
+//                    is read from (-1: the semiring's one) / written to (-1: nobody reads it);
+//   kSchedStage      w[1] = staged row whose registers go to LDS now (it is first read by
+//                    the next node entry);
+//   kSchedPrefetch   behind the last stage entry: the registers are free again - issue the
+//                    loads of the workgroup's next unit into them;
+//   sentinel         end of the schedule.
+// Everything the interpreter decodes per node becomes an immediate, the walk is straight-line
+// code, and - what the interpreter cannot do - the rows of a unit are loaded together but
+// each is completed only in front of the first node that reads it: the nodes that need row 0
+// alone run while the other rows are still in flight.  The host orders the schedule for that
+// (plan.cpp, static_schedule): any order in which a parent precedes its children is a valid
+// walk, since frames are registers named by constants, not a stack.
+
+template <class PG, int PC>
+__device__ __forceinline__ constexpr Rec static_rec() {
+  Rec r{};
+  for (int i = 0; i < 16; ++i) r.w[i] = PG::w[PC * 16 + i];
+  return r;
+}
+template <class PG>
+constexpr int static_kind(int pc) { return PG::w[pc * 16] & 0xff; }
+
+template <class C>
+struct StaticRegs {
+  static constexpr int U = C::CHUNK / 2 / kWalkThreads;
+  vd2 v[kStaticMaxRows][U];                  // rows in flight (global -> registers -> LDS)
+  double fr[kStaticMaxFrames][C::EP];        // open prefixes
+};
+
+// issues the loads of the rows in MASK of series n into rg.v
+template <class C, class PG, int MASK>
+__device__ __forceinline__ void static_load_rows(const WalkCtx &cx, StaticRegs<C> &rg, int64_t n) {
+  const IssArgs &a = *cx.a;
+#pragma unroll
+  for (int r = 0; r < PG::rows; ++r) {
+    if (!(MASK & (1 << r))) continue;
+    const double *gp = a.X + (n * a.D + PG::row_src[r]) * a.T;
+#pragma unroll
+    for (int k = 0; k < StaticRegs<C>::U; ++k) {
+      const int i = 2 * (k * kWalkThreads + cx.tid);
+      rg.v[r][k] = vd2{0.0, 0.0};
+      if (cx.full_chunk || i < a.T) rg.v[r][k] = *reinterpret_cast<const vd2 *>(gp + i);
+    }
+  }
+}
+
+template <class C, class PG, int PC>
+__device__ __forceinline__ void walk_static(WalkCtx &cx, StaticRegs<C> &rg, double *rows_w) {
+  constexpr int kind = static_kind<PG>(PC);
+  if constexpr (kind == kRecSentinelLevel) {
+    return;
+  } else if constexpr (kind == kSchedPrefetch) {
+    // (single-group programs only: the next unit is the same program on another series)
+    cx.have_rows = cx.next_unit < (int)cx.a->N;
+    if (cx.have_rows) static_load_rows<C, PG, PG::group_rows[0]>(cx, rg, cx.next_unit);
+    walk_static<C, PG, PC + 1>(cx, rg, rows_w);
+  } else if constexpr (kind == kSchedStage) {
+    constexpr int r = PG::w[PC * 16 + 1];
+#pragma unroll
+    for (int k = 0; k < StaticRegs<C>::U; ++k) {
+      const int i = 2 * (k * kWalkThreads + cx.tid);
+      *reinterpret_cast<vd2 *>(rows_w + r * C::CHUNK + lds_pos<C>(i)) = rg.v[r][k];
+    }
+    lds_barrier();
+    walk_static<C, PG, PC + 1>(cx, rg, rows_w);
+  } else {
+    constexpr Rec nd = static_rec<PG, PC>();
+    constexpr int fin = nd.w[14], fout = nd.w[15];
+    double ones[C::EP], dead[C::EP];
+#pragma unroll
+    for (int i = 0; i < C::EP; ++i) ones[i] = C::SEMI != 1 ? 1.0 : 0.0;
+    if constexpr (fin < 0 && fout < 0)
+      process_node<C>(cx, nd, 0, ones, dead);
+    else if constexpr (fin < 0)
+      process_node<C>(cx, nd, 0, ones, rg.fr[fout < 0 ? 0 : fout]);
+    else if constexpr (fout < 0)
+      process_node<C>(cx, nd, 0, rg.fr[fin < 0 ? 0 : fin], dead);
+    else
+      process_node<C>(cx, nd, 0, rg.fr[fin], rg.fr[fout]);
+    walk_static<C, PG, PC + 1>(cx, rg, rows_w);
+  }
+}
+
+template <class C, class PG, int GI>
+__device__ __forceinline__ void static_run_group(WalkCtx &cx, StaticRegs<C> &rg, double *rows_w,
+                                                 int64_t n, int g) {
+  if constexpr (GI < PG::groups) {
+    if (g == GI) {
+      if (!cx.have_rows) static_load_rows<C, PG, PG::group_rows[GI]>(cx, rg, n);
+      walk_static<C, PG, PG::group_begin[GI]>(cx, rg, rows_w);
+    } else {
+      static_run_group<C, PG, GI + 1>(cx, rg, rows_w, n, g);
+    }
+  }
+}
+
+// Materialising walk of a static program: one aligned time chunk (MULTI = 0, VEC), a unit is
+// (series, group of the schedule), at most kStaticMaxRows staged rows, all of them rows of X.
+template <class C, class PG>
+__global__ __launch_bounds__(kWalkThreads) void iss_walk_static_kernel(const IssArgs a) {
+  static_assert(C::MODE == 0 && C::MULTI == 0 && C::VEC && C::TEAM == 4 && !C::WEIGHTED,
+                "static programs: materialising, single chunk, aligned, unweighted");
+  static_assert(PG::rows <= kStaticMaxRows && PG::frames <= kStaticMaxFrames, "static program too wide");
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x;
+  WalkCtx cx;
+  cx.a = &a;
+  cx.rows = lds;
+  cx.tot = lds + PG::rows * C::CHUNK;
+  cx.tail = cx.tot + 2 * C::NW;
+  cx.tid = tid;
+  cx.lane = tid & 63;
+  cx.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  cx.team = 0;
+  cx.buf = 0;
+  cx.tail_buf = 0;
+  cx.carry = nullptr;
+  cx.pc_begin = 0;
+  cx.t0 = 0;
+  cx.first_chunk = true;
+  cx.full_chunk = C::CHUNK <= a.T;
+  StaticRegs<C> rg;
+  // The rows of a unit travel global -> registers -> LDS.  A unit loads its rows when it
+  // starts (all of them at once, each completed in front of its first reader) - unless the
+  // kSchedPrefetch entry of the workgroup's previous unit has already loaded them, many nodes
+  // ahead of their use and in front of most of that unit's stores (vmcnt counts in order: a
+  // load issued behind a store waits for it).
+  cx.have_rows = false;
+  bool first_unit = true;
+  constexpr int G = PG::groups;
+  const int u_end = (int)(a.N * G);
+#ifdef FRUITS_HIP_TIMING_BUILD
+  unsigned long long t_unit[4] = {0, 0, 0, 0};
+  int n_unit = 0;
+  const unsigned long long real_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+  for (int u = blockIdx.x; u < u_end; u += gridDim.x) {
+    int64_t n = u;
+    int g = 0;
+    if constexpr (G > 1) {
+      if (a.xcd_map) {   // the groups of one series meet in one XCD's L2
+        const int q = u >> 3, r = u & 7;
+        n = (int64_t)(q / G) * 8 + r;
+        g = q % G;
+      } else {
+        n = u / G;
+        g = u - (int)n * G;
+      }
+    }
+    cx.out_base = a.out + n * a.out_n_stride;
+    cx.next_unit = u + (int)gridDim.x;
+    if (!first_unit) lds_barrier();  // all reads of the previous unit's rows are done
+    first_unit = false;
+#ifdef FRUITS_HIP_TIMING_BUILD
+    if (n_unit < 4) t_unit[n_unit++] = __builtin_amdgcn_s_memrealtime();
+#endif
+    static_run_group<C, PG, 0>(cx, rg, lds, n, g);
+  }
+#ifdef FRUITS_HIP_TIMING_BUILD
+  if ((a.debug & 16) && a.dbg != nullptr && cx.lane == 0) {
+    unsigned long long *o = a.dbg + ((int64_t)blockIdx.x * 4 + cx.wave) * 12;
+    for (int i = 0; i < 4; ++i) o[i] = t_unit[i];
+    unsigned hw_id, xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    o[4] = hw_id;
+    o[5] = xcc_id;
+    o[8] = 1;
+    o[10] = real_begin;
+    o[11] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+}
+
 // WALK_SPILL_LV: fused kernels with at least this many register levels are built for three
 // waves per SIMD (<= 168 VGPRs, no scratch) instead of four (128 VGPRs, the deepest frames
 // spill 20-92 bytes per lane).  Measured (fruits_amd.build --variant, one process per arm,
@@ -950,6 +1130,7 @@ static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
   int64_t blocks = units;
   if (a.persistent) {
     // at most one resident round of workgroups (a multiple of 8 for the XCD numbering)
+    if (a.persistent > 1 && per_cu > a.persistent) per_cu = a.persistent;  // experiments: cap per CU
     int64_t resident = (int64_t)per_cu * device_cu_count();
     resident -= resident % 8;
     if (resident < 8) resident = 8;
@@ -964,6 +1145,30 @@ static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
   }
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(iss_walk_kernel<C>, dim3((unsigned)blocks), dim3(kWalkThreads), lds, st, a);
+  return hipGetLastError();
+}
+
+// launch of a static program: same persistent grid as the interpreter's
+template <class C, class PG>
+static hipError_t launch_walk_static(const IssArgs &a, hipStream_t st) {
+  const size_t lds = ((size_t)PG::rows * C::CHUNK + 4 * C::NW) * sizeof(double);
+  static LaunchCache cache;
+  int per_cu = 1;
+  hipError_t e = cache.facts(iss_walk_static_kernel<C, PG>, kWalkThreads, lds, &per_cu);
+  if (e != hipSuccess) return e;
+  const int64_t units = a.N * PG::groups;
+  if (units > 0x7fffffffLL || a.G != PG::groups) return hipErrorInvalidValue;
+  if (a.persistent > 1 && per_cu > a.persistent) per_cu = a.persistent;  // experiments: cap per CU
+  int64_t resident = (int64_t)per_cu * device_cu_count();
+  resident -= resident % 8;
+  if (resident < 8) resident = 8;
+  if (a.resident_out != nullptr) {
+    *a.resident_out = (int32_t)resident;
+    return hipSuccess;
+  }
+  const int64_t blocks = (units < resident || !a.persistent) ? units : resident;
+  hipLaunchKernelGGL((iss_walk_static_kernel<C, PG>), dim3((unsigned)blocks), dim3(kWalkThreads),
+                     lds, st, a);
   return hipGetLastError();
 }
 

@@ -124,6 +124,18 @@ int64_t fr_plan_info(const fr_plan_t *plan, int32_t what);
  * (8 per node: level, flags, n_factors, n_emit, first_emit_row, emit_mul,
  * z_mul, group) and returns the number of nodes. */
 int32_t fr_plan_dump(const fr_plan_t *plan, int32_t *buf, int32_t cap);
+/* Debug / test view of the DEVICE program for `groups` groups per series: the
+ * 64-byte node records (16 int32 words each, sentinel records included) in walk
+ * order.  Returns the number of records; copies them when `cap_words` holds them. */
+int32_t fr_plan_records(fr_plan_t *plan, int32_t groups, int32_t *buf, int64_t cap_words);
+/* Debug / test view of the plan's STATIC schedule for `groups` groups per series (small
+ * unweighted plans whose walk is compiled as straight-line code): 32 header words {entries,
+ * staged rows, frames, groups, row sources [4..8), first entry of each group [8..16), rows
+ * read by each group as bit masks [16..24)} followed by 16 words per entry (node records
+ * with the input / output frame in words 14 / 15, "complete row r" entries of kind 0xfe,
+ * "load the next unit's rows" 0xfd, a sentinel per group).  Returns the number of entries,
+ * 0 when the plan does not qualify. */
+int32_t fr_plan_static_schedule(fr_plan_t *plan, int32_t groups, int32_t *buf, int64_t cap_words);
 /* Bytes of device workspace fr_iss_run needs for this plan and shape
  * (exp tables for weighted plans, chunk carries for T > one chunk). */
 int64_t fr_plan_workspace_bytes(const fr_plan_t *plan, int64_t N, int64_t T,

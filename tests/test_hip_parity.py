@@ -772,7 +772,9 @@ def test_capture_without_prior_eager_run(fr):
     pwork = torch.empty(int(nat.lib().fr_pipeline_workspace_bytes(pipe._h, N, 0)) + 1,
                         dtype=torch.uint8, device=Xd.device)
     # an unprepared plan inside a capture: refused, the capture survives
-    other = fr.ISS(fr.words.of_weight(2, 2))._plan(0, 6)
+    # (a plan of the record interpreter: the pre-compiled static programs of the standard
+    # word sets read no device tables and have nothing to prepare)
+    other = fr.ISS(fr.words.of_weight(3, 2))._plan(0, 6)
     oout = torch.zeros((other.rows, N, T), dtype=torch.float64, device=Xd.device)
     plan.prepare(N, T)
     pipe.prepare(N)
@@ -1335,3 +1337,53 @@ def test_word_sharded_config4_full_size(fr):
         assert block.shape == (N, len(maps[r]))
         out[:, torch.as_tensor(maps[r], device="cuda")] = block
     np.testing.assert_array_equal(np.nan_to_num(out.cpu().numpy()), ref)
+
+
+@pytest.mark.parametrize("wd", [(1, 1), (1, 3), (1, 4), (2, 1), (2, 2), (2, 3), (3, 1)], ids=str)
+@pytest.mark.parametrize("mode", ["EXTENDED", "SINGLE"])
+def test_static_programs(fr, monkeypatch, wd, mode):
+    """The pre-compiled static programs of the standard word sets (walk_static_inst.hip):
+    against the C oracle, and against the record interpreter (same sums; a*b+c may contract
+    differently, so 1e-12 row-wise instead of bit equality).  Batches below and above one
+    resident round, N not a multiple of 8 (plain unit numbering), T below the chunk (bounds
+    checks), several launches in a row (the register prefetch of single-group programs)."""
+    from fruits_amd import _native as nat
+    w, d = wd
+    words = fr.words.of_weight(w, dim=d)
+    iss = fr.ISS(words, mode=getattr(fr.ISSMode, mode))
+    plan = iss._plan(0, len(words))
+    assert plan.static_schedule(1) is not None
+    strs = [str(x) for x in words]
+    for N, T, dist in ((37, 1024, "normal"), (1601, 1024, "uniform"), (64, 600, "normal"), (3080, 1022, "normal")):
+        X = gen_input({"seed": N + T, "dist": dist, "shape": [N, d, T]})
+        Xd = nat.to_device(X)
+        monkeypatch.setenv("FRUITS_HIP_STATIC", "1")
+        got = nat.to_host(iss.transform_device(Xd))
+        again = nat.to_host(iss.transform_device(Xd))
+        np.testing.assert_array_equal(got, again)
+        monkeypatch.setenv("FRUITS_HIP_STATIC", "0")
+        interp = nat.to_host(iss.transform_device(Xd))
+        rowwise_close(got, interp, rtol=1e-12)
+        if N <= 1601:
+            ref = corc.iss_transform(X, strs, mode)
+            rowwise_close(got, ref)
+            if dist == "uniform":
+                np.testing.assert_allclose(got, ref, rtol=RTOL)
+
+
+def test_static_program_is_what_runs(fr, monkeypatch):
+    """A word list that compiles to the records of a standard set runs the static kernel
+    whatever it was built from; an explicit group count the schedule was not generated for,
+    a weighting or T <= 512 fall back to the interpreter - all with the same results."""
+    from fruits_amd import _native as nat
+    X = gen_input({"seed": 11, "dist": "normal", "shape": [520, 3, 1024]})
+    Xd = nat.to_device(X)
+    ws = [fr.words.SimpleWord(str(w)) for w in fr.words.of_weight(2, dim=3)]
+    iss = fr.ISS(ws, mode=fr.ISSMode.EXTENDED)
+    a = nat.to_host(iss.transform_device(Xd))
+    for groups in (1, 2, 3, 9):
+        b = nat.to_host(iss.transform_device(Xd, groups=groups))
+        rowwise_close(a, b, rtol=1e-12)
+    monkeypatch.setenv("FRUITS_HIP_STATIC", "0")
+    c = nat.to_host(iss.transform_device(Xd))
+    rowwise_close(a, c, rtol=1e-12)

@@ -400,3 +400,79 @@ def test_plan_compiler_sanitized(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "checksum" in r.stdout and "rejected" in r.stdout
     assert "K=18 nodes=18" in r.stdout.splitlines()[0]
+
+
+def test_static_schedules_are_valid_walks():
+    """plan.cpp static_schedule: every node once, letters only on completed rows, children
+    behind their parents - for the standard word sets and 1-3 groups per series."""
+    for w, d in ((1, 3), (2, 2), (2, 3), (3, 1)):
+        for mode in (fr.ISSMode.EXTENDED, fr.ISSMode.SINGLE):
+            words = fr.words.of_weight(w, dim=d)
+            plan = fr.ISS(words, mode=mode)._plan(0, len(words))
+            for G in (1, 2, 3):
+                got = plan.static_schedule(G)
+                assert got is not None
+                head, sched = got
+                recs = plan.records(1)
+                _check_schedule_with_children(recs, head, sched)
+    # plans that do not qualify: weighted, too many nodes, Arctic letter sums
+    big = fr.words.of_weight(4, dim=2)
+    assert fr.ISS(big, mode=fr.ISSMode.EXTENDED)._plan(0, len(big)).static_schedule(1) is None
+    wd = fr.ISS(fr.words.of_weight(2, dim=2), weighting=fr.iss.weighting.Indices())
+    assert wd._plan(0, 7).static_schedule(1) is None
+
+
+def _check_schedule_with_children(recs, head, sched):
+    # parents from the interpreter records (level / chain structure, as walk() reads them)
+    parent, last_at = {}, {}
+    for r in recs[:-1]:
+        lv, fl, nid = int(r[0]) & 0xff, int(r[0]) >> 8, int(r[9])
+        parent[nid] = last_at.get(lv) if fl & 1 else (last_at.get(lv - 1) if lv > 0 else None)
+        last_at[lv] = nid
+    children = {}
+    for c, p in parent.items():
+        if p is not None:
+            children[p] = children.get(p, 0) + 1
+    seen = []
+    for g in range(head["groups"]):
+        staged, frame_of, left = set(), {}, {}
+        i = head["group_begin"][g]
+        while True:
+            e = sched[i]
+            i += 1
+            kind = int(e[0]) & 0xff
+            if kind == 0xff:
+                break
+            if kind == 0xfe:
+                staged.add(int(e[1]))
+                continue
+            if kind == 0xfd:
+                assert head["groups"] == 1
+                continue
+            nid, fin, fout = int(e[9]), int(e[14]), int(e[15])
+            for j in range(int(e[1])):
+                assert (int(e[2 + j]) & 0x7f) in staged, "letter on a row that is still in flight"
+            p = parent[nid]
+            if p is None:
+                assert fin == -1
+            else:
+                assert frame_of.get(p) == fin, "reads the frame its parent wrote"
+                left[p] -= 1
+                if left[p] == 0:
+                    del frame_of[p]
+            if children.get(nid, 0) > 0:
+                assert 0 <= fout < head["frames"] and fout not in frame_of.values()
+                frame_of[nid] = fout
+                left[nid] = children[nid]
+            else:
+                assert fout == -1
+            seen.append(nid)
+        assert not frame_of, "a frame was left open"
+    assert sorted(seen) == sorted(parent), "every node exactly once"
+
+
+def test_static_program_header_is_current():
+    """csrc/static_programs.h is generated data: regenerate and compare."""
+    from fruits_amd import gen_static
+    with open(gen_static.HEADER) as f:
+        assert f.read() == gen_static.render(), "run `python -m fruits_amd.gen_static` and rebuild"
