@@ -488,7 +488,7 @@ def main() -> None:
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "iss_walk_kernel", "algorithmic_bytes_per_launch": b_alg,
+            "kernel": "iss_walk_static_kernel (of_weight(2,3) program, one group per series)", "algorithmic_bytes_per_launch": b_alg,
             "kernel_avg_us": kernel_avg_s * 1e6,
             "timing": "one HIP event pair around the `steps` launches of the timed region / steps",
             "batches": batches,

@@ -634,16 +634,31 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     // of the standard word sets': materialising, one aligned 1024-element chunk, unweighted
     // Reals, the group count its schedule was generated for.  It reads no device tables, so
     // nothing is uploaded for it (and a run of it is capturable without fr_plan_prepare).
-    if (p.static_prog < 0) {
-      const fr::GroupedProgram &g1 = fr::grouped(p, 1);
-      p.static_prog = fr::static_program_for(g1.recs.data(), (int)g1.recs.size(), &p.static_groups);
-    }
+    int static_groups = 0;
     const int asked = groups > 0 ? groups : env_int("FRUITS_HIP_GROUPS", 0);
-    if (p.static_prog > 0 && !fu && !packed && !wave_rows && vec_ok_pre && p.weighting == 0 &&
-        p.semiring == fr::kSemiReals && T > 512 && T <= 1024 && N > 0 &&
-        (asked <= 0 || asked == p.static_groups) && env_int("FRUITS_HIP_STATIC", 1) != 0)
-      static_prog = p.static_prog;
-    const int G = static_prog ? p.static_groups
+    if (!fu && !packed && !wave_rows && vec_ok_pre && p.weighting == 0 &&
+        p.semiring == fr::kSemiReals && T > 512 && T <= 1024 && N > 0 && asked <= 3 &&
+        env_int("FRUITS_HIP_STATIC", 1) != 0) {
+      if (p.static_prog[0] < 0) {
+        const fr::GroupedProgram &g1 = fr::grouped(p, 1);
+        for (int g = 1; g <= 3; ++g)
+          p.static_prog[g] = fr::static_program_for(g1.recs.data(), (int)g1.recs.size(), g);
+        p.static_prog[0] = 0;
+      }
+      // Groups per series.  Small batches: as many groups as the schedule has, to fill the
+      // chip.  Batches whose input + output are at most twice the 256 MiB Infinity Cache: ONE
+      // group - every input row is then read once, with non-temporal loads that do not
+      // allocate in that cache, where the input would only evict output lines (config 2:
+      // 69 -> 56 us).  Larger batches stream through HBM whatever is done; there the
+      // finer units balance better (N = 8192: 273 vs 283 us).
+      const int gmax = p.static_prog[3] > 0 ? 3 : (p.static_prog[2] > 0 ? 2 : 1);
+      const double footprint = 8.0 * (double)N * (double)T * (double)(p.dims_used + p.K);
+      const bool cache_sized = N >= env_int("FRUITS_HIP_STATIC_SPLIT_BELOW", 768) &&
+                               footprint <= 2.0 * 256.0 * 1024.0 * 1024.0;
+      static_groups = asked > 0 ? asked : (cache_sized ? 1 : gmax);
+      static_prog = p.static_prog[static_groups];
+    }
+    const int G = static_prog ? static_groups
                               : (wave_rows ? 4 : (auto_groups ? choose_groups_walk(p, N, resident) : shape.G));
     gpp = &fr::grouped(p, G);   // (map nodes are stable: the reference outlives the lock)
     if (!static_prog) {
@@ -719,7 +734,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   a.static_prog = static_prog;
   // static programs of several groups run one short-lived workgroup per unit: the hardware
   // dispatcher balances them and keeps the write front compact
-  if (static_prog && a.G > 1) a.persistent = 0;
+  if (static_prog) a.persistent = env_int("FRUITS_HIP_STATIC_PERSIST", 0);
   hipError_t e = fr::launch_iss_walk(a, p.levels, st);
   if (e != hipSuccess) return hip_fail(e, "iss_walk launch");
   return FR_OK;

@@ -123,7 +123,9 @@ struct Plan {
   bool multiplicative() const { return semiring != kSemiArctic; }
   int dims_used = 0;
   std::map<int, GroupedProgram> programs;  // per G
-  int static_prog = -1, static_groups = 0;  // pre-compiled static program (1 + index; 0: none; -1: not looked up)
+  // pre-compiled static programs for 1 / 2 / 3 groups per series (1 + index; 0: none;
+  // -1: not looked up yet)
+  int static_prog[4] = {-1, -1, -1, -1};
   int device = -1;     // HIP device the uploaded tables live on (-1: nothing uploaded yet)
   std::mutex mu;       // guards `programs`, `cos->d_blob` and `device` (uploads at run time)
 

@@ -122,6 +122,18 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 #define STAMP(cx, i) do { } while (0)
 #endif
 
+// 16 bytes of an input row.  With one group per series every input element is read exactly
+// once per launch: a NON-TEMPORAL load then keeps it from allocating in the Infinity Cache,
+// where it would only evict output lines (measured with a pure data mover of the headline's
+// traffic, tools/stream_mix.hip: 64 -> 51 us at 352 MB; no difference beyond 1 GB).
+// Compile-time: a run-time select of the two loads is folded into one plain load.
+template <bool NT>
+__device__ __forceinline__ vd2 load_input(const double *p) {
+  const vd2 *q = reinterpret_cast<const vd2 *>(p);
+  if constexpr (NT) return __builtin_nontemporal_load(q);
+  return *q;
+}
+
 // reads the lane's EP elements of staged row `row`
 template <class C>
 __device__ __forceinline__ void read_row(const WalkCtx &cx, int row, double (&v)[C::EP]) {
@@ -758,7 +770,7 @@ __device__ __forceinline__ void static_load_rows(const WalkCtx &cx, StaticRegs<C
     for (int k = 0; k < StaticRegs<C>::U; ++k) {
       const int i = 2 * (k * kWalkThreads + cx.tid);
       rg.v[r][k] = vd2{0.0, 0.0};
-      if (cx.full_chunk || i < a.T) rg.v[r][k] = *reinterpret_cast<const vd2 *>(gp + i);
+      if (cx.full_chunk || i < a.T) rg.v[r][k] = load_input<PG::groups == 1>(gp + i);
     }
   }
 }

@@ -14,13 +14,9 @@ namespace fr {
 #define SP_CAT(a, b) SP_CAT2(a, b)
 
 #ifdef STATIC_REGISTRY
-template <int I> struct StaticProgOf;
-#define SP_DECL(i)                                                          \
-  hipError_t walk_static_launch_##i(const IssArgs &, hipStream_t);          \
-  template <> struct StaticProgOf<i> { using type = StaticProg##i; };
-SP_DECL(0) SP_DECL(1) SP_DECL(2) SP_DECL(3) SP_DECL(4) SP_DECL(5) SP_DECL(6) SP_DECL(7)
-SP_DECL(8) SP_DECL(9) SP_DECL(10) SP_DECL(11)
-static_assert(kStaticPrograms == 12, "list the generated programs above and below");
+#define SP_DECL(i) hipError_t walk_static_launch_##i(const IssArgs &, hipStream_t);
+SP_DECL(0) SP_DECL(1) SP_DECL(2) SP_DECL(3) SP_DECL(4) SP_DECL(5) SP_DECL(6) SP_DECL(7) SP_DECL(8) SP_DECL(9) SP_DECL(10) SP_DECL(11) SP_DECL(12) SP_DECL(13) SP_DECL(14) SP_DECL(15) SP_DECL(16) SP_DECL(17) SP_DECL(18) SP_DECL(19) SP_DECL(20) SP_DECL(21) SP_DECL(22)
+static_assert(kStaticPrograms == 23, "list the generated programs above and below");
 
 struct StaticEntry {
   const int32_t *src;
@@ -29,23 +25,23 @@ struct StaticEntry {
 };
 #define SP_ENTRY(i) {StaticProg##i::src, StaticProg##i::n_src, StaticProg##i::groups, walk_static_launch_##i}
 static const StaticEntry kStaticTable[kStaticPrograms] = {
-    SP_ENTRY(0), SP_ENTRY(1), SP_ENTRY(2), SP_ENTRY(3), SP_ENTRY(4), SP_ENTRY(5),
-    SP_ENTRY(6), SP_ENTRY(7), SP_ENTRY(8), SP_ENTRY(9), SP_ENTRY(10), SP_ENTRY(11)};
+    SP_ENTRY(0), SP_ENTRY(1), SP_ENTRY(2), SP_ENTRY(3), SP_ENTRY(4), SP_ENTRY(5), SP_ENTRY(6), SP_ENTRY(7), SP_ENTRY(8), SP_ENTRY(9), SP_ENTRY(10), SP_ENTRY(11), SP_ENTRY(12), SP_ENTRY(13), SP_ENTRY(14), SP_ENTRY(15), SP_ENTRY(16), SP_ENTRY(17), SP_ENTRY(18), SP_ENTRY(19), SP_ENTRY(20), SP_ENTRY(21), SP_ENTRY(22)};
 
-// 1 + index of the static program whose interpreter records (one group) equal `recs`, or 0;
-// *groups = the groups per series its schedule was generated for
-int static_program_for(const NodeRec *recs, int n, int *groups) {
+// 1 + index of the static program for `groups` groups per series whose interpreter records
+// (one group) equal `recs`, or 0
+int static_program_for(const NodeRec *recs, int n, int groups) {
   for (int i = 0; i < kStaticPrograms; ++i)
-    if (n == kStaticTable[i].n_src && std::memcmp(recs, kStaticTable[i].src, (size_t)n * 64) == 0) {
-      if (groups != nullptr) *groups = kStaticTable[i].groups;
+    if (groups == kStaticTable[i].groups && n == kStaticTable[i].n_src &&
+        std::memcmp(recs, kStaticTable[i].src, (size_t)n * 64) == 0)
       return i + 1;
-    }
   return 0;
 }
 
 // materialising, one aligned 1024-element chunk, unweighted Reals
 hipError_t walk_static_launch(const IssArgs &a, hipStream_t st) {
-  if (a.static_prog < 1 || a.static_prog > kStaticPrograms) return hipErrorInvalidValue;
+  if (a.static_prog < 1 || a.static_prog > kStaticPrograms ||
+      kStaticTable[a.static_prog - 1].groups != a.G)
+    return hipErrorInvalidValue;
   return kStaticTable[a.static_prog - 1].launch(a, st);
 }
 #else
