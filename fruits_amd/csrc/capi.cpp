@@ -732,6 +732,15 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     }
   }
   a.static_prog = static_prog;
+  // The interpreter's share of the same finding, in the window where it was measured to pay:
+  // one group per series and a batch just above the Infinity Cache (1 to 1.5 times its
+  // 256 MiB - config 2: 70 -> 65 us; 264 MB: 43 -> 45 us, 440 MB: 88 -> 93 us, so not there).
+  {
+    const double footprint = 8.0 * (double)N * (double)T * (double)(p.dims_used + p.K);
+    const double cache = 256.0 * 1024.0 * 1024.0;
+    a.nt_input = (!fu && !packed && !wave_rows && a.G == 1 && footprint > cache &&
+                  footprint <= 1.5 * cache && env_int("FRUITS_HIP_NT_INPUT", 1) != 0) ? 1 : 0;
+  }
   // static programs of several groups run one short-lived workgroup per unit: the hardware
   // dispatcher balances them and keeps the write front compact
   if (static_prog) a.persistent = env_int("FRUITS_HIP_STATIC_PERSIST", 0);

@@ -28,8 +28,11 @@ namespace fr {
 // every piece.  So every 16-byte global access of a wave is lane-contiguous
 // (E = 2: 1 KiB per instruction) and only NW wave totals cross waves.
 template <int E_, int P_, int MAXLV_, int MULTI_, bool VEC_, bool WEIGHTED_, int TEAM_ = 4,
-          int MODE_ = 0, int SEMI_ = 0>
+          int MODE_ = 0, int SEMI_ = 0, bool NT_ = false>
 struct WalkCfg {
+  // NT: the rows of X are staged with non-temporal loads (load_input; the host asks for it
+  // when every row is read once per launch and the batch is about the size of the cache)
+  static constexpr bool NT = NT_;
   // SEMI 0: Reals (+, x) with an exclusive shift between letters; SEMI 1: Arctic
   // (max, +), letters add el * x and children continue from the INCLUSIVE maximum;
   // SEMI 2: Bayesian (max, x): the letters and weights of Reals, the scan of Arctic
@@ -1060,7 +1063,7 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
                 const int64_t t = t0 + i;
                 v[rr][k] = vd2{0.0, 0.0};
                 if (a.vec_ok) {
-                  if (cx.full_chunk || t < a.T) v[rr][k] = *reinterpret_cast<const vd2 *>(gp + t);
+                  if (cx.full_chunk || t < a.T) v[rr][k] = load_input<C::NT>(gp + t);
                 } else {
                   if (t < a.T) v[rr][k].x = gp[t];
                   if (t + 1 < a.T) v[rr][k].y = gp[t + 1];
@@ -1125,9 +1128,9 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
 
 // ---------------------------------------------------------------- launch
 template <int E, int P, int LV, int MULTI, bool VEC, bool W, int TEAM = 4, int MODE = 0,
-          int SEMI = 0>
+          int SEMI = 0, bool NT = false>
 static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
-  using C = WalkCfg<E, P, LV, MULTI, VEC, W, TEAM, MODE, SEMI>;
+  using C = WalkCfg<E, P, LV, MULTI, VEC, W, TEAM, MODE, SEMI, NT>;
   const size_t lds = ((size_t)a.R * C::CHUNK + 2 * C::NW + 2 * C::NW +
                       (MULTI == 1 ? a.carry_slots : 0)) *
                      sizeof(double);

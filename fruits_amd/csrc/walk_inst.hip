@@ -38,6 +38,14 @@ static hipError_t inst_w(const IssArgs &a, hipStream_t st) {
   if (a.semiring == kSemiBayesian)
     return a.aux ? launch_walk_cfg<E, PP, WALK_LV, MULTI, VEC, true, 4, WALK_MODE, 2>(a, st)
                  : launch_walk_cfg<E, PP, WALK_LV, MULTI, VEC, false, 4, WALK_MODE, 2>(a, st);
+#if WALK_MODE == 0
+  // unweighted Reals, one aligned chunk, one group per series on a cache-sized batch: the
+  // input is staged with non-temporal loads (capi.cpp sets nt_input)
+  if constexpr (MULTI == 0 && VEC) {
+    if (a.nt_input && !a.aux)
+      return launch_walk_cfg<E, PP, WALK_LV, MULTI, VEC, false, 4, WALK_MODE, 0, true>(a, st);
+  }
+#endif
   return a.aux ? launch_walk_cfg<E, PP, WALK_LV, MULTI, VEC, true, 4, WALK_MODE>(a, st)
                : launch_walk_cfg<E, PP, WALK_LV, MULTI, VEC, false, 4, WALK_MODE>(a, st);
 }
