@@ -317,7 +317,7 @@ class CosPlan(Plan):
     """Device program of a cosine weighted ISS (fr_plan_create_coswiss): rows
     word-major, ``len(freqs)`` rows per word."""
 
-    MAX_EXPONENT = 4
+    MAX_EXPONENT = 8
     MAX_LETTERS = 16
 
     def __init__(self, words: Sequence[np.ndarray], freqs, exponent: int, total: bool):

@@ -33,7 +33,7 @@ def units():
                         [f"-DWALK_MODE={mode}", f"-DWALK_LV={lv}"]))
     for mode in (0, 1):
         out.append((f"walk_packed_m{mode}", "walk_packed_inst.hip", [f"-DWALK_MODE={mode}"]))
-    for s in (1, 2, 3, 4):
+    for s in (1, 2, 3, 4, 5, 6, 7, 8):
         out.append((f"coswiss_s{s}", "coswiss_inst.hip", [f"-DCOS_S={s}"]))
     for i in range(static_program_count()):
         # no a*b+c contraction: the interpreter cannot fuse a letter's product with the first

@@ -1244,7 +1244,9 @@ int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32
   const size_t o_hist = align_up(o_groups + groups.size() * 4, 256);
   const size_t o_out = align_up(o_hist + (size_t)n_dev * 256 * 4, 256);
   const size_t o_succ = align_up(o_out + (size_t)n_dev * 8, 256);
-  const size_t need = align_up(o_succ + (size_t)n_dev * 8, 256);
+  const size_t o_cnt = align_up(o_succ + (size_t)n_dev * 8, 256);
+  const size_t o_cand = align_up(o_cnt + ((size_t)n_dev + 1) * 4, 256);   // (+1: jobs left in the passes)
+  const size_t need = align_up(o_cand + (size_t)n_dev * fr::kSelSmallCap * 8, 256);
   const int dev = current_device_id();
   if (dev < 0 || dev >= kScratchDevices) return fail(FR_E_ARG, "fr_select_ranks: device id");
   std::lock_guard<std::mutex> lock(g_scratch_mu);
@@ -1265,10 +1267,13 @@ int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32
                           st)) != hipSuccess ||
       (e = hipMemsetAsync(b + o_hist, 0, (size_t)n_dev * 256 * 4, st)) != hipSuccess ||
       (e = hipMemsetAsync(b + o_succ, 0xff, (size_t)n_dev * 8, st)) != hipSuccess ||
+      (e = hipMemsetAsync(b + o_cnt, 0, ((size_t)n_dev + 1) * 4, st)) != hipSuccess ||
       (e = fr::launch_select_ranks(b + o_jobs, n_dev, b + o_groups, n_groups, N, T,
                                    reinterpret_cast<unsigned int *>(b + o_hist),
                                    reinterpret_cast<double *>(b + o_out),
-                                   reinterpret_cast<unsigned long long *>(b + o_succ), st)) !=
+                                   reinterpret_cast<unsigned long long *>(b + o_succ),
+                                   reinterpret_cast<unsigned long long *>(b + o_cand),
+                                   reinterpret_cast<unsigned int *>(b + o_cnt), st)) !=
           hipSuccess ||
       (e = hipMemcpyAsync(dev_out.data(), b + o_out, (size_t)n_dev * 8, hipMemcpyDeviceToHost,
                           st)) != hipSuccess ||

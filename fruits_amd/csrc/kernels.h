@@ -108,15 +108,17 @@ hipError_t launch_sieve(int kind, const double *A, int64_t N, int64_t T, int64_t
 // jobs sorted so that the jobs of one group (<= kSelGroupMax, same row block) are adjacent;
 // groups = int2 {first job, count}
 constexpr int kSelGroupMax = 8;
+constexpr int kSelSmallCap = 2048;   // candidates a job settles inside one workgroup (kernels_misc.hip)
 // job.pad bit 0: also return the next order statistic (succ[job] = its order key; all-ones
 // when there is none); succ must be preset to all-ones
 hipError_t launch_select_ranks(void *jobs, int n_jobs, const void *groups, int n_groups, int64_t N,
                                int64_t T, unsigned int *hist, double *out,
-                               unsigned long long *succ, hipStream_t st);
+                               unsigned long long *succ, unsigned long long *cand,
+                               unsigned int *cand_count, hipStream_t st);
 constexpr int kSelJobBytes = 32;
 hipError_t launch_pre_transform(const double *A, int64_t N, int64_t T, int64_t a_stride, int inc,
                                 double *out, hipStream_t st);
-constexpr int kCosMaxExponent = 4;
+constexpr int kCosMaxExponent = 8;
 hipError_t launch_coswiss(IssArgs &a, int exponent, hipStream_t st);
 hipError_t launch_coswiss_ffn(const double *X, int64_t N, int64_t D, int64_t T, const double *A,
                               const double *b, const double *Cm, int hidden, double *Z,

@@ -423,9 +423,12 @@ hipError_t launch_arctic_argmax(const double *V, int64_t rows, int64_t N, int64_
 // ---------------------------------------------------------------- rank selection (fit)
 // SegmentSieve._fit needs np.quantile of the pre-transformed fit sample
 // (fruits/sieving/segment.py:66-75, increment.py:73-74).  np.quantile interpolates
-// between two ORDER STATISTICS; those are found here exactly by an 8-pass radix
-// select over the order-preserving 64-bit image of the doubles (one job per wanted
-// rank), so the (N_fit, T) rows never leave the device.
+// between two ORDER STATISTICS; those are found here exactly by a radix select over the
+// order-preserving 64-bit image of the doubles (one job per wanted rank), so the
+// (N_fit, T) rows never leave the device.  Three histogram passes fix the leading 24 bits
+// (sign, exponent, 12 mantissa bits); the few elements that share them (<= kSelSmall,
+// else the histogram passes simply go on) are gathered in ONE more pass over the data and
+// the remaining 40 bits are settled inside a workgroup: 4 passes over the data instead of 9.
 struct SelJob {
   const double *base;        // (N, T) row block of one iterated sum
   unsigned long long prefix; // key bits fixed so far
@@ -443,6 +446,13 @@ __device__ __forceinline__ double key_to_double(unsigned long long k) {
   return __longlong_as_double((long long)u);
 }
 
+// SelJob::pad: bit 0 the caller also wants the NEXT order statistic; bit 1 that one lies
+// outside what this job has seen (select_succ_kernel finds it); bit 2 the candidates that
+// share the job's leading 24 bits fit a workgroup (their number in pad >> 8): no further
+// histogram passes, select_gather_kernel + select_small_kernel finish the job
+constexpr int kSelSmall = kSelSmallCap;   // (the host sizes the candidate lists with it)
+constexpr int kSelSmallShift = 40;   // bits below this are settled among the gathered candidates
+
 // One block column per GROUP of jobs that read the same (N, T) row block (the ranks and
 // differencing orders one iterated sum is asked for): every element is loaded once per
 // pass for all of them.
@@ -453,6 +463,10 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const SelJob *__restri
                                                            unsigned int *__restrict__ hist) {
   __shared__ unsigned int lh[kSelGroupJobs][256];
   const int jb = groups[blockIdx.y].x, nj = groups[blockIdx.y].y;
+  // jobs that finish among their gathered candidates take no part in later passes
+  bool any = false;
+  for (int j = 0; j < nj; ++j) any = any || !(jobs[jb + j].pad & 4);
+  if (!any) return;
   for (int j = 0; j < nj; ++j) lh[j][threadIdx.x] = 0;
   __syncthreads();
   const double *base = jobs[jb].base;
@@ -468,7 +482,11 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const SelJob *__restri
     unsigned long long key = 0;
     int key_inc = -1;
     for (int j = 0; j < nj; ++j) {
+      if (jobs[jb + j].pad & 4) continue;
       const int inc = jobs[jb + j].inc;
+      // first pass: no prefix yet - jobs of one differencing order see the same histogram,
+      // which is counted once and copied below
+      if (shift == 56 && j > 0 && inc == jobs[jb + j - 1].inc) continue;
       if (inc != key_inc) {  // jobs are sorted by differencing order
         key = order_key(diff_at(base + n * T, t, inc));
         key_inc = inc;
@@ -492,14 +510,21 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const SelJob *__restri
     }
   }
   __syncthreads();
-  for (int j = 0; j < nj; ++j)
-    if (lh[j][threadIdx.x]) atomicAdd(&hist[(jb + j) * 256 + threadIdx.x], lh[j][threadIdx.x]);
+  for (int j = 0; j < nj; ++j) {
+    if (jobs[jb + j].pad & 4) continue;
+    int src = j;   // first pass: the histogram of the first job of this differencing order
+    if (shift == 56)
+      while (src > 0 && jobs[jb + src - 1].inc == jobs[jb + j].inc) --src;
+    if (lh[src][threadIdx.x]) atomicAdd(&hist[(jb + j) * 256 + threadIdx.x], lh[src][threadIdx.x]);
+  }
 }
 
 __global__ void select_pick_kernel(SelJob *__restrict__ jobs, int shift,
                                    unsigned int *__restrict__ hist, double *__restrict__ out,
-                                   unsigned long long *__restrict__ succ) {
+                                   unsigned long long *__restrict__ succ,
+                                   unsigned int *__restrict__ n_big) {
   const int job = blockIdx.x;
+  if (jobs[job].pad & 4) return;   // (its histogram received nothing)
   if (threadIdx.x == 0) {
     long long k = jobs[job].k, run = 0;
     int d = 0;
@@ -510,6 +535,12 @@ __global__ void select_pick_kernel(SelJob *__restrict__ jobs, int shift,
     }
     jobs[job].k = k - run;
     jobs[job].prefix |= (unsigned long long)d << shift;
+    if (shift == kSelSmallShift) {
+      if (hist[job * 256 + d] <= (unsigned int)kSelSmall)
+        jobs[job].pad |= 4 | ((int)hist[job * 256 + d] << 8);
+      else if (n_big != nullptr)
+        atomicAdd(n_big, 1u);   // a job that stays in the histogram passes
+    }
     if (shift == 0) {
       out[job] = key_to_double(jobs[job].prefix);
       // the NEXT order statistic (np.quantile interpolates between two neighbours): the same
@@ -525,6 +556,99 @@ __global__ void select_pick_kernel(SelJob *__restrict__ jobs, int shift,
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[job * 256 + i] = 0;
+}
+
+// One pass over the data: the keys that share a small job's leading bits go to its
+// candidate list (cand[job][0 .. kSelSmall), filled through cnt[job]).
+__global__ __launch_bounds__(256) void select_gather_kernel(const SelJob *__restrict__ jobs,
+                                                             const int2 *__restrict__ groups,
+                                                             int64_t N, int64_t T,
+                                                             unsigned long long *__restrict__ cand,
+                                                             unsigned int *__restrict__ cnt) {
+  const int jb = groups[blockIdx.y].x, nj = groups[blockIdx.y].y;
+  bool any = false;
+  for (int j = 0; j < nj; ++j) any = any || (jobs[jb + j].pad & 4);
+  if (!any) return;
+  const double *base = jobs[jb].base;
+  const int64_t per_series = (N >= (int64_t)gridDim.x) ? 1 : ((int64_t)gridDim.x + N - 1) / N;
+  const int64_t n_first = (int64_t)blockIdx.x / per_series, part = (int64_t)blockIdx.x % per_series;
+  const int64_t n_step = ((int64_t)gridDim.x + per_series - 1) / per_series;
+  const int64_t t_len = (T + per_series - 1) / per_series;
+  const int64_t t_lo = part * t_len, t_hi = (t_lo + t_len < T) ? t_lo + t_len : T;
+  for (int64_t n = n_first; n < N; n += n_step)
+  for (int64_t t = t_lo + threadIdx.x; t < t_hi; t += blockDim.x) {
+    unsigned long long key = 0;
+    int key_inc = -1;
+    for (int j = 0; j < nj; ++j) {
+      if (!(jobs[jb + j].pad & 4)) continue;
+      const int inc = jobs[jb + j].inc;
+      if (inc != key_inc) {
+        key = order_key(diff_at(base + n * T, t, inc));
+        key_inc = inc;
+      }
+      if ((key >> kSelSmallShift) == (jobs[jb + j].prefix >> kSelSmallShift)) {
+        const unsigned int slot = atomicAdd(&cnt[jb + j], 1u);
+        if (slot < (unsigned int)kSelSmall) cand[(int64_t)(jb + j) * kSelSmall + slot] = key;
+      }
+    }
+  }
+}
+
+// One workgroup per small job: the k-th smallest of its candidates (and the next one) by
+// counting - every thread ranks its candidates against all of them in LDS.
+__global__ __launch_bounds__(256) void select_small_kernel(SelJob *__restrict__ jobs,
+                                                            const unsigned long long *__restrict__ cand,
+                                                            const unsigned int *__restrict__ cnt,
+                                                            double *__restrict__ out,
+                                                            unsigned long long *__restrict__ succ) {
+  __shared__ unsigned long long keys[kSelSmall];
+  __shared__ unsigned long long next_key;
+  const int job = blockIdx.x;
+  if (!(jobs[job].pad & 4)) return;
+  int n = (int)cnt[job];
+  if (n > kSelSmall) n = kSelSmall;   // (cannot happen: the histogram counted the same elements)
+  const long long k = jobs[job].k;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) keys[i] = cand[(int64_t)job * kSelSmall + i];
+  if (threadIdx.x == 0) next_key = ~0ull;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const unsigned long long mine = keys[i];
+    int lt = 0, eq = 0;
+    for (int j = 0; j < n; ++j) {
+      const unsigned long long other = keys[j];
+      lt += other < mine;
+      eq += other == mine;
+    }
+    if (lt <= k && k < lt + eq) {          // (every copy of the k-th key writes the same)
+      out[job] = key_to_double(mine);
+      jobs[job].prefix = mine;
+      if (jobs[job].pad & 1) {
+        if (k + 1 < lt + eq) succ[job] = mine;
+        else atomicMin(&next_key, ~0ull - 1);   // marks: look for the smallest larger key
+      }
+    }
+  }
+  __syncthreads();
+  if (!(jobs[job].pad & 1) || next_key == ~0ull) return;
+  // the next order statistic is the smallest candidate above the selected key - or, when the
+  // selected key is the largest candidate, outside the list (select_succ_kernel)
+  const unsigned long long sel = jobs[job].prefix;
+  unsigned long long best = ~0ull;
+  for (int i = threadIdx.x; i < n; i += blockDim.x)
+    if (keys[i] > sel && keys[i] < best) best = keys[i];
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long w = __shfl_xor(best, o);
+    best = w < best ? w : best;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) next_key = ~0ull;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0 && best != ~0ull) atomicMin(&next_key, best);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (next_key != ~0ull) succ[job] = next_key;
+    else jobs[job].pad |= 2;
+  }
 }
 
 // smallest key above the selected one, for the jobs select_pick_kernel flagged (pad & 2);
@@ -574,21 +698,39 @@ __global__ __launch_bounds__(256) void select_succ_kernel(const SelJob *__restri
 
 hipError_t launch_select_ranks(void *jobs, int n_jobs, const void *groups, int n_groups, int64_t N,
                                int64_t T, unsigned int *hist, double *out,
-                               unsigned long long *succ, hipStream_t st) {
+                               unsigned long long *succ, unsigned long long *cand,
+                               unsigned int *cand_count, hipStream_t st) {
   if (n_jobs <= 0 || n_groups <= 0 || N * T <= 0) return hipSuccess;
   int64_t bpj = (N * T + 256 * 16 - 1) / (256 * 16);
   if (bpj > 512) bpj = 512;
   if (bpj < 1) bpj = 1;
+  SelJob *jb = static_cast<SelJob *>(jobs);
+  const int2 *gr = static_cast<const int2 *>(groups);
   for (int shift = 56; shift >= 0; shift -= 8) {
+    // (below kSelSmallShift only the jobs with too many candidates for a workgroup - heavy
+    // ties - are still in the histogram passes; groups without one return at once)
     hipLaunchKernelGGL(select_hist_kernel, dim3((unsigned)bpj, (unsigned)n_groups), dim3(256), 0,
-                       st, static_cast<const SelJob *>(jobs), static_cast<const int2 *>(groups), N,
-                       T, shift, hist);
-    hipLaunchKernelGGL(select_pick_kernel, dim3((unsigned)n_jobs), dim3(64), 0, st,
-                       static_cast<SelJob *>(jobs), shift, hist, out, succ);
+                       st, jb, gr, N, T, shift, hist);
+    hipLaunchKernelGGL(select_pick_kernel, dim3((unsigned)n_jobs), dim3(64), 0, st, jb, shift,
+                       hist, out, succ, cand_count + n_jobs);
+    if (shift == kSelSmallShift) {
+      hipLaunchKernelGGL(select_gather_kernel, dim3((unsigned)bpj, (unsigned)n_groups), dim3(256),
+                         0, st, jb, gr, N, T, cand, cand_count);
+      hipLaunchKernelGGL(select_small_kernel, dim3((unsigned)n_jobs), dim3(256), 0, st, jb, cand,
+                         cand_count, out, succ);
+      // no job left in the histogram passes (the usual case): the five remaining passes would
+      // launch tens of thousands of workgroups only to return - ask the device
+      unsigned int n_big = 1;
+      if (hipMemcpyAsync(&n_big, cand_count + n_jobs, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipStreamSynchronize(st) != hipSuccess) {
+        (void)hipGetLastError();
+        n_big = 1;
+      }
+      if (n_big == 0) break;
+    }
   }
   hipLaunchKernelGGL(select_succ_kernel, dim3((unsigned)bpj, (unsigned)n_groups), dim3(256), 0, st,
-                     static_cast<const SelJob *>(jobs), static_cast<const int2 *>(groups), N, T,
-                     succ);
+                     jb, gr, N, T, succ);
   return hipGetLastError();
 }
 
@@ -657,6 +799,10 @@ hipError_t coswiss_inst_s1(const IssArgs &, int, hipStream_t);
 hipError_t coswiss_inst_s2(const IssArgs &, int, hipStream_t);
 hipError_t coswiss_inst_s3(const IssArgs &, int, hipStream_t);
 hipError_t coswiss_inst_s4(const IssArgs &, int, hipStream_t);
+hipError_t coswiss_inst_s5(const IssArgs &, int, hipStream_t);
+hipError_t coswiss_inst_s6(const IssArgs &, int, hipStream_t);
+hipError_t coswiss_inst_s7(const IssArgs &, int, hipStream_t);
+hipError_t coswiss_inst_s8(const IssArgs &, int, hipStream_t);
 
 hipError_t launch_coswiss(IssArgs &a, int exponent, hipStream_t st) {
   const int chunk = walk_chunk_elems(a.T);
@@ -667,6 +813,10 @@ hipError_t launch_coswiss(IssArgs &a, int exponent, hipStream_t st) {
     case 2: return coswiss_inst_s2(a, chunk, st);
     case 3: return coswiss_inst_s3(a, chunk, st);
     case 4: return coswiss_inst_s4(a, chunk, st);
+    case 5: return coswiss_inst_s5(a, chunk, st);
+    case 6: return coswiss_inst_s6(a, chunk, st);
+    case 7: return coswiss_inst_s7(a, chunk, st);
+    case 8: return coswiss_inst_s8(a, chunk, st);
     default: return hipErrorInvalidValue;
   }
 }

@@ -341,13 +341,16 @@ class FruitSlice:
                     jobs[key] = len(rows)
                     rows.append(k); incs.append(inc); ranks.append(rank)
                 return jobs[key]
+            # (what a sieve asks for depends on its q and the sample size only: once per sieve,
+            # not once per copy)
+            asks = [sv._quantile_requests(n) if sv.requires_fitting else None for sv in self._sieves]
             for k in range(block.shape[0]):
                 fitted = [sieve.copy() for sieve in self._sieves]
-                for sieve in fitted:
+                for sieve, reqs in zip(fitted, asks):
                     sieve._cache = cache
-                    if sieve.requires_fitting:
-                        reqs = sieve._quantile_requests(n)
-                        owners.append((sieve, reqs, [(job(k, sieve._inc, lo), job(k, sieve._inc, hi))
+                    if reqs is not None:
+                        inc = sieve._inc
+                        owners.append((sieve, reqs, [(job(k, inc, lo), job(k, inc, hi))
                                                      for (_, lo, hi, _) in reqs]))
                 copies.append(fitted)
             vals = nat.select_ranks(block, rows, incs, ranks) if rows else np.zeros(0)

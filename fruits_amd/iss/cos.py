@@ -7,7 +7,7 @@ product - a *term* - is an ordinary Reals iterated sum of the word over the inpu
 extended by one sin and one cos row.  The reference evaluates the
 ``(s+1)**(p-1)`` terms one after another in numba (cos.py:11-49).  Two device paths:
 
-* exponents 1..4 (``fr_plan_create_coswiss``, csrc/coswiss.h): the sum over the terms
+* exponents 1..8 (``fr_plan_create_coswiss``, csrc/coswiss.h): the sum over the terms
   factorises letter by letter, so one workgroup per (series, word, frequency) needs
   ``s+1`` scans per letter; the plan behaves like any other (``fr_iss_run``, fused
   sieve pipelines).

@@ -315,7 +315,7 @@ int fr_standardize(const double *d_X, int64_t rows, int64_t T, int32_t div_std, 
  * CosWISS.batch_transform without ffn / dropout (fruits/iss/cos.py:11-49,167-181,
  * 289-330): the cosine weighted iterated sums of W simple words (exps / L / Dw as in
  * fr_plan_create) for n_freqs frequencies (float32 like the reference's f4 argument),
- * cosine exponent 1..4, optionally with total weighting.  The result is a plan like
+ * cosine exponent 1..8, optionally with total weighting.  The result is a plan like
  * any other: fr_iss_run writes its K = W*n_freqs rows (row = word*n_freqs + freq,
  * cos.py:167-181; d_lookup is ignored), fr_plan_workspace_bytes sizes the sin / cos
  * tables the run computes, and fr_pipeline_create fuses the sieves onto it.  The device

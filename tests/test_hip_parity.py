@@ -561,6 +561,10 @@ def test_coswiss_brute_force(fr):
     (["[1][1][1]"], 4, False),               # reference test_cosine.py:113-134
     (["[1][1][1]", "[11][-1]"], 4, True),
     (["[1]", "[2][1]", "[12][2][33]", "[3][11]", "[11][23][1]"], 2, True),
+    (["[1][2]", "[2][1][1]", "[3]"], 5, True),     # exponents 5-8: factorised kernels too
+    (["[1][2][3]", "[11][2]"], 6, False),
+    (["[2][1]", "[1][1][2]"], 7, True),
+    (["[1][2]", "[3][1][2]"], 8, False),
 ])
 def test_coswiss_vs_oracle(fr, words, exponent, total):
     X = np.random.default_rng(len(words) + exponent).random((10, 3, 50)) + 0.25
@@ -611,8 +615,8 @@ def test_coswiss_term_path(fr, monkeypatch):
     # exponents beyond the factorised kernels use the reference's term-by-term form
     X = np.random.default_rng(3).random((4, 2, 40)) + 0.25
     words, freqs = ["[1][2]", "[2][1][1]"], [0.3, 0.5]
-    ref5 = orc.coswiss_transform(X, words, freqs, 5, True)
-    cw5 = fr.CosWISS([fr.words.SimpleWord(s) for s in words], freqs, exponent=5,
+    ref5 = orc.coswiss_transform(X, words, freqs, 9, True)
+    cw5 = fr.CosWISS([fr.words.SimpleWord(s) for s in words], freqs, exponent=9,
                      total_weighting=True)
     assert not cw5._native()
     out5 = cw5.fit_transform(X)
@@ -688,7 +692,7 @@ def test_random_coswiss_differential(fr, seed):
     words = [w for w in words if len(orc.parse_word(w)) <= 4] or ["[1]"]
     freqs = [float(f) for f in rng.choice([0.05, 0.15, 0.25, 0.5, 0.75, 1.0, 2.0],
                                           size=int(rng.integers(1, 4)), replace=False)]
-    exponent = int(rng.integers(1, 5))
+    exponent = int(rng.integers(1, 9))
     total = bool(rng.random() < 0.5)
     X = rng.random((N, D, T)) * 0.9 + 0.3
     out = fr.CosWISS([fr.words.SimpleWord(s) for s in words], freqs, exponent=exponent,
@@ -874,7 +878,7 @@ def test_coswiss_dropout_fused_and_long(fr, monkeypatch, T):
 
 
 def test_coswiss_unsupported(fr):
-    cw = fr.CosWISS([fr.words.SimpleWord("[1]")], [0.5], dropout=0.5, exponent=7)
+    cw = fr.CosWISS([fr.words.SimpleWord("[1]")], [0.5], dropout=0.5, exponent=9)
     with pytest.raises(NotImplementedError):
         cw.transform_device(None)
     with pytest.raises(ValueError):
