@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(_HERE, os.environ.get("FRUITS_HIP_LIB", "libfruits_hip.s
 
 FR_W_NONE, FR_W_NONTOTAL, FR_W_TOTAL = 0, 1, 2
 FR_SIEVE_NPI, FR_SIEVE_MPI, FR_SIEVE_END = 0, 1, 2
+FR_SIEVE_SERIES_CUTS = 0x100   # OR-ed into a kind: the sieve's cuts are slots of a per-series table
 (FR_INFO_ROWS, FR_INFO_NODES, FR_INFO_LEVELS, FR_INFO_DIMS_USED, FR_INFO_MAX_DIM,
  FR_INFO_ALPHAS, FR_INFO_GROUPS, FR_INFO_SHARED, FR_INFO_STAGED_ROWS) = range(9)
 FR_E_ARG, FR_E_DIM, FR_E_HIP, FR_E_NOMEM, FR_E_LIMIT, FR_E_INDEX = -1, -2, -3, -4, -5, -6
@@ -34,7 +35,7 @@ EXPORTS = [
     "fr_pipeline_workspace_bytes", "fr_pipeline_run", "fr_pipeline_set_quantiles",
     "fr_select_ranks", "fr_coswiss_combine", "fr_plan_create_coswiss", "fr_nan_to_num",
     "fr_plan_prepare", "fr_pipeline_prepare", "fr_plan_fits", "fr_release_scratch",
-    "fr_pipeline_set_preparation", "fr_arctic_argmax", "fr_coswiss_set_dropout",
+    "fr_pipeline_set_preparation", "fr_pipeline_set_series_cuts", "fr_arctic_argmax", "fr_coswiss_set_dropout",
     "fr_coswiss_set_input_stride", "fr_coswiss_ffn",
 ]
 
@@ -92,6 +93,7 @@ def lib():
     L.fr_plan_fits.argtypes = [C.c_void_p, C.c_int64]
     L.fr_plan_prepare.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32]
     L.fr_pipeline_prepare.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
+    L.fr_pipeline_set_series_cuts.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     L.fr_pipeline_set_preparation.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                               C.c_int32, C.c_double]
     _lib = L
@@ -415,6 +417,17 @@ class Pipeline:
             raise ValueError("quantile table must be (K, q_stride)")
         check(lib().fr_pipeline_set_quantiles(self._h, q.ctypes.data_as(C.POINTER(C.c_double))),
               "fr_pipeline_set_quantiles")
+
+    def set_series_cuts(self, table) -> None:
+        """``table`` (N, slots) int32 device tensor: the per-series boundaries of the sieves
+        created with FR_SIEVE_SERIES_CUTS, for the following runs on exactly N series."""
+        t = torch()
+        if table.dtype != t.int32 or table.dim() != 2 or not table.is_contiguous():
+            raise TypeError("the cut table must be a contiguous int32 (N, slots) device tensor")
+        check(lib().fr_pipeline_set_series_cuts(self._h, C.c_void_p(table.data_ptr()),
+                                                C.c_int64(table.shape[0]), C.c_int32(table.shape[1])),
+              "fr_pipeline_set_series_cuts")
+        self._series_cuts = table    # (keeps the tensor alive while the pipeline points at it)
 
     def set_preparation(self, D: int, inc_lag: int = 0, as_new: bool = False,
                         standardize: int = 0, std_eps: float = 1e-5) -> bool:

@@ -522,6 +522,8 @@ struct FusedArgs {          // non-null feats selects the fused sieve kernels
   double *feats = nullptr, *cnt = nullptr;
   int64_t feat_stride = 0;
   int32_t n_ops = 0, n_ops_padded = 0;
+  const int32_t *series_cuts = nullptr;   // device (N, cut_slots) per-series boundaries
+  int32_t cut_slots = 0;
   // fused preparation: d_X is the raw input, the staging forms the prepared rows
   const int32_t *prep = nullptr;   // device (n_prep, 4) table
   const double *stats = nullptr;   // device (N, n_prep, 2) or nullptr (no STD)
@@ -592,6 +594,8 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
       a.feat_stride = fu->feat_stride;
       a.n_ops = fu->n_ops;
       a.n_ops_padded = fu->n_ops_padded;
+      a.series_cuts = fu->series_cuts;
+      a.cut_slots = fu->cut_slots;
     }
     e = fr::launch_coswiss(a, c.exponent, st);
     if (e != hipSuccess) return hip_fail(e, "coswiss launch");
@@ -723,6 +727,8 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     a.feat_stride = fu->feat_stride;
     a.n_ops = fu->n_ops;
     a.n_ops_padded = fu->n_ops_padded;
+    a.series_cuts = fu->series_cuts;
+    a.cut_slots = fu->cut_slots;
     if (fu->prep) {
       if (packed || wave_rows)
         return fail(FR_E_LIMIT, w + ": the fused preparation needs the cooperative kernel");
@@ -753,6 +759,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
 
 struct PipeSieve {
   int32_t kind, inc, Q1, col, q_off;
+  bool series_cuts = false;    // cuts are slots of the per-series table (coquantile cuts)
   std::vector<int32_t> cuts;   // transformed, clamped to [0, T]
 };
 
@@ -768,6 +775,11 @@ struct fr_pipeline {
   void *d_ops = nullptr;           // (K, n_ops_padded) FeatOp
   void *d_mpi_cols = nullptr;
   bool have_quantiles = false;
+  // per-series cut table (fr_pipeline_set_series_cuts): device (cuts_N, cut_slots) int32, owned
+  // by the caller; cut_slots_needed = 1 + the highest slot a sieve names
+  const int32_t *d_series_cuts = nullptr;
+  int64_t cuts_N = 0;
+  int32_t cut_slots = 0, cut_slots_needed = 0;
   // fused preparation (fr_pipeline_set_preparation): 0 dims = none
   int32_t prep_D = 0, prep_n = 0, prep_std = 0;
   double prep_eps = 0.0;
@@ -799,7 +811,8 @@ fr_pipeline_t *fr_pipeline_create(fr_plan_t *plan, int32_t n_sieves, const int32
   int32_t col = 0, qoff = 0, n_ops = 0;
   for (int i = 0; i < n_sieves; ++i) {
     PipeSieve sv;
-    sv.kind = kinds[i];
+    sv.kind = kinds[i] & 0xff;
+    sv.series_cuts = (kinds[i] & FR_SIEVE_SERIES_CUTS) != 0;
     sv.inc = incs[i];
     sv.Q1 = Q1[i];
     const int c1 = C1[i];
@@ -821,7 +834,18 @@ fr_pipeline_t *fr_pipeline_create(fr_plan_t *plan, int32_t n_sieves, const int32
       delete pl;
       return nullptr;
     }
-    for (int j = 0; j < c1; ++j) {
+    for (int j = 0; j < c1 && sv.series_cuts; ++j) {
+      // the "cuts" of such a sieve are slots of the per-series table
+      const int64_t c = *cuts++;
+      if (c < 0 || c > 0xffff) {
+        fail(FR_E_ARG, "fr_pipeline_create: bad cut slot " + std::to_string(c));
+        delete pl;
+        return nullptr;
+      }
+      sv.cuts.push_back((int32_t)c);
+      pl->cut_slots_needed = std::max(pl->cut_slots_needed, (int32_t)c + 1);
+    }
+    for (int j = 0; j < c1 && !sv.series_cuts; ++j) {
       const int64_t c = *cuts++;
       // END reads X[:, c - 1] (index -1 wraps like numpy): the reference raises IndexError
       // outside [-T, T-1] (np.take_along_axis, fruits/sieving/segment.py:213-218)
@@ -890,6 +914,11 @@ int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
         const int C = (int)sv.cuts.size() - 1;
         if (sv.kind == FR_SIEVE_END) {
           for (int j = 0; j < C; ++j) {
+            if (sv.series_cuts) {   // the kernel reads cut_row[slot] - 1 (and wraps -1)
+              row.push_back(fr::FeatOp{FR_SIEVE_END | (1 << 16), k * pl->per_sum + sv.col + j,
+                                       sv.cuts[j + 1], 0, 0.0, 0.0});
+              continue;
+            }
             int idx = sv.cuts[j + 1] - 1;
             if (idx < 0) idx += (int)pl->T;  // numpy's wrap of index -1 (segment.py:213-218)
             row.push_back(fr::FeatOp{FR_SIEVE_END, k * pl->per_sum + sv.col + j, idx, 0, 0.0, 0.0});
@@ -899,7 +928,7 @@ int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
         const double *q = h_quant + (size_t)k * pl->q_stride + sv.q_off;
         for (int j = 0; j < C; ++j)
           for (int b = 0; b + 1 < sv.Q1; ++b)
-            row.push_back(fr::FeatOp{sv.kind | (sv.inc << 8),
+            row.push_back(fr::FeatOp{sv.kind | (sv.inc << 8) | (sv.series_cuts ? (1 << 16) : 0),
                                      k * pl->per_sum + sv.col + j * (sv.Q1 - 1) + b, sv.cuts[j],
                                      sv.cuts[j + 1], q[b], q[b + 1]});
       }
@@ -1008,6 +1037,19 @@ int fr_pipeline_prepare(fr_pipeline_t *pl, int64_t N, int32_t groups) {
   return prepare_plan(*pl->plan->p, N, pl->T, groups, true, "fr_pipeline_prepare");
 }
 
+int fr_pipeline_set_series_cuts(fr_pipeline_t *pl, const int32_t *d_cuts, int64_t N, int32_t slots) {
+  if (!pl || N < 0 || slots < 0 || (N * slots > 0 && !d_cuts))
+    return fail(FR_E_ARG, "fr_pipeline_set_series_cuts: bad argument");
+  if (slots < pl->cut_slots_needed)
+    return fail(FR_E_ARG, "fr_pipeline_set_series_cuts: the sieves name " +
+                              std::to_string(pl->cut_slots_needed) + " slots, the table has " +
+                              std::to_string(slots));
+  pl->d_series_cuts = d_cuts;
+  pl->cuts_N = N;
+  pl->cut_slots = slots;
+  return FR_OK;
+}
+
 int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, int64_t T,
                     const double *d_lookup, int64_t lookup_rows, double *d_feats,
                     int64_t feat_stride, void *d_work, int64_t work_bytes, int32_t groups,
@@ -1032,6 +1074,14 @@ int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, 
   fu.feat_stride = feat_stride;
   fu.n_ops = pl->n_ops_eff;
   fu.n_ops_padded = pl->n_ops_padded;
+  if (pl->cut_slots_needed > 0) {
+    if (!pl->d_series_cuts || pl->cuts_N != N || pl->cut_slots < pl->cut_slots_needed)
+      return fail(FR_E_ARG, "fr_pipeline_run: a sieve has per-series cuts - call "
+                            "fr_pipeline_set_series_cuts with a table for these " +
+                                std::to_string(N) + " series first");
+    fu.series_cuts = pl->d_series_cuts;
+    fu.cut_slots = pl->cut_slots;
+  }
   // (the population table of MPI features shares the feature row stride)
   if (!pl->mpi_cols.empty() && feat_stride != F)
     return fail(FR_E_ARG, "fr_pipeline_run: MPI needs feat_stride == F");

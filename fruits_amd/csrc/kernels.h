@@ -18,7 +18,8 @@ constexpr int FR_SIEVE_END_K = 2;
 // with one scalar load): END picks the value at index `lo`; NPI / MPI look at
 // t in [lo, hi) and values in (qlo, qhi] of the inc-times differenced row.
 struct FeatOp {
-  int32_t kind_inc;   // kind | inc << 8
+  int32_t kind_inc;   // kind | inc << 8 | per-series cuts << 16 (lo / hi are then slots of the
+                      // series' row of IssArgs::series_cuts)
   int32_t col;        // absolute feature column
   int32_t lo, hi;
   double qlo, qhi;
@@ -58,6 +59,10 @@ struct IssArgs {
   double *cnt;              // same shape: band population of MPI features
   int64_t feat_stride;
   int32_t n_ops, n_ops_padded;
+  // per-series segment boundaries (coquantile cuts, fruits/sieving/segment.py:51-64): (N,
+  // cut_slots) int32 in [0, T], the rows of every such sieve sorted; nullptr: none
+  const int32_t *series_cuts;
+  int32_t cut_slots;
   // CosWISS programs (coswiss.h): letters of word w = [cw_letter_begin[w], ..+1), factors of
   // letter l = factors[cw_fac_begin[l] .. cw_fac_begin[l+1]) as dimension | FAC_DIV; aux
   // holds the (F, 2, T) sin / cos tables

@@ -90,6 +90,7 @@ struct WalkCtx {
   double *out_base;     // out + n*out_n_stride + t0
   double *feat_row;     // MODE 1: feats + n*feat_stride
   double *cnt_row;      // MODE 1: band population of MPI features
+  const int32_t *cut_row;  // MODE 1: this series' row of IssArgs::series_cuts (or nullptr)
   double *carry;        // carry slots of this series (multi-chunk; LDS or global) or nullptr
   int64_t t0;           // first time index of the chunk
   int tid, lane, wave, team;   // wave = index inside the team
@@ -480,9 +481,16 @@ __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w,
                                          const double (&s)[C::EP], bool seq_steps,
                                          FusedScratch<C::EP> &sc) {
   constexpr int E = C::E, P = C::P, EP = C::EP;
-  const int kind = w[0] & 0xff, inc = w[0] >> 8, col = w[1];
+  const int kind = w[0] & 0xff, inc = (w[0] >> 8) & 0xff, col = w[1];
+  // per-series cuts (coquantile positions): lo / hi name slots of the series' cut row
+  const bool series_cuts = (w[0] >> 16) & 1;
   if (kind == FR_SIEVE_END_K) {
-    const int rel = w[2] - (int)cx.t0;  // w[2] = index of the value to pick
+    int pick = w[2];                    // index of the value to pick
+    if (series_cuts) {                  // X[:, cut - 1], index -1 wrapping like numpy
+      pick = as_const(cx.cut_row)[w[2]] - 1;
+      if (pick < 0) pick += (int)cx.a->T;
+    }
+    const int rel = pick - (int)cx.t0;
     if (rel >= 0 && rel < C::CHUNK) {
       const int wv = rel / C::SPAN;
       if (cx.wave == wv) {
@@ -500,7 +508,11 @@ __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w,
     }
     return;
   }
-  const int lo = w[2], hi = w[3];
+  int lo = w[2], hi = w[3];
+  if (series_cuts) {
+    lo = as_const(cx.cut_row)[w[2]];
+    hi = as_const(cx.cut_row)[w[3]];
+  }
   const double qlo = bits_to_double(w[4], w[5]), qhi = bits_to_double(w[6], w[7]);
   const int t_first = (int)cx.t0 + cx.wave * C::SPAN + cx.lane * E;  // element (h=0, e=0)
   double d[EP];
@@ -1002,6 +1014,7 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
       if constexpr (C::MODE == 1) {
         cx.feat_row = a.feats + n * a.feat_stride;
         cx.cnt_row = a.cnt + n * a.feat_stride;
+        cx.cut_row = a.series_cuts ? a.series_cuts + n * a.cut_slots : nullptr;
       }
       if (!first_unit || chunk > 0) lds_barrier();  // all reads of the old rows are done
       // stage the referenced rows of this chunk: coalesced 16-byte units, the

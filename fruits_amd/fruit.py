@@ -376,7 +376,7 @@ class FruitSlice:
             if self._iss[0]._ffn_size is not None:
                 return False     # every (word, frequency) reads its own transformed input
         for sv in self._sieves:
-            if type(sv) not in (NPI, MPI, END) or sv._has_float_cuts():
+            if type(sv) not in (NPI, MPI, END):
                 return False
             if type(sv) is not END and sv._inc not in (0, 1, 2):
                 return False
@@ -412,8 +412,26 @@ class FruitSlice:
                 first = np.concatenate([[0], np.cumsum(
                     [iss._depth(i) for i in range(len(iss.words))])]).astype(int)
                 rows = [r for i in indices for r in range(first[i], first[i + 1])]
-            specs = [(sv._kind, 0 if type(sv) is END else sv._inc, sv._int_cut_row(T),
-                      len(sv._q)) for sv in self._sieves]
+            # float ("coquantile") cuts differ from series to series: such a sieve names
+            # columns of a per-series table instead of indices; sieves with the same cuts
+            # share their columns (so NPI / MPI pairs still merge)
+            # (the sieves that transform are the fitted COPIES, which forget coquantile_norm -
+            # fruits/sieving/segment.py:90-91 - so the copies decide the norm here too)
+            specs, cut_columns, n_slots = [], {}, 0
+            acting = (self._sieves_extended[rows[0]] if self._sieves_extended and len(rows)
+                      else self._sieves)
+            for sv in acting:
+                inc = 0 if type(sv) is END else sv._inc
+                if sv._has_float_cuts():
+                    key = (tuple(sv._cut), sv._coquantile_norm)
+                    if key not in cut_columns:
+                        cut_columns[key] = (n_slots, sv)
+                        n_slots += len(sv._cut) + 1
+                    first = cut_columns[key][0]
+                    specs.append((sv._kind | nat.FR_SIEVE_SERIES_CUTS, inc,
+                                  np.arange(first, first + len(sv._cut) + 1), len(sv._q)))
+                else:
+                    specs.append((sv._kind, inc, sv._int_cut_row(T), len(sv._q)))
             try:
                 pipe = nat.Pipeline(plan, specs, T) if len(rows) and plan.fits(T) else None
             except ValueError:
@@ -432,9 +450,24 @@ class FruitSlice:
                         quant[k, off:off + len(sv._q)] = sv._quantiles
                         off += len(sv._q)
                 pipe.set_quantiles(quant)
+                pipe._cut_columns = [(first, sv) for first, sv in cut_columns.values()]
+                pipe._cut_slots = n_slots
                 entry = pipe
         self._fused_cache[key] = entry
         return entry
+
+    def _arm_series_cuts(self, pipe, N: int, T: int, cache) -> None:
+        """Uploads the per-series boundaries of the float-cut sieves of a fused pipeline
+        (SegmentSieve._get_transformed_cuts on this batch's cache) for a run on N series."""
+        if not getattr(pipe, "_cut_slots", 0):
+            return
+        table = np.zeros((N, pipe._cut_slots), dtype=np.int32)
+        shape = np.empty((N, T))
+        for first, sv in pipe._cut_columns:
+            sv._cache = cache
+            rows = sv._get_transformed_cuts(shape)      # sorted, leading 0; END checks its range
+            table[:, first:first + rows.shape[1]] = np.clip(rows, 0, T)
+        pipe.set_series_cuts(nat.to_device(table, dtype=np.int32))
 
     def _fusable_preparation(self, T: int):
         """(inc_lag, as_new, standardize, eps) when the preparateur chain is one the fused
@@ -532,6 +565,7 @@ class FruitSlice:
                     fused._prep_chain = (chain, int(Xd.shape[1]))
                 if fused.raw_dims > 0:
                     self._attach(cache)
+                    self._arm_series_cuts(fused, int(Xd.shape[0]), T, cache)
                     return fused.run(Xd, self._iss[0].lookup_device(Xd))
         Pd = self._prepare_device(Xd, cache, callbacks)
         for cb in callbacks:
@@ -542,6 +576,7 @@ class FruitSlice:
             if fused.raw_dims > 0:       # (was configured for raw input by another call)
                 fused.set_preparation(int(Pd.shape[1]))
                 fused._prep_chain = None
+            self._arm_series_cuts(fused, int(Pd.shape[0]), int(Pd.shape[2]), cache)
             return fused.run(Pd, self._iss[0].lookup_device(Pd))
         feats = t.zeros((X.shape[0], self.nfeatures()), dtype=t.float64, device=Pd.device)
         col = 0

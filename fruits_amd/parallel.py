@@ -182,6 +182,7 @@ def _device_block(slc, iss, X, cache, indices, depths, per_sum):
         return feats
     fused = slc._fused(int(Pd.shape[2]), indices=indices)
     if fused is not None:      # the rank's share in ONE launch, no (K_r, N, T) tensor
+        slc._arm_series_cuts(fused, int(Pd.shape[0]), int(Pd.shape[2]), cache)
         return fused.run(Pd, iss.lookup_device(Pd))
     block = iss.transform_device(Pd, indices=indices)
     col = k = 0

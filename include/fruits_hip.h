@@ -82,6 +82,10 @@ extern "C" {
 #define FR_SIEVE_NPI 0 /* fruits/sieving/increment.py:101-129 */
 #define FR_SIEVE_MPI 1 /* fruits/sieving/increment.py:132-163 */
 #define FR_SIEVE_END 2 /* fruits/sieving/segment.py:203-225   */
+/* OR-ed into a sieve's kind at fr_pipeline_create: its cuts are PER SERIES (coquantile
+ * cuts, fruits/sieving/segment.py:51-64) - the sieve's `cuts` entries then name columns
+ * ("slots") of the table given to fr_pipeline_set_series_cuts */
+#define FR_SIEVE_SERIES_CUTS 0x100
 
 typedef struct fr_plan fr_plan_t;
 typedef struct fr_pipeline fr_pipeline_t;
@@ -279,6 +283,15 @@ int fr_pipeline_set_preparation(fr_pipeline_t *pipeline, int32_t D, int32_t inc_
  * fr_pipeline_set_quantiles): fr_pipeline_run for batches of N series then only
  * enqueues work (two memsets, the exp-table kernel, the walk, the MPI finalize). */
 int fr_pipeline_prepare(fr_pipeline_t *pipeline, int64_t N, int32_t groups);
+/* Per-series segment boundaries for the sieves created with FR_SIEVE_SERIES_CUTS: device
+ * table (N, slots) int32, row n = the boundaries of series n (values in [0, T]; the slots of
+ * one sieve sorted ascending, the first one its leading 0) - what
+ * SegmentSieve._get_transformed_cuts (fruits/sieving/segment.py:51-64) returns for float
+ * ("coquantile") cuts.  The table belongs to the caller and must stay valid until the runs
+ * that use it have finished; it applies to the following fr_pipeline_run calls with exactly
+ * N series. */
+int fr_pipeline_set_series_cuts(fr_pipeline_t *pipeline, const int32_t *d_cuts, int64_t N,
+                                int32_t slots);
 int fr_pipeline_run(fr_pipeline_t *pipeline, const double *d_X, int64_t N, int64_t D, int64_t T,
                     const double *d_lookup, int64_t lookup_rows, double *d_feats,
                     int64_t feat_stride, void *d_work, int64_t work_bytes, int32_t groups,

@@ -675,6 +675,10 @@ class SieveOracle:
         self.quantiles = fit_quantiles(self.q, pre_transform(A, self.inc))
 
     def transform(self, A, X_raw=None):
+        # a sieve used on its own builds its cache from its own (N, T) input
+        # (fruits/seed.py:40-52: SharedSeedCache(X[:, np.newaxis, :]))
+        if X_raw is None:
+            X_raw = A[:, np.newaxis, :]
         if self.kind == "END":
             cuts = transformed_cuts(A.shape[0], A.shape[1], self.cut, X_raw,
                                     self.norm)

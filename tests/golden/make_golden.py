@@ -513,6 +513,13 @@ sieve_case("npi_fit_other", "NPI", "S_8_50", fit_key="S_8_50", q=(0.1, 0.9),
 sieve_case("mpi_s_default", "MPI", "S_8_50")
 sieve_case("mpi_s_q", "MPI", "S_8_50", q=(0.5, 1.0), inc=2, cut=[20, -1])
 sieve_case("mpi_x11", "MPI", "X_1_1", cut=[-1, 3, 1])
+# float ("coquantile") cuts: per-series boundaries from the path length of the input
+# (fruits/sieving/segment.py:51-64, fruits/cache.py:16-40)
+sieve_case("end_s_coq", "END", "S_8_50", cut=[0.5, 0.25, -1])
+sieve_case("npi_s_coq", "NPI", "S_8_50", q=(0.5, 1.0), cut=[0.3, -1])
+sieve_case("npi_s_coq_l1", "NPI", "S_8_50", q=(0.25, 0.75, 1.0), cut=[10, 0.6, -1], inc=0,
+           coquantile_norm="L1")
+sieve_case("mpi_s_coq", "MPI", "S_8_50", q=(0.5, 1.0), cut=[0.2, 0.8], inc=2)
 
 
 # --------------------------------------------------------------------------
@@ -705,6 +712,22 @@ assert np.array_equal(_out, arrays[_case["out"]], equal_nan=True), "spec != expe
 assert _mod.fruit.nfeatures() == _case["nfeatures"]
 
 # chained ISS (reference tests/signature/test_consecutive.py) with END
+# float cuts through a whole fruit (the fused epilogue reads them from a per-series table)
+fruit_case("coquantile_cuts", "G_16_3_96", {"name": "coq", "slices": [
+    {"preps": [{"kind": "INC"}],
+     "iss": [{"words": manifest["words"]["2,3"]["words"], "mode": "EXTENDED",
+              "weighting": {"kind": "Indices"}}],
+     "sieves": [{"kind": "NPI", "q": [0.5, 1.0], "cut": [0.3, -1]},
+                {"kind": "MPI", "q": [0.5, 1.0], "cut": [0.3, -1]},
+                {"kind": "NPI", "q": [0.25, 0.75, 1.0], "cut": [0.5, 20, 0.9], "inc": 2},
+                {"kind": "END", "cut": [0.25, 0.5, -1]}],
+     "fit_sample_size": 1.0}]}, np_seed=19)
+fruit_case("coquantile_cuts_arctic", "G_10_1_128", {"name": "coq2", "slices": [
+    {"preps": [{"kind": "NEW", "inner": {"kind": "INC"}}],
+     "iss": [{"words": ALT, "mode": "EXTENDED", "semiring": "Arctic"}],
+     "sieves": [{"kind": "NPI", "cut": [0.4, 0.7]}, {"kind": "END", "cut": [0.6, -1]}],
+     "fit_sample_size": 1.0}]}, np_seed=20)
+
 fruit_case("consecutive_end", "U_9_3_60", {"slices": [
     {"iss": [{"words": ["[12][1]", "[1][32]", "[11][121][3]"], "mode": "EXTENDED"},
              {"words": ["[11]", "[111]", "[111][1][11]", "[1][1][11]"],

@@ -314,6 +314,9 @@ def test_random_fruit_differential(fr, seed, monkeypatch):
     for _ in range(int(rng.integers(1, 5))):
         kind = str(rng.choice(["NPI", "MPI", "END"]))
         cut = sorted({int(c) for c in rng.integers(1, T, size=int(rng.integers(0, 3)))}) + [-1]
+        if rng.random() < 0.35:    # float cuts: per-series coquantile positions
+            cut = [float(c) for c in rng.choice([0.2, 0.35, 0.5, 0.8], size=int(rng.integers(1, 3)),
+                                                replace=False)] + cut[:int(rng.integers(0, 2))]
         if kind == "END":
             sieves.append({"kind": "END", "cut": cut})
         else:
@@ -514,7 +517,9 @@ def test_sieves(fr, case):
         np.testing.assert_allclose(out, G[case["out"]], rtol=1e-9, atol=1e-12)
     else:
         np.testing.assert_array_equal(out, G[case["out"]])   # counts / gathers: exact
-    np.testing.assert_array_equal(sv.copy().fit_transform(A) if not case["fit"] else out, out)
+    # (a copy forgets coquantile_norm, in the reference too: segment.py:90-91, increment.py:83-84)
+    if "coquantile_norm" not in kw:
+        np.testing.assert_array_equal(sv.copy().fit_transform(A) if not case["fit"] else out, out)
 
 
 @pytest.mark.parametrize("case", G.manifest.get("coswiss", []), ids=lambda c: c["name"])
@@ -1391,3 +1396,43 @@ def test_static_program_is_what_runs(fr, monkeypatch):
     monkeypatch.setenv("FRUITS_HIP_STATIC", "0")
     c = nat.to_host(iss.transform_device(Xd))
     rowwise_close(a, c, rtol=1e-12)
+
+
+def test_float_cuts_run_fused(fr, monkeypatch):
+    """Coquantile (float) cuts are per-series boundaries: the fused launch reads them from a
+    table (fr_pipeline_set_series_cuts) - same features as the materialising sieve kernels,
+    NPI / MPI pairs with the same cuts still merged, a batch of another size re-arms the
+    table, END range errors as in the unfused path."""
+    rng = np.random.default_rng(77)
+    T = 300
+    X = rng.standard_normal((21, 2, T)).cumsum(axis=2)
+
+    def build():
+        fruit = fr.Fruit()
+        fruit.add(fr.preparation.INC)
+        fruit.add(fr.ISS(fr.words.of_weight(3, 2), mode=fr.ISSMode.EXTENDED,
+                         weighting=fr.iss.weighting.Indices()))
+        fruit.add(fr.sieving.NPI(q=(0.5, 1.0), cut=[0.3, 100, -1]))
+        fruit.add(fr.sieving.MPI(q=(0.5, 1.0), cut=[0.3, 100, -1]))
+        fruit.add(fr.sieving.NPI(q=(0.25, 0.75), cut=0.7, inc=2))
+        fruit.add(fr.sieving.END(cut=[0.5, 0.05, -1]))
+        for slc in fruit:
+            slc.fit_sample_size = 1.0
+        return fruit
+    fused = build()
+    np.random.seed(3)
+    fused.fit(X)
+    slc = fused.get_slice()
+    assert slc._fusable() and slc._fused(T) is not None and slc._fused(T)._cut_slots == 4 + 2 + 4
+    a = fused.transform(X)
+    b = fused.transform(X[:7])                 # another batch size: the table follows
+    np.testing.assert_array_equal(a[:7], b)
+    monkeypatch.setenv("FRUITS_AMD_FUSED", "0")
+    plain = build()
+    np.random.seed(3)
+    plain.fit(X)
+    c = plain.transform(X)
+    labels = [fused.label(i) for i in range(fused.nfeatures())]
+    counts = np.array([("NPI" in s) for s in labels])
+    np.testing.assert_array_equal(a[:, counts], c[:, counts])
+    np.testing.assert_allclose(a[:, ~counts], c[:, ~counts], rtol=1e-9, atol=1e-12)
