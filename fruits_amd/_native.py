@@ -22,13 +22,13 @@ FR_W_NONE, FR_W_NONTOTAL, FR_W_TOTAL = 0, 1, 2
 FR_SIEVE_NPI, FR_SIEVE_MPI, FR_SIEVE_END = 0, 1, 2
 FR_SIEVE_SERIES_CUTS = 0x100   # OR-ed into a kind: the sieve's cuts are slots of a per-series table
 (FR_INFO_ROWS, FR_INFO_NODES, FR_INFO_LEVELS, FR_INFO_DIMS_USED, FR_INFO_MAX_DIM,
- FR_INFO_ALPHAS, FR_INFO_GROUPS, FR_INFO_SHARED, FR_INFO_STAGED_ROWS) = range(9)
+ FR_INFO_ALPHAS, FR_INFO_GROUPS, FR_INFO_SHARED, FR_INFO_STAGED_ROWS, FR_INFO_JIT_PROGRAMS) = range(10)
 FR_E_ARG, FR_E_DIM, FR_E_HIP, FR_E_NOMEM, FR_E_LIMIT, FR_E_INDEX = -1, -2, -3, -4, -5, -6
 
 EXPORTS = [
     "fr_last_error", "fr_version", "fr_device_count", "fr_malloc", "fr_free",
     "fr_memcpy_h2d", "fr_memcpy_d2h", "fr_stream_sync", "fr_plan_create",
-    "fr_plan_destroy", "fr_plan_info", "fr_plan_dump", "fr_plan_records", "fr_plan_static_schedule", "fr_plan_workspace_bytes",
+    "fr_plan_destroy", "fr_plan_info", "fr_plan_dump", "fr_plan_records", "fr_plan_static_schedule", "fr_plan_jit", "fr_plan_workspace_bytes",
     "fr_iss_run", "fr_iterated_sum_fast_host", "fr_increments",
     "fr_pathlen_lookup", "fr_sieve", "fr_pre_transform", "fr_standardize",
     "fr_pipeline_create", "fr_pipeline_destroy", "fr_pipeline_info",
@@ -77,6 +77,8 @@ def lib():
     L.fr_plan_info.argtypes = [C.c_void_p, C.c_int32]
     L.fr_plan_dump.restype = C.c_int32
     L.fr_plan_records.restype = C.c_int32
+    L.fr_plan_jit.restype = C.c_int32
+    L.fr_plan_jit.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int64]
     L.fr_plan_static_schedule.restype = C.c_int32
     L.fr_plan_static_schedule.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
     L.fr_plan_records.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
@@ -256,6 +258,17 @@ class Plan:
         buf = np.zeros((max(n, 1), 16), dtype=np.int32)
         check(lib().fr_plan_records(self._h, groups, buf.ctypes.data, buf.size))
         return buf[:n]
+
+    def jit(self, groups: int = 1, compile_only: bool = False):
+        """fr_plan_jit: (count or code size, message)."""
+        buf = C.create_string_buffer(8192)
+        rc = lib().fr_plan_jit(self._h, int(groups), 1 if compile_only else 0, buf, len(buf))
+        check(rc, "fr_plan_jit")
+        return int(rc), buf.value.decode(errors="replace")
+
+    def jit_loaded(self) -> int:
+        """Number of run-time compiled static programs this plan holds on the device."""
+        return int(lib().fr_plan_info(self._h, FR_INFO_JIT_PROGRAMS))
 
     def static_schedule(self, groups: int = 1):
         """(header dict, (entries, 16) int32) of the plan's static schedule, or None."""

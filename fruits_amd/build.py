@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libfruits_hip.so")
-HEADERS = ["kernels.h", "plan.h", "walk.h", "walk_scan.h", "coswiss.h", "walk_packed.h",
+HEADERS = ["kernels.h", "plan.h", "jit.h", "walk.h", "walk_device.h", "walk_types.h", "walk_scan.h", "coswiss.h", "walk_packed.h",
            "launch_cache.h", "static_programs.h",
            os.path.join("..", "..", "include", "fruits_hip.h")]
 
@@ -25,7 +25,7 @@ HEADERS = ["kernels.h", "plan.h", "walk.h", "walk_scan.h", "coswiss.h", "walk_pa
 def units():
     """(object name, source, extra flags)"""
     out = [("kernels_misc", "kernels_misc.hip", []), ("plan", "plan.cpp", []),
-           ("capi", "capi.cpp", []),
+           ("capi", "capi.cpp", []), ("jit", "jit.cpp", []),
            ("walk_static_reg", "walk_static_inst.hip", ["-DSTATIC_REGISTRY"]), ("walk_team1", "walk_inst.hip", ["-DWALK_TEAM1"])]
     for mode in (0, 1):
         for lv in (2, 4, 6, 8):
@@ -108,9 +108,38 @@ def build_native(force: bool = False, verbose: bool = False, jobs: int = 0,
     return lib
 
 
+JIT_HEADERS = ["walk_types.h", "walk_scan.h", "walk_device.h"]
+
+
+def write_jit_sources() -> str:
+    """csrc/jit_sources.inc: the device headers as ONE string literal (local includes and
+    include guards dropped) - the text jit.cpp hands to hipRTC in front of a schedule."""
+    parts = []
+    for h in JIT_HEADERS:
+        with open(os.path.join(CSRC, h)) as f:
+            for line in f:
+                if line.startswith('#include "') or line.startswith("#pragma once"):
+                    continue
+                parts.append(line)
+    text = "".join(parts)
+    assert ')FRJIT"' not in text
+    out = os.path.join(CSRC, "jit_sources.inc")
+    body = "static const char *kJitDeviceSource = R\"FRJIT(\n" + text + ")FRJIT\";\n"
+    try:
+        with open(out) as f:
+            if f.read() == body:
+                return out
+    except OSError:
+        pass
+    with open(out, "w") as f:
+        f.write(body)
+    return out
+
+
 def _build(lib_path: str, tag: str, defines, force: bool, verbose: bool, jobs: int,
            only=()) -> str:
     os.makedirs(OBJ, exist_ok=True)
+    write_jit_sources()
     cc = hipcc()
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
              "-Wno-unused-function"] + [f"-D{d}" for d in defines]
@@ -136,7 +165,7 @@ def _build(lib_path: str, tag: str, defines, force: bool, verbose: bool, jobs: i
     jobs = jobs or min(8, os.cpu_count() or 1)
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(compile_one, units()))
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path + ".tmp"] + objs
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path + ".tmp"] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/fruits_hip.h"
+#include "jit.h"
 #include "kernels.h"
 #include "launch_cache.h"
 #include "plan.h"
@@ -274,6 +275,43 @@ int choose_groups_walk(const fr::Plan &p, int64_t N, int64_t resident) {
   return std::min(U, 3);
 }
 
+// Run-time compiled static programs of a plan (jit.cpp), by groups per series.
+struct JitState {
+  std::map<int, fr::JitProgram> progs;
+  bool tried = false;
+  std::string error;     // why the plan has none (not an error of the caller's)
+};
+
+bool static_shape_ok(const fr::Plan &p, int64_t T) {
+  return !p.cos && p.weighting == 0 && p.semiring == fr::kSemiReals && T > 512 && T <= 1024;
+}
+
+// Compiles and loads the plan's static programs (one group and min(3, units) groups per
+// series) unless an ahead-of-time program covers it.  Called with p.mu held; failures leave
+// the plan on the interpreter.
+void ensure_jit(fr::Plan &p) {
+  if (p.jit == nullptr) p.jit = new JitState;
+  JitState &js = *static_cast<JitState *>(p.jit);
+  if (js.tried) return;
+  js.tried = true;
+  const int gmax = std::max(1, std::min(3, p.units()));
+  for (int g : {1, gmax}) {
+    if (js.progs.count(g)) continue;
+    const fr::StaticSchedule sc = fr::static_schedule(p, g);
+    if (!sc.ok || sc.groups != g) {
+      js.error = "the plan does not qualify for a static program";
+      return;
+    }
+    std::string code, err;
+    fr::JitProgram prog;
+    if (!fr::jit_compile(sc, code, err) || !fr::jit_load(code, sc, prog, err)) {
+      js.error = err;
+      return;
+    }
+    js.progs[g] = prog;
+  }
+}
+
 // One-time uploads for the node order a run of this (N, T, groups) asks for.
 int prepare_plan(fr::Plan &p, int64_t N, int64_t T, int32_t groups, bool fused, const char *who) {
   std::lock_guard<std::mutex> lock(p.mu);
@@ -416,6 +454,11 @@ void fr_plan_destroy(fr_plan_t *plan) {
     }
     for (auto &kv : plan->p->programs)
       if (kv.second.d_blob) (void)hipFree(kv.second.d_blob);
+    if (plan->p->jit) {
+      JitState *js = static_cast<JitState *>(plan->p->jit);
+      for (auto &kv : js->progs) fr::jit_unload(kv.second);
+      delete js;
+    }
     delete plan->p;
   }
   delete plan;
@@ -434,6 +477,8 @@ int64_t fr_plan_info(const fr_plan_t *plan, int32_t what) {
     case FR_INFO_GROUPS: return p.units();
     case FR_INFO_SHARED: return p.shared ? 1 : 0;
     case FR_INFO_STAGED_ROWS: return p.cos ? 0 : p.rows_staged();
+    case FR_INFO_JIT_PROGRAMS:
+      return p.jit ? (int64_t)static_cast<const JitState *>(p.jit)->progs.size() : 0;
     default: return fail(FR_E_ARG, "fr_plan_info: unknown selector");
   }
 }
@@ -510,7 +555,51 @@ int32_t fr_plan_fits(const fr_plan_t *plan, int64_t T) {
 
 int fr_plan_prepare(fr_plan_t *plan, int64_t N, int64_t T, int32_t groups) {
   if (!plan || !plan->p || N < 0 || T < 0) return fail(FR_E_ARG, "fr_plan_prepare: bad argument");
-  return prepare_plan(*plan->p, N, T, groups, false, "fr_plan_prepare");
+  fr::Plan &p = *plan->p;
+  int rc = prepare_plan(p, N, T, groups, false, "fr_plan_prepare");
+  if (rc != FR_OK) return rc;
+  // a small plan without an ahead-of-time static program gets one compiled now (hipRTC,
+  // cached on disk); a failure is not the caller's: the interpreter runs the plan
+  if (static_shape_ok(p, T) && env_int("FRUITS_HIP_JIT", 1) != 0 &&
+      env_int("FRUITS_HIP_STATIC", 1) != 0) {
+    std::lock_guard<std::mutex> lock(p.mu);
+    if (p.static_prog[0] < 0) {
+      const fr::GroupedProgram &g1 = fr::grouped(p, 1);
+      for (int g = 1; g <= 3; ++g)
+        p.static_prog[g] = fr::static_program_for(g1.recs.data(), (int)g1.recs.size(), g);
+      p.static_prog[0] = 0;
+    }
+    if (p.static_prog[1] <= 0 && fr::static_schedule(p, 1).ok) ensure_jit(p);
+  }
+  return FR_OK;
+}
+
+int32_t fr_plan_jit(fr_plan_t *plan, int32_t groups, int32_t compile_only, char *msg, int64_t msg_cap) {
+  if (!plan || !plan->p) return fail(FR_E_ARG, "fr_plan_jit: null plan");
+  fr::Plan &p = *plan->p;
+  std::lock_guard<std::mutex> lock(p.mu);
+  auto say = [&](const std::string &s) {
+    if (msg && msg_cap > 0) {
+      const size_t n = std::min((size_t)msg_cap - 1, s.size());
+      std::memcpy(msg, s.data(), n);
+      msg[n] = 0;
+    }
+  };
+  say("");
+  if (compile_only) {   // needs no GPU: the code object's size, 0 when the plan has no schedule
+    const fr::StaticSchedule sc = fr::static_schedule(p, groups);
+    if (!sc.ok) return 0;
+    std::string code, err;
+    if (!fr::jit_compile(sc, code, err)) {
+      say(err);
+      return fail(FR_E_LIMIT, "fr_plan_jit: " + err);
+    }
+    return (int32_t)code.size();
+  }
+  ensure_jit(p);
+  JitState &js = *static_cast<JitState *>(p.jit);
+  say(js.error);
+  return (int32_t)js.progs.size();
 }
 
 }  // extern "C"
@@ -631,7 +720,8 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   const bool auto_groups = !wave_rows && !packed && groups <= 0 && env_int("FRUITS_HIP_GROUPS", 0) <= 0;
   const int64_t resident = auto_groups ? query_resident(p, N, T, fu != nullptr, vec_ok_pre) : 0;
   fr::GroupedProgram *gpp = nullptr;
-  int static_prog = 0;
+  int static_prog = 0;                      // > 0: ahead-of-time program, -1: run-time compiled
+  const fr::JitProgram *jit_prog = nullptr;
   {
     std::lock_guard<std::mutex> lock(p.mu);
     // A pre-compiled static program (walk_static_inst.hip) runs plans whose records equal one
@@ -640,27 +730,37 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     // nothing is uploaded for it (and a run of it is capturable without fr_plan_prepare).
     int static_groups = 0;
     const int asked = groups > 0 ? groups : env_int("FRUITS_HIP_GROUPS", 0);
-    if (!fu && !packed && !wave_rows && vec_ok_pre && p.weighting == 0 &&
-        p.semiring == fr::kSemiReals && T > 512 && T <= 1024 && N > 0 && asked <= 3 &&
-        env_int("FRUITS_HIP_STATIC", 1) != 0) {
+    if (!fu && !packed && !wave_rows && vec_ok_pre && static_shape_ok(p, T) && N > 0 &&
+        asked <= 3 && env_int("FRUITS_HIP_STATIC", 1) != 0) {
       if (p.static_prog[0] < 0) {
         const fr::GroupedProgram &g1 = fr::grouped(p, 1);
         for (int g = 1; g <= 3; ++g)
           p.static_prog[g] = fr::static_program_for(g1.recs.data(), (int)g1.recs.size(), g);
         p.static_prog[0] = 0;
       }
+      // no ahead-of-time program: one compiled at run time by fr_plan_prepare - or right here
+      // with FRUITS_HIP_JIT=2 (a couple of seconds, once per plan; never inside a capture)
+      const bool aot = p.static_prog[1] > 0;
+      if (!aot && env_int("FRUITS_HIP_JIT", 1) == 2 && !stream_is_capturing(st)) ensure_jit(p);
+      JitState *js = aot ? nullptr : static_cast<JitState *>(p.jit);
+      auto have = [&](int g) {
+        return p.static_prog[g] > 0 || (js != nullptr && js->progs.count(g) != 0);
+      };
       // Groups per series.  Small batches: as many groups as the schedule has, to fill the
       // chip.  Batches whose input + output are at most twice the 256 MiB Infinity Cache: ONE
       // group - every input row is then read once, with non-temporal loads that do not
       // allocate in that cache, where the input would only evict output lines (config 2:
       // 69 -> 56 us).  Larger batches stream through HBM whatever is done; there the
       // finer units balance better (N = 8192: 273 vs 283 us).
-      const int gmax = p.static_prog[3] > 0 ? 3 : (p.static_prog[2] > 0 ? 2 : 1);
+      const int gmax = have(3) ? 3 : (have(2) ? 2 : 1);
       const double footprint = 8.0 * (double)N * (double)T * (double)(p.dims_used + p.K);
       const bool cache_sized = N >= env_int("FRUITS_HIP_STATIC_SPLIT_BELOW", 768) &&
                                footprint <= 2.0 * 256.0 * 1024.0 * 1024.0;
       static_groups = asked > 0 ? asked : (cache_sized ? 1 : gmax);
-      static_prog = p.static_prog[static_groups];
+      if (have(static_groups)) {
+        static_prog = p.static_prog[static_groups] > 0 ? p.static_prog[static_groups] : -1;
+        if (static_prog < 0) jit_prog = &js->progs[static_groups];
+      }
     }
     const int G = static_prog ? static_groups
                               : (wave_rows ? 4 : (auto_groups ? choose_groups_walk(p, N, resident) : shape.G));
@@ -737,7 +837,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
       a.n_prep = fu->n_prep;
     }
   }
-  a.static_prog = static_prog;
+  a.static_prog = static_prog > 0 ? static_prog : 0;
   // The interpreter's share of the same finding, in the window where it was measured to pay:
   // one group per series and a batch just above the Infinity Cache (1 to 1.5 times its
   // 256 MiB - config 2: 70 -> 65 us; 264 MB: 43 -> 45 us, 440 MB: 88 -> 93 us, so not there).
@@ -750,7 +850,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   // static programs of several groups run one short-lived workgroup per unit: the hardware
   // dispatcher balances them and keeps the write front compact
   if (static_prog) a.persistent = env_int("FRUITS_HIP_STATIC_PERSIST", 0);
-  hipError_t e = fr::launch_iss_walk(a, p.levels, st);
+  hipError_t e = jit_prog ? fr::jit_launch(*jit_prog, a, st) : fr::launch_iss_walk(a, p.levels, st);
   if (e != hipSuccess) return hip_fail(e, "iss_walk launch");
   return FR_OK;
 }

@@ -1,0 +1,254 @@
+// Run-time compilation of static walk programs with hipRTC.
+//
+// The ahead-of-time programs (static_programs.h) cover the reference's standard word sets;
+// any other plan the scheduler accepts (plan.cpp, static_schedule) gets the same straight-line
+// kernel here: the schedule is printed as a constexpr struct behind the device headers
+// (walk_types.h, walk_scan.h, walk_device.h - embedded as text by the build, jit_sources.inc)
+// and compiled for gfx950 with the flags of the ahead-of-time units (-ffp-contract=off: results
+// stay bit-identical to the interpreter's).  hipRTC is loaded with dlopen: without it the plan
+// simply keeps running on the interpreter.  Compiled code objects are cached on disk
+// (FRUITS_HIP_JIT_CACHE, default ~/.cache/fruits_amd/jit) keyed by a hash of the source.
+#include "jit.h"
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <mutex>
+#include <sstream>
+#include <vector>
+
+#include "launch_cache.h"
+
+namespace fr {
+
+namespace {
+
+#include "jit_sources.inc"   // static const char *kJitDeviceSource
+
+const char *kKernelExpr =
+    "fr::iss_walk_static_kernel<fr::WalkCfg<2, 2, 2, 0, true, false, 4, 0, 0>, fr::JitProg>";
+
+struct Rtc {
+  void *lib = nullptr;
+  int (*create)(void **, const char *, const char *, int, const char **, const char **) = nullptr;
+  int (*add_name)(void *, const char *) = nullptr;
+  int (*compile)(void *, int, const char **) = nullptr;
+  int (*log_size)(void *, size_t *) = nullptr;
+  int (*log)(void *, char *) = nullptr;
+  int (*lowered)(void *, const char *, const char **) = nullptr;
+  int (*code_size)(void *, size_t *) = nullptr;
+  int (*code)(void *, char *) = nullptr;
+  int (*destroy)(void **) = nullptr;
+  bool ok = false;
+};
+
+Rtc &rtc() {
+  static Rtc r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) return;
+    auto sym = [&](const char *n) { return dlsym(r.lib, n); };
+    r.create = reinterpret_cast<decltype(r.create)>(sym("hiprtcCreateProgram"));
+    r.add_name = reinterpret_cast<decltype(r.add_name)>(sym("hiprtcAddNameExpression"));
+    r.compile = reinterpret_cast<decltype(r.compile)>(sym("hiprtcCompileProgram"));
+    r.log_size = reinterpret_cast<decltype(r.log_size)>(sym("hiprtcGetProgramLogSize"));
+    r.log = reinterpret_cast<decltype(r.log)>(sym("hiprtcGetProgramLog"));
+    r.lowered = reinterpret_cast<decltype(r.lowered)>(sym("hiprtcGetLoweredName"));
+    r.code_size = reinterpret_cast<decltype(r.code_size)>(sym("hiprtcGetCodeSize"));
+    r.code = reinterpret_cast<decltype(r.code)>(sym("hiprtcGetCode"));
+    r.destroy = reinterpret_cast<decltype(r.destroy)>(sym("hiprtcDestroyProgram"));
+    r.ok = r.create && r.add_name && r.compile && r.log_size && r.log && r.lowered &&
+           r.code_size && r.code && r.destroy;
+  });
+  return r;
+}
+
+unsigned long long fnv1a(const std::string &s) {
+  unsigned long long h = 1469598103934665603ull;
+  for (unsigned char c : s) {
+    h ^= c;
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+
+std::string cache_dir() {
+  if (const char *d = getenv("FRUITS_HIP_JIT_CACHE")) return *d ? std::string(d) : std::string();
+  const char *home = getenv("XDG_CACHE_HOME");
+  std::string base = home && *home ? std::string(home) : std::string();
+  if (base.empty()) {
+    const char *h = getenv("HOME");
+    if (!h || !*h) return std::string();
+    base = std::string(h) + "/.cache";
+  }
+  return base + "/fruits_amd/jit";
+}
+
+void make_dirs(const std::string &path) {
+  for (size_t i = 1; i <= path.size(); ++i)
+    if (i == path.size() || path[i] == '/') (void)mkdir(path.substr(0, i).c_str(), 0755);
+}
+
+}  // namespace
+
+std::string jit_source(const StaticSchedule &sc) {
+  std::ostringstream o;
+  o << kJitDeviceSource << "\nnamespace fr {\nstruct JitProg {\n";
+  o << "  static constexpr int groups = " << sc.groups << ", rows = " << sc.rows
+    << ", frames = " << sc.frames << ";\n";
+  auto list = [&](const char *name, const std::vector<int32_t> &v, size_t n) {
+    o << "  static constexpr int32_t " << name << "[" << (n ? n : 1) << "] = {";
+    for (size_t i = 0; i < n; ++i) o << (i ? ", " : "") << v[i];
+    if (n == 0) o << 0;
+    o << "};\n";
+  };
+  list("row_src", sc.row_src, (size_t)sc.rows);
+  list("group_begin", sc.group_begin, sc.group_begin.size());
+  list("group_rows", sc.group_rows, sc.group_rows.size());
+  o << "  static constexpr int n = " << sc.entries.size() << ";\n";
+  o << "  static constexpr int32_t w[" << sc.entries.size() * 16 << "] = {\n";
+  for (const NodeRec &r : sc.entries) {
+    o << "     ";
+    for (int i = 0; i < 16; ++i) o << " " << r.w[i] << ",";
+    o << "\n";
+  }
+  o << "  };\n};\n}  // namespace fr\n";
+  return o.str();
+}
+
+bool jit_compile(const StaticSchedule &sc, std::string &code, std::string &err) {
+  if (!sc.ok) {
+    err = "the plan has no static schedule";
+    return false;
+  }
+  const std::string src = jit_source(sc);
+  char key[32];
+  snprintf(key, sizeof key, "%016llx", fnv1a(src));
+  const std::string dir = cache_dir();
+  const std::string file = dir.empty() ? std::string() : dir + "/" + key + ".gfx950.co";
+  if (!file.empty()) {
+    std::ifstream f(file, std::ios::binary);
+    if (f) {
+      std::stringstream ss;
+      ss << f.rdbuf();
+      code = ss.str();
+      if (!code.empty()) return true;
+    }
+  }
+  Rtc &r = rtc();
+  if (!r.ok) {
+    err = "hipRTC (libhiprtc.so) is not available";
+    return false;
+  }
+  void *prog = nullptr;
+  if (r.create(&prog, src.c_str(), "fruits_static_program.hip", 0, nullptr, nullptr) != 0) {
+    err = "hiprtcCreateProgram failed";
+    return false;
+  }
+  bool ok = false;
+  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+  if (r.add_name(prog, kKernelExpr) != 0) {
+    err = "hiprtcAddNameExpression failed";
+  } else if (r.compile(prog, 4, opts) != 0) {
+    size_t n = 0;
+    r.log_size(prog, &n);
+    std::string log(n, '\0');
+    if (n) r.log(prog, log.data());
+    err = "hipRTC compilation failed:\n" + log.substr(0, 4000);
+  } else {
+    const char *low = nullptr;
+    size_t n = 0;
+    if (r.lowered(prog, kKernelExpr, &low) != 0 || !low || r.code_size(prog, &n) != 0 || n == 0) {
+      err = "hipRTC returned no code";
+    } else {
+      // the code object, then the lowered kernel name (the loader needs it)
+      std::string co(n, '\0');
+      r.code(prog, co.data());
+      const std::string name(low);
+      code = co;
+      code.append(name);
+      const unsigned int len = (unsigned int)name.size();
+      code.append(reinterpret_cast<const char *>(&len), 4);
+      ok = true;
+    }
+  }
+  r.destroy(&prog);
+  if (ok && !file.empty()) {
+    make_dirs(dir);
+    const std::string tmp = file + ".tmp" + std::to_string((long long)getpid());
+    std::ofstream f(tmp, std::ios::binary);
+    if (f) {
+      f.write(code.data(), (std::streamsize)code.size());
+      f.close();
+      if (rename(tmp.c_str(), file.c_str()) != 0) (void)remove(tmp.c_str());
+    }
+  }
+  return ok;
+}
+
+bool jit_load(const std::string &code, const StaticSchedule &sc, JitProgram &out, std::string &err) {
+  if (code.size() < 8) {
+    err = "empty code object";
+    return false;
+  }
+  unsigned int len = 0;
+  std::memcpy(&len, code.data() + code.size() - 4, 4);
+  if ((size_t)len + 4 > code.size()) {
+    err = "corrupt code object";
+    return false;
+  }
+  const std::string name = code.substr(code.size() - 4 - len, len);
+  const std::string image = code.substr(0, code.size() - 4 - len);
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  if (hipModuleLoadData(&mod, image.data()) != hipSuccess ||
+      hipModuleGetFunction(&fn, mod, name.c_str()) != hipSuccess) {
+    (void)hipGetLastError();
+    if (mod) (void)hipModuleUnload(mod);
+    err = "hipModuleLoadData failed for the compiled program";
+    return false;
+  }
+  out.module = mod;
+  out.fn = fn;
+  out.groups = sc.groups;
+  out.lds_bytes = ((size_t)sc.rows * 1024 + 4 * 4) * sizeof(double);
+  out.device = current_device();
+  int nb = 0;
+  if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, kWalkThreads, out.lds_bytes) !=
+          hipSuccess || nb < 1) {
+    (void)hipGetLastError();
+    nb = 1;
+  }
+  out.per_cu = nb;
+  return true;
+}
+
+void jit_unload(JitProgram &p) {
+  if (p.module) (void)hipModuleUnload(p.module);
+  p = JitProgram{};
+}
+
+hipError_t jit_launch(const JitProgram &p, const IssArgs &a, hipStream_t st) {
+  const int64_t units = a.N * p.groups;
+  if (units <= 0) return hipSuccess;
+  if (units > 0x7fffffffLL || a.G != p.groups) return hipErrorInvalidValue;
+  int64_t resident = (int64_t)p.per_cu * device_cu_count();
+  resident -= resident % 8;
+  if (resident < 8) resident = 8;
+  const int64_t blocks = (units < resident || !a.persistent) ? units : resident;
+  IssArgs args = a;
+  void *params[] = {&args};
+  return hipModuleLaunchKernel(p.fn, (unsigned)blocks, 1, 1, kWalkThreads, 1, 1,
+                               (unsigned)p.lds_bytes, st, params, nullptr);
+}
+
+}  // namespace fr

@@ -1,0 +1,32 @@
+// Run-time compiled static programs (hipRTC): what static_programs.h holds for the standard
+// word sets, for ANY plan the scheduler accepts.  See jit.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "plan.h"
+#include "walk_types.h"
+
+namespace fr {
+
+struct JitProgram {
+  hipModule_t module = nullptr;
+  hipFunction_t fn = nullptr;
+  int groups = 0;
+  size_t lds_bytes = 0;
+  int per_cu = 0;          // resident workgroups per CU
+  int device = -1;
+};
+
+// The HIP source of the static program of `sc` (self-contained: device headers + schedule).
+std::string jit_source(const StaticSchedule &sc);
+// Compiles `sc` for gfx950 (code object in `code`); false + `err` when hipRTC is missing or
+// the compilation fails.  Needs no GPU.
+bool jit_compile(const StaticSchedule &sc, std::string &code, std::string &err);
+// Loads a compiled program on the current device.
+bool jit_load(const std::string &code, const StaticSchedule &sc, JitProgram &out, std::string &err);
+void jit_unload(JitProgram &p);
+hipError_t jit_launch(const JitProgram &p, const IssArgs &a, hipStream_t st);
+
+}  // namespace fr

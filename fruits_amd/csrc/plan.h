@@ -14,23 +14,9 @@
 #include <utility>
 #include <vector>
 
+#include "walk_types.h"
+
 namespace fr {
-
-// node flags
-constexpr int32_t F_CHAIN = 1;     // only child: processed in place in its parent's frame
-constexpr int32_t F_CHILDREN = 2;  // the exclusive prefix of this node is consumed by children
-// factor code: LDS row in the low 7 bits.  Reals: bit 7 = divide instead of multiply
-// (one code per occurrence of a letter).  Arctic: bits 8-15 = signed multiplier el of
-// the ADDED term el * row (one code per dimension of the extended letter).
-constexpr int32_t FAC_DIV = 0x80;
-constexpr int32_t FAC_ROW_MASK = 0x7f;
-constexpr int kSemiReals = 0, kSemiArctic = 1, kSemiBayesian = 2;
-constexpr int32_t fac_arctic(int row, int el) { return row | ((el & 0xff) << 8); }
-// letter-sum plans (Arctic argmax): the letter's terms collected so far are added to the
-// prefix BEFORE this factor is applied (the weight term follows `tmp = tmp + C`)
-constexpr int32_t FAC_FOLD = 1 << 16;
-
-constexpr int kMaxLevels = 8;   // deepest register-frame stack a kernel variant supports
 
 struct NodeDesc {  // 32 bytes, read by the kernel with scalar loads
   int32_t level;       // register frame this node writes (reads level-1; level 0 reads ones)
@@ -41,24 +27,6 @@ struct NodeDesc {  // 32 bytes, read by the kernel with scalar loads
   int32_t emit_count;
   int32_t emit_mul;    // LDS row multiplied into emitted values (total weighting) or -1
   int32_t z_mul;       // LDS row multiplied into the summand of the child scan (non-total) or -1
-};
-
-// Device form of a node: one 64-byte record = one s_load_dwordx16, every field a
-// whole dword so the walk needs no bit unpacking.  The records of a group are
-// contiguous in DFS order and end with a sentinel (level 0xff), so the walk
-// prefetches record pc+1 while it works on record pc and needs no bounds checks.
-constexpr int kRecInlineFactors = 4;   // multiply-only factors held in the record
-constexpr int kRecInlineEmits = 2;
-constexpr int kRecSentinelLevel = 0xff;
-constexpr int32_t F_SLOW = 4;          // a division or more than kRecInlineFactors factors:
-                                       // the factor table is walked instead
-struct NodeRec {
-  int32_t w[16];
-  // w[0]  level | flags << 8          w[1]  fac_count
-  // w[2..5]  inline factor rows       w[6]  emit_count
-  // w[7..8]  inline emit rows         w[9]  node id (carry slot)
-  // w[10] emit_mul row or -1          w[11] z_mul row or -1
-  // w[12] fac_begin (factor table: row | FAC_DIV)   w[13] emit_begin (emit-row table)
 };
 
 struct GroupedProgram {       // node order for one choice of G (groups per series)
@@ -126,6 +94,7 @@ struct Plan {
   // pre-compiled static programs for 1 / 2 / 3 groups per series (1 + index; 0: none;
   // -1: not looked up yet)
   int static_prog[4] = {-1, -1, -1, -1};
+  void *jit = nullptr;   // run-time compiled static programs (capi.cpp: JitState), or nullptr
   int device = -1;     // HIP device the uploaded tables live on (-1: nothing uploaded yet)
   std::mutex mu;       // guards `programs`, `cos->d_blob` and `device` (uploads at run time)
 
@@ -142,11 +111,6 @@ Plan *build_coswiss_plan(int W, const int32_t *exps, const int32_t *L, const int
                          const float *freqs, int exponent, int total, std::string &err);
 // Schedule of a static program (walk.h, walk_static): the whole plan as one group, nodes in
 // an order that needs the staged rows as late as possible, register frames named explicitly.
-constexpr int kSchedStage = 0xfe;      // entry kind: complete staged row w[1]
-constexpr int kSchedPrefetch = 0xfd;   // entry kind: load the next unit's rows (registers are free)
-constexpr int kStaticMaxRows = 4;      // staged rows held in registers while in flight
-constexpr int kStaticMaxFrames = 4;    // open prefixes
-constexpr int kStaticMaxNodes = 32;
 struct StaticSchedule {
   bool ok = false;                     // the plan qualifies (small, unweighted, inline letters)
   int groups = 0, rows = 0, frames = 0;

@@ -1,6 +1,8 @@
 // Wave64 DPP scan primitives and small device helpers shared by the kernels.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 
 namespace fr {
 

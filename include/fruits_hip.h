@@ -77,6 +77,7 @@ extern "C" {
 #define FR_INFO_STAGED_ROWS 8 /* rows a workgroup stages in LDS per time chunk (input dimensions +
                                 exp tables); fr_iss_run returns FR_E_LIMIT when they do not fit -
                                 the caller then splits the word list */
+#define FR_INFO_JIT_PROGRAMS 9 /* run-time compiled static programs loaded for this plan (fr_plan_jit) */
 
 /* sieve kinds of fr_sieve_* and the fused pipeline */
 #define FR_SIEVE_NPI 0 /* fruits/sieving/increment.py:101-129 */
@@ -147,6 +148,14 @@ int64_t fr_plan_workspace_bytes(const fr_plan_t *plan, int64_t N, int64_t T,
 /* 1 when a workgroup can stage the plan's rows (input dimensions + exp tables) of one
  * time chunk of a length-T series in LDS, 0 when fr_iss_run would return FR_E_LIMIT
  * (the caller then splits the word list). */
+/* Run-time compiled static program of a small plan (hipRTC): what fr_plan_prepare does for a
+ * materialising plan of at most 32 nodes that has no ahead-of-time program.  compile_only != 0:
+ * compiles the schedule for `groups` groups per series WITHOUT touching a GPU and returns the
+ * size of the code object (0: the plan has no static schedule; FR_E_LIMIT + message: hipRTC
+ * missing or the compilation failed).  compile_only == 0: compiles and loads the programs on
+ * the current device and returns how many the plan now has; `msg` receives why not. */
+int32_t fr_plan_jit(fr_plan_t *plan, int32_t groups, int32_t compile_only, char *msg,
+                    int64_t msg_cap);
 int32_t fr_plan_fits(const fr_plan_t *plan, int64_t T);
 /* One-time upload of the plan's device tables for batches of N series of length T
  * (`groups` as in fr_iss_run).  Allocates and synchronises - call it OUTSIDE a stream

@@ -1436,3 +1436,40 @@ def test_float_cuts_run_fused(fr, monkeypatch):
     counts = np.array([("NPI" in s) for s in labels])
     np.testing.assert_array_equal(a[:, counts], c[:, counts])
     np.testing.assert_allclose(a[:, ~counts], c[:, ~counts], rtol=1e-9, atol=1e-12)
+
+
+def test_jit_static_program(fr, monkeypatch, tmp_path):
+    """A plan outside the standard word sets: fr_plan_prepare compiles its static program at
+    run time (hipRTC); results bit-identical to the interpreter's, equal to the oracle's;
+    FRUITS_HIP_JIT=2 compiles at the first run instead; =0 leaves the interpreter."""
+    from fruits_amd import _native as nat
+    monkeypatch.setenv("FRUITS_HIP_JIT_CACHE", str(tmp_path / "jit"))
+    strs = ["[1][2]", "[12][1]", "[2]", "[1][1][2]", "[3][1]", "[33]", "[2][3][1]"]
+    words = [fr.words.SimpleWord(s) for s in strs]
+
+    def fresh():
+        iss = fr.ISS(words, mode=fr.ISSMode.EXTENDED)
+        return iss, iss._plan(0, len(words))
+    for N, T, dist in ((53, 1024, "normal"), (1601, 1024, "uniform"), (3080, 1022, "normal")):
+        X = gen_input({"seed": N + T, "dist": dist, "shape": [N, 3, T]})
+        Xd = nat.to_device(X)
+        monkeypatch.setenv("FRUITS_HIP_JIT", "0")
+        iss, plan = fresh()
+        plan.prepare(N, T)
+        assert plan.jit_loaded() == 0
+        interp = nat.to_host(iss.transform_device(Xd))
+        monkeypatch.setenv("FRUITS_HIP_JIT", "1")
+        iss, plan = fresh()
+        plan.prepare(N, T)
+        assert plan.jit_loaded() >= 1
+        got = nat.to_host(iss.transform_device(Xd))
+        np.testing.assert_array_equal(got, interp)
+        np.testing.assert_array_equal(got, nat.to_host(iss.transform_device(Xd)))
+        if N <= 1601:
+            rowwise_close(got, corc.iss_transform(X, strs, "EXTENDED"))
+        monkeypatch.setenv("FRUITS_HIP_JIT", "2")         # no prepare: compiled at the first run
+        iss, plan = fresh()
+        lazy = nat.to_host(iss.transform_device(Xd))
+        assert plan.jit_loaded() >= 1
+        np.testing.assert_array_equal(lazy, interp)
+    assert len(os.listdir(tmp_path / "jit")) >= 2

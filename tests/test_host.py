@@ -476,3 +476,25 @@ def test_static_program_header_is_current():
     from fruits_amd import gen_static
     with open(gen_static.HEADER) as f:
         assert f.read() == gen_static.render(), "run `python -m fruits_amd.gen_static` and rebuild"
+
+
+def test_jit_compiles_static_programs(tmp_path, monkeypatch):
+    """jit.cpp: the static program of a plan outside the standard word sets compiles with
+    hipRTC (no GPU needed) and is cached on disk; plans without a schedule compile nothing."""
+    monkeypatch.setenv("FRUITS_HIP_JIT_CACHE", str(tmp_path / "jit"))
+    words = [fr.words.SimpleWord(s) for s in ["[1][2]", "[12][1]", "[2]", "[1][1][2]", "[3][1]", "[33]"]]
+    plan = fr.ISS(words, mode=fr.ISSMode.EXTENDED)._plan(0, len(words))
+    assert plan.static_schedule(1) is not None
+    try:
+        size, msg = plan.jit(1, compile_only=True)
+    except ValueError as e:
+        if "not available" in str(e):
+            pytest.skip("hipRTC is not installed")
+        raise
+    assert size > 4096 and msg == ""
+    files = os.listdir(tmp_path / "jit")
+    assert len(files) == 1 and files[0].endswith(".gfx950.co")
+    assert plan.jit(1, compile_only=True)[0] == size          # served from the cache
+    assert plan.jit(3, compile_only=True)[0] > 4096 and len(os.listdir(tmp_path / "jit")) == 2
+    big = fr.words.of_weight(4, dim=2)
+    assert fr.ISS(big, mode=fr.ISSMode.EXTENDED)._plan(0, len(big)).jit(1, compile_only=True)[0] == 0
