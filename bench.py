@@ -202,11 +202,15 @@ def extras(torch, fr, nat, dev, quick=False):
     w15 = fr.words.of_weight(2, dim=N_DIMS)
     w48 = [w15[i % 15] for i in range(48)]
     plan = fr.ISS(w48)._plan(0, 48)
+    # (not one of the pre-compiled word sets: fr_plan_prepare compiles its static program with
+    # hipRTC - once, cached on disk - as a caller that launches a plan repeatedly would)
+    plan.prepare(N_SERIES, N_STEPS_T)
     buf = torch.empty((48, N_SERIES, N_STEPS_T), dtype=torch.float64, device=dev)
     t = _event_time_us(torch, lambda: plan.run(Xd, None, out=buf))
     b_alg = 8.0 * N_SERIES * N_STEPS_T * (3 + 48)
     out["words48_single"] = {"kernel_us": t, "elements_per_s": N_SERIES * 48 * N_STEPS_T / (t * 1e-6),
-                             "GBs": b_alg / (t * 1e-6) / 1e9, "frac": b_alg / (t * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                             "GBs": b_alg / (t * 1e-6) / 1e9, "frac": b_alg / (t * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                             "static_programs_compiled_at_run_time": plan.jit_loaded()}
     del buf
     # (a') what this box sustains (SURVEY.md 8d asks for an on-box peak next to the 8 TB/s
     # spec): a device fill and a device-to-device copy of the size of the output tensor

@@ -366,14 +366,14 @@ GroupedProgram &grouped(Plan &p, int G) {
 // readies the most nodes.  So the first nodes of a unit run on the first row alone while the
 // loads of the other rows are still in flight.
 static bool schedule_group(const NodeRec *recs, int n, int R, bool prefetch,
-                           std::vector<NodeRec> &out, int &frames_hi, int &need_mask) {
+                           const std::vector<int32_t> &emit_rows, std::vector<NodeRec> &out,
+                           int &frames_hi, int &need_mask) {
   std::vector<int> parent(n, -1), pending(n, 0), need(n, 0), last_at(kMaxLevels + 1, -1);
   int need_all = 0;
   for (int i = 0; i < n; ++i) {
     const NodeRec &r = recs[i];
     const int lv = r.w[0] & 0xff, fl = r.w[0] >> 8;
-    if ((fl & F_SLOW) || r.w[6] > kRecInlineEmits || r.w[1] > kRecInlineFactors || lv >= kMaxLevels)
-      return false;
+    if ((fl & F_SLOW) || r.w[1] > kRecInlineFactors || lv >= kMaxLevels) return false;
     parent[i] = (fl & F_CHAIN) ? last_at[lv] : (lv > 0 ? last_at[lv - 1] : -1);
     last_at[lv] = i;
     if (parent[i] >= 0) ++pending[parent[i]];
@@ -441,7 +441,18 @@ static bool schedule_group(const NodeRec *recs, int n, int R, bool prefetch,
       e.w[15] = f;
       frames_hi = std::max(frames_hi, f + 1);
     }
+    // output rows beyond the two a record holds become immediates of kSchedEmits entries
+    const int ne = e.w[6];
+    if (ne > kRecInlineEmits) e.w[6] = kRecInlineEmits;
     out.push_back(e);
+    for (int j = kRecInlineEmits; j < ne;) {
+      NodeRec m{};
+      m.w[0] = kSchedEmits;
+      int k = 0;
+      for (; k < kSchedEmitsPerEntry && j < ne; ++k, ++j) m.w[2 + k] = emit_rows[e.w[13] + j];
+      m.w[1] = k;
+      out.push_back(m);
+    }
     done[pick] = 1;
     --left;
   }
@@ -464,7 +475,8 @@ StaticSchedule static_schedule(Plan &p, int G) {
     int mask = 0;
     sc.group_begin.push_back((int32_t)sc.entries.size());
     // the next unit of a workgroup is another group when G > 1: no prefetch entry then
-    if (!schedule_group(gp.recs.data() + b, n, R, gp.groups == 1, sc.entries, frames_hi, mask))
+    if (!schedule_group(gp.recs.data() + b, n, R, gp.groups == 1, p.emit_rows, sc.entries, frames_hi,
+                        mask))
       return sc;
     sc.group_rows.push_back(mask);
   }

@@ -377,9 +377,12 @@ __device__ __forceinline__ double *emit_ptr(const WalkCtx &cx, int k) {
   return cx.out_base + (int64_t)k * a.out_k_stride;
 }
 
+// `more` / `n_more`: further output rows of a STATIC program's node (compile-time constants,
+// kSchedEmits entries); the interpreter reads rows beyond the inline two from the table
 template <class C>
 __device__ __forceinline__ void emit_all(const WalkCtx &cx, const Rec &nd,
-                                         const double (&c)[C::EP]) {
+                                         const double (&c)[C::EP], const int32_t *more = nullptr,
+                                         int n_more = 0) {
   const IssArgs &a = *cx.a;
   const int ne = nd.emit_count();
   if (ne > 0) emit_store<C>(cx, c, emit_ptr(cx, nd.w[7]));
@@ -388,6 +391,7 @@ __device__ __forceinline__ void emit_all(const WalkCtx &cx, const Rec &nd,
     for (int j = kRecInlineEmits; j < ne; ++j)
       emit_store<C>(cx, c, emit_ptr(cx, as_const(a.emit_rows)[nd.emit_begin() + j]));
   }
+  for (int j = 0; j < n_more; ++j) emit_store<C>(cx, c, emit_ptr(cx, more[j]));
 }
 
 // ---------------------------------------------------------------- fused sieves
@@ -588,7 +592,8 @@ __device__ __forceinline__ void fused_all(WalkCtx &cx, const Rec &nd, const Ops2
 template <class C>
 __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd, int slot,
                                              const double (&pin)[C::EP],
-                                             double (&pout)[C::EP]) {
+                                             double (&pout)[C::EP], const int32_t *more = nullptr,
+                                             int n_more = 0) {
   constexpr int EP = C::EP;
   cx.slot = slot;
   double s[EP];
@@ -652,7 +657,7 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd, int slo
       if constexpr (C::MODE == 1)
         fused_all<C>(cx, nd, pre, c, x, s, !(C::WEIGHTED && emit_mul >= 0));
       else
-        emit_all<C>(cx, nd, c);
+        emit_all<C>(cx, nd, c, more, n_more);
       STAMP(cx, 5);  // stores
     }
   }
@@ -743,6 +748,8 @@ __device__ __forceinline__ void walk(WalkCtx &cx, Rec &cur, int &pc,
 //                    is read from (-1: the semiring's one) / written to (-1: nobody reads it);
 //   kSchedStage      w[1] = staged row whose registers go to LDS now (it is first read by
 //                    the next node entry);
+//   kSchedEmits      w[1] further output rows (w[2..]) of the node entry in front of it (a
+//                    record holds two; SINGLE-mode plans with repeated words have more);
 //   kSchedPrefetch   behind the last stage entry: the registers are free again - issue the
 //                    loads of the workgroup's next unit into them;
 //   sentinel         end of the schedule.
@@ -761,6 +768,15 @@ __device__ __forceinline__ constexpr Rec static_rec() {
 }
 template <class PG>
 constexpr int static_kind(int pc) { return PG::w[pc * 16] & 0xff; }
+template <class PG>
+constexpr int static_more_emits(int pc) {   // rows in the kSchedEmits entries starting at pc
+  int n = 0;
+  while (static_kind<PG>(pc) == kSchedEmits) {
+    n += PG::w[pc * 16 + 1];
+    ++pc;
+  }
+  return n;
+}
 
 template <class C>
 struct StaticRegs {
@@ -808,18 +824,25 @@ __device__ __forceinline__ void walk_static(WalkCtx &cx, StaticRegs<C> &rg, doub
   } else {
     constexpr Rec nd = static_rec<PG, PC>();
     constexpr int fin = nd.w[14], fout = nd.w[15];
+    // further output rows of this node: kSchedEmits entries right behind it
+    constexpr int n_more = static_more_emits<PG>(PC + 1);
+    constexpr int skip = (n_more + kSchedEmitsPerEntry - 1) / kSchedEmitsPerEntry;
+    int32_t more[n_more > 0 ? n_more : 1];
+#pragma unroll
+    for (int j = 0; j < n_more; ++j)
+      more[j] = PG::w[(PC + 1 + j / kSchedEmitsPerEntry) * 16 + 2 + j % kSchedEmitsPerEntry];
     double ones[C::EP], dead[C::EP];
 #pragma unroll
     for (int i = 0; i < C::EP; ++i) ones[i] = C::SEMI != 1 ? 1.0 : 0.0;
     if constexpr (fin < 0 && fout < 0)
-      process_node<C>(cx, nd, 0, ones, dead);
+      process_node<C>(cx, nd, 0, ones, dead, more, n_more);
     else if constexpr (fin < 0)
-      process_node<C>(cx, nd, 0, ones, rg.fr[fout < 0 ? 0 : fout]);
+      process_node<C>(cx, nd, 0, ones, rg.fr[fout < 0 ? 0 : fout], more, n_more);
     else if constexpr (fout < 0)
-      process_node<C>(cx, nd, 0, rg.fr[fin < 0 ? 0 : fin], dead);
+      process_node<C>(cx, nd, 0, rg.fr[fin < 0 ? 0 : fin], dead, more, n_more);
     else
-      process_node<C>(cx, nd, 0, rg.fr[fin], rg.fr[fout]);
-    walk_static<C, PG, PC + 1>(cx, rg, rows_w);
+      process_node<C>(cx, nd, 0, rg.fr[fin], rg.fr[fout], more, n_more);
+    walk_static<C, PG, PC + 1 + skip>(cx, rg, rows_w);
   }
 }
 

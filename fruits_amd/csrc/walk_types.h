@@ -50,6 +50,8 @@ struct NodeRec {
 };
 
 constexpr int kSchedStage = 0xfe;      // entry kind: complete staged row w[1]
+constexpr int kSchedEmits = 0xfc;      // entry kind: w[1] more output rows (w[2..]) of the node entry before it
+constexpr int kSchedEmitsPerEntry = 14;
 constexpr int kSchedPrefetch = 0xfd;   // entry kind: load the next unit's rows (registers are free)
 constexpr int kStaticMaxRows = 4;      // staged rows held in registers while in flight
 constexpr int kStaticMaxFrames = 4;    // open prefixes

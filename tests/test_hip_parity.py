@@ -1473,3 +1473,25 @@ def test_jit_static_program(fr, monkeypatch, tmp_path):
         assert plan.jit_loaded() >= 1
         np.testing.assert_array_equal(lazy, interp)
     assert len(os.listdir(tmp_path / "jit")) >= 2
+
+
+def test_jit_repeated_words(fr, monkeypatch, tmp_path):
+    """The metric's "48 weight-2 words" (words[i % 15], SINGLE): nodes with up to four output
+    rows - immediates of the run-time compiled program; identical to the interpreter."""
+    from fruits_amd import _native as nat
+    monkeypatch.setenv("FRUITS_HIP_JIT_CACHE", str(tmp_path / "jit"))
+    w15 = fr.words.of_weight(2, dim=3)
+    w48 = [w15[i % 15] for i in range(48)]
+    X = gen_input({"seed": 48, "dist": "normal", "shape": [1032, 3, 1024]})
+    Xd = nat.to_device(X)
+    monkeypatch.setenv("FRUITS_HIP_JIT", "0")
+    interp = nat.to_host(fr.ISS(w48).transform_device(Xd))
+    monkeypatch.setenv("FRUITS_HIP_JIT", "1")
+    iss = fr.ISS(w48)
+    plan = iss._plan(0, 48)
+    plan.prepare(1032, 1024)
+    assert plan.jit_loaded() == 2
+    got = nat.to_host(iss.transform_device(Xd))
+    np.testing.assert_array_equal(got, interp)
+    for i in range(15, 48):
+        np.testing.assert_array_equal(got[i], got[i % 15])

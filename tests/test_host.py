@@ -415,6 +415,14 @@ def test_static_schedules_are_valid_walks():
                 head, sched = got
                 recs = plan.records(1)
                 _check_schedule_with_children(recs, head, sched)
+    # repeated words (SINGLE mode): nodes with more than the two output rows a record holds
+    w15 = fr.words.of_weight(2, dim=3)
+    w48 = [w15[i % 15] for i in range(48)]
+    plan = fr.ISS(w48)._plan(0, 48)
+    for G in (1, 3):
+        head, sched = plan.static_schedule(G)
+        assert any((int(e[0]) & 0xff) == 0xfc for e in sched)
+        _check_schedule_with_children(plan.records(1), head, sched)
     # plans that do not qualify: weighted, too many nodes, Arctic letter sums
     big = fr.words.of_weight(4, dim=2)
     assert fr.ISS(big, mode=fr.ISSMode.EXTENDED)._plan(0, len(big)).static_schedule(1) is None
@@ -433,7 +441,7 @@ def _check_schedule_with_children(recs, head, sched):
     for c, p in parent.items():
         if p is not None:
             children[p] = children.get(p, 0) + 1
-    seen = []
+    seen, emitted = [], []
     for g in range(head["groups"]):
         staged, frame_of, left = set(), {}, {}
         i = head["group_begin"][g]
@@ -449,7 +457,12 @@ def _check_schedule_with_children(recs, head, sched):
             if kind == 0xfd:
                 assert head["groups"] == 1
                 continue
+            if kind == 0xfc:     # further output rows of the node entry before it
+                assert seen and 1 <= int(e[1]) <= 14
+                emitted[-1] += int(e[1])
+                continue
             nid, fin, fout = int(e[9]), int(e[14]), int(e[15])
+            emitted.append(int(e[6]))
             for j in range(int(e[1])):
                 assert (int(e[2 + j]) & 0x7f) in staged, "letter on a row that is still in flight"
             p = parent[nid]
@@ -469,6 +482,8 @@ def _check_schedule_with_children(recs, head, sched):
             seen.append(nid)
         assert not frame_of, "a frame was left open"
     assert sorted(seen) == sorted(parent), "every node exactly once"
+    total = {int(r[9]): int(r[6]) for r in recs[:-1]}
+    assert sorted(emitted) == sorted(total.values()), "every output row of every node"
 
 
 def test_static_program_header_is_current():
