@@ -50,7 +50,11 @@ class IncrementSieve(SegmentSieve):
                   out, col)
 
     def _copy(self):
-        return self.__class__(self._cut, self._q, self._inc)
+        # (Fruit.fit makes one copy per iterated sum and sieve - thousands: the state set
+        # directly; like the reference's __class__(cut, q, inc) it forgets coquantile_norm)
+        dup = object.__new__(self.__class__)
+        dup._cut, dup._q, dup._inc, dup._coquantile_norm = self._cut, self._q, self._inc, "L2"
+        return dup
 
     def __str__(self) -> str:
         return f"{self.__class__.__name__}({self._cut}, {self._q}, {self._inc})"

@@ -97,12 +97,7 @@ class SegmentSieve(FeatureSieve, ABC):
         return reqs
 
     def _set_quantiles_from_stats(self, reqs, lo_vals, hi_vals) -> None:
-        qs = np.zeros(len(self._q))
-        for i, q in enumerate(self._q):
-            if q == 1.0:
-                qs[i] = np.inf
-            elif q == -1.0:
-                qs[i] = -np.inf
+        qs = [np.inf if q == 1.0 else (-np.inf if q == -1.0 else 0.0) for q in self._q]
         for (i, _, _, gamma), a, b in zip(reqs, lo_vals, hi_vals):
             # numpy's _lerp (lib/_function_base_impl.py): a + (b-a)*t, from the other end
             # when t >= 0.5
@@ -110,8 +105,14 @@ class SegmentSieve(FeatureSieve, ABC):
             r = a + d * gamma
             if gamma >= 0.5:
                 r = b - d * (1 - gamma)
-            qs[i] = r
-        self._quantiles = np.sort(qs)
+            qs[i] = float(r)
+        # (plain floats: thousands of sieve copies are fitted per Fruit.fit; np.sort's NaN-last
+        # order only matters when a statistic is NaN)
+        if any(v != v for v in qs):
+            self._quantiles = np.sort(np.array(qs))
+        else:
+            qs.sort()
+            self._quantiles = np.array(qs)
 
     def _get_unfitted_quantiles(self) -> None:
         qs = np.zeros(len(self._q))
@@ -150,7 +151,10 @@ class SegmentSieve(FeatureSieve, ABC):
         return len(self._cut) * (len(self._q) - 1)
 
     def _copy(self):
-        return self.__class__(self._cut, self._q)
+        # (see IncrementSieve._copy; the reference's __class__(cut, q) forgets the norm too)
+        dup = object.__new__(self.__class__)
+        dup._cut, dup._q, dup._coquantile_norm = self._cut, self._q, "L2"
+        return dup
 
     def __str__(self) -> str:
         return f"{self.__class__.__name__}({self._cut}, {self._q})"
