@@ -51,9 +51,15 @@ Rtc &rtc() {
   static Rtc r;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
-      r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (r.lib) break;
+    // FRUITS_HIP_RTC_LIB: another hipRTC (or none: tests of the interpreter fallback)
+    const char *forced = getenv("FRUITS_HIP_RTC_LIB");
+    if (forced && *forced) {
+      r.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    } else {
+      for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+      }
     }
     if (!r.lib) return;
     auto sym = [&](const char *n) { return dlsym(r.lib, n); };

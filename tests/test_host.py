@@ -2,6 +2,7 @@
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -513,3 +514,25 @@ def test_jit_compiles_static_programs(tmp_path, monkeypatch):
     assert plan.jit(3, compile_only=True)[0] > 4096 and len(os.listdir(tmp_path / "jit")) == 2
     big = fr.words.of_weight(4, dim=2)
     assert fr.ISS(big, mode=fr.ISSMode.EXTENDED)._plan(0, len(big)).jit(1, compile_only=True)[0] == 0
+
+
+def test_jit_without_hiprtc_falls_back(tmp_path):
+    """No hipRTC: fr_plan_jit says so (FR_E_LIMIT) and nothing else changes - the plan keeps
+    its interpreter program (checked in a fresh process: the library handle is cached)."""
+    import subprocess
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import fruits_amd as fr\n"
+        "ws = [fr.words.SimpleWord(s) for s in ['[1][2]', '[12][1]', '[2]']]\n"
+        "plan = fr.ISS(ws, mode=fr.ISSMode.EXTENDED)._plan(0, 3)\n"
+        "try:\n"
+        "    plan.jit(1, compile_only=True)\n"
+        "    print('compiled')\n"
+        "except ValueError as e:\n"
+        "    print('refused:', 'not available' in str(e))\n"
+        "print(len(plan.records(1)))\n" % ROOT)
+    env = dict(os.environ, FRUITS_HIP_RTC_LIB="/nonexistent/libhiprtc.so",
+               FRUITS_HIP_JIT_CACHE=str(tmp_path / "jit"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "refused: True" in r.stdout and r.stdout.strip().endswith("4")
