@@ -263,7 +263,7 @@ int64_t query_resident(const fr::Plan &p, int64_t N, int64_t T, bool fused, bool
 //                       rounds and their restaging hits the XCD's L2 (N = 4096: 135.5 vs
 //                       146.6 us, N = 8192: 272 vs 291 us); larger plans keep whole series
 //                       (config 3 / 4 / 5: no difference measured)
-int choose_groups_walk(const fr::Plan &p, int64_t N, int64_t resident) {
+int choose_groups_walk(const fr::Plan &p, int64_t N, int64_t resident, bool fused = false) {
   const int U = p.units();
   if (U <= 1 || N <= 0) return 1;
   if (resident <= 0) return choose_groups(p, N, 0);
@@ -271,6 +271,10 @@ int choose_groups_walk(const fr::Plan &p, int64_t N, int64_t resident) {
     const int64_t G = std::min<int64_t>((resident + N - 1) / N, 6);
     return (int)std::max<int64_t>(1, std::min<int64_t>(G, U));
   }
+  // fused launches run one short-lived workgroup per unit (run_walk): two groups per series
+  // balance a little better than whole series (configs 3 / 4 / 5: 529 -> 516 us, 22.0 -> 21.5 ms,
+  // 37.2 -> 36.3 ms; three groups: 514 us, 21.4 ms, 37.8 ms)
+  if (fused) return std::min(U, 2);
   if (N < 2 * resident || p.nodes.size() > 32) return 1;
   return std::min(U, 3);
 }
@@ -327,7 +331,7 @@ int prepare_plan(fr::Plan &p, int64_t N, int64_t T, int32_t groups, bool fused, 
   if (auto_groups) {
     // (the choice depends on the kernel instance - fused or not, 16-byte aligned or not -
     // which is only known when the pointers are: upload what either would ask for)
-    Gs.push_back(choose_groups_walk(p, N, query_resident(p, N, T, fused, true)));
+    Gs.push_back(choose_groups_walk(p, N, query_resident(p, N, T, fused, true), fused));
     if (!fused) Gs.push_back(choose_groups_walk(p, N, query_resident(p, N, T, false, false)));
   } else {
     Gs.push_back(shape.G);
@@ -763,7 +767,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
       }
     }
     const int G = static_prog ? static_groups
-                              : (wave_rows ? 4 : (auto_groups ? choose_groups_walk(p, N, resident) : shape.G));
+                              : (wave_rows ? 4 : (auto_groups ? choose_groups_walk(p, N, resident, fu != nullptr) : shape.G));
     gpp = &fr::grouped(p, G);   // (map nodes are stable: the reference outlives the lock)
     if (!static_prog) {
       int rc = ensure_device_program(p, *gpp, st, who);
@@ -809,7 +813,17 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     if (extra > 0 && d_work && work_bytes >= (int64_t)wl.total() + extra)
       a.dbg = reinterpret_cast<unsigned long long *>(work + align_up(wl.total(), 256));
   }
-  a.persistent = env_int("FRUITS_HIP_PERSIST", 1);
+  // Persistent grid (one resident round of workgroups striding over the units) or one
+  // short-lived workgroup per unit.  Measured (tools/gpu_persist.sh, gpu_static2.sh): the fused
+  // kernels gain 3-12 % from the hardware dispatcher's balancing (config 4: 25.1 -> 22.1 ms,
+  // config 5: 42.6 -> 37.3 ms); the materialising interpreter keeps the persistent grid up
+  // to two resident rounds (config 2: 68.9 vs 73.7 us) and drops it beyond (N = 8192:
+  // 287 -> 256 us).
+  {
+    const int64_t round = resident > 0 ? resident : 1536;
+    const int by_shape = fu ? 0 : ((N * (int64_t)gp.groups < 2 * round) ? 1 : 0);
+    a.persistent = env_int("FRUITS_HIP_PERSIST", by_shape);
+  }
   a.wave_rows = wave_rows ? 1 : 0;
   a.packed = packed ? 1 : 0;
   a.prefetch_next = env_int("FRUITS_HIP_PREFETCH", 24);  // longest unit (nodes) that prefetches; 0: off
