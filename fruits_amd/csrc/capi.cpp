@@ -690,6 +690,9 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
       a.series_cuts = fu->series_cuts;
       a.cut_slots = fu->cut_slots;
     }
+    // one short-lived workgroup per (series, word, frequency) unit: 0-2.5 % faster than a
+    // persistent grid (exponent 2: 1515 -> 1478 us)
+    a.persistent = env_int("FRUITS_HIP_COS_PERSIST", 0);
     e = fr::launch_coswiss(a, c.exponent, st);
     if (e != hipSuccess) return hip_fail(e, "coswiss launch");
     return FR_OK;

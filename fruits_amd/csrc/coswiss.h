@@ -401,8 +401,9 @@ static hipError_t launch_coswiss_cfg(const IssArgs &a, hipStream_t st) {
   hipError_t e = cache.facts(coswiss_kernel<C, S>, kWalkThreads, lds, &per_cu);
   if (e != hipSuccess) return e;
   int64_t blocks = (int64_t)per_cu * device_cu_count();
-  if (blocks > units) blocks = units;
+  if (blocks > units || !a.persistent) blocks = units;   // persistent grid or one workgroup per unit
   if (blocks < 1) return hipSuccess;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL((coswiss_kernel<C, S>), dim3((unsigned)blocks), dim3(kWalkThreads), lds, st,
                      a);
   return hipGetLastError();

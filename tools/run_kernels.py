@@ -38,6 +38,10 @@ else:
     fn = lambda: cw.transform_device(Xd, out=out)
 fn()
 torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
 for _ in range(reps):
     fn()
+b.record()
 torch.cuda.synchronize()
+print(f"{which}: {a.elapsed_time(b) / reps * 1e3:.1f} us per launch ({reps} launches)")
