@@ -766,7 +766,14 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
       static_groups = asked > 0 ? asked : (cache_sized ? 1 : gmax);
       if (have(static_groups)) {
         static_prog = p.static_prog[static_groups] > 0 ? p.static_prog[static_groups] : -1;
-        if (static_prog < 0) jit_prog = &js->progs[static_groups];
+        if (static_prog < 0) {
+          jit_prog = &js->progs[static_groups];
+          // (a module is loaded on ONE device: elsewhere the interpreter runs the plan)
+          if (jit_prog->device != fr::current_device()) {
+            jit_prog = nullptr;
+            static_prog = 0;
+          }
+        }
       }
     }
     const int G = static_prog ? static_groups
