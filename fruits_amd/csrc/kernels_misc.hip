@@ -522,7 +522,9 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const SelJob *__restri
 __global__ void select_pick_kernel(SelJob *__restrict__ jobs, int shift,
                                    unsigned int *__restrict__ hist, double *__restrict__ out,
                                    unsigned long long *__restrict__ succ,
-                                   unsigned int *__restrict__ n_big) {
+                                   unsigned int *__restrict__ n_big,
+                                   unsigned long long *__restrict__ cand,
+                                   unsigned int *__restrict__ cnt) {
   const int job = blockIdx.x;
   if (jobs[job].pad & 4) return;   // (its histogram received nothing)
   if (threadIdx.x == 0) {
@@ -538,8 +540,16 @@ __global__ void select_pick_kernel(SelJob *__restrict__ jobs, int shift,
     if (shift == kSelSmallShift) {
       if (hist[job * 256 + d] <= (unsigned int)kSelSmall)
         jobs[job].pad |= 4 | ((int)hist[job * 256 + d] << 8);
-      else if (n_big != nullptr)
-        atomicAdd(n_big, 1u);   // a job that stays in the histogram passes
+      else {
+        // too many candidates for a workgroup - usually ONE value many times (the zeros among
+        // the increments of a running maximum): select_gather_kernel checks whether they are
+        // all equal (cand[0] = the first one seen, cand[1] != 0 = another one exists)
+        jobs[job].pad |= 8;
+        cnt[job] = hist[job * 256 + d];
+        cand[(int64_t)job * kSelSmall] = ~0ull;
+        cand[(int64_t)job * kSelSmall + 1] = 0ull;
+        atomicAdd(n_big, 1u);   // a job that stays in the histogram passes (unless resolved)
+      }
     }
     if (shift == 0) {
       out[job] = key_to_double(jobs[job].prefix);
@@ -567,8 +577,19 @@ __global__ __launch_bounds__(256) void select_gather_kernel(const SelJob *__rest
                                                              unsigned int *__restrict__ cnt) {
   const int jb = groups[blockIdx.y].x, nj = groups[blockIdx.y].y;
   bool any = false;
-  for (int j = 0; j < nj; ++j) any = any || (jobs[jb + j].pad & 4);
+  int big0 = -1, big1 = -1;   // up to two jobs of the group whose candidates may all be equal
+  for (int j = 0; j < nj; ++j) {
+    any = any || (jobs[jb + j].pad & 12);
+    if (jobs[jb + j].pad & 8) {
+      if (big0 < 0) big0 = j;
+      else if (big1 < 0) big1 = j;
+    }
+  }
   if (!any) return;
+  unsigned long long ref0 = ~0ull, ref1 = ~0ull;   // the first candidate anybody saw
+  bool other0 = false, other1 = false;
+  if (big0 >= 0) ref0 = cand[(int64_t)(jb + big0) * kSelSmall];
+  if (big1 >= 0) ref1 = cand[(int64_t)(jb + big1) * kSelSmall];
   const double *base = jobs[jb].base;
   const int64_t per_series = (N >= (int64_t)gridDim.x) ? 1 : ((int64_t)gridDim.x + N - 1) / N;
   const int64_t n_first = (int64_t)blockIdx.x / per_series, part = (int64_t)blockIdx.x % per_series;
@@ -580,6 +601,32 @@ __global__ __launch_bounds__(256) void select_gather_kernel(const SelJob *__rest
     unsigned long long key = 0;
     int key_inc = -1;
     for (int j = 0; j < nj; ++j) {
+      if (j == big0 || j == big1) {
+        const int inc = jobs[jb + j].inc;
+        if (inc != key_inc) {
+          key = order_key(diff_at(base + n * T, t, inc));
+          key_inc = inc;
+        }
+        const bool hit = (key >> kSelSmallShift) == (jobs[jb + j].prefix >> kSelSmallShift);
+        unsigned long long &ref = j == big0 ? ref0 : ref1;
+        // nobody has published a candidate yet: ONE lane of the wave tries (a compare-and-swap
+        // per thread on one address would serialise a hundred thousand of them) and tells
+        // the others what the reference is
+        const unsigned long long ask = __ballot(hit && ref == ~0ull);
+        if (ask != 0) {
+          const int leader = __ffsll((long long)ask) - 1;
+          unsigned long long got = 0;
+          if ((int)(threadIdx.x & 63) == leader) {
+            const unsigned long long old =
+                atomicCAS(&cand[(int64_t)(jb + j) * kSelSmall], ~0ull, key);
+            got = old == ~0ull ? key : old;
+          }
+          const unsigned long long told = __shfl(got, leader);
+          if (ref == ~0ull) ref = told;
+        }
+        if (hit && key != ref) (j == big0 ? other0 : other1) = true;
+        continue;
+      }
       if (!(jobs[jb + j].pad & 4)) continue;
       const int inc = jobs[jb + j].inc;
       if (inc != key_inc) {
@@ -592,6 +639,8 @@ __global__ __launch_bounds__(256) void select_gather_kernel(const SelJob *__rest
       }
     }
   }
+  if (other0) cand[(int64_t)(jb + big0) * kSelSmall + 1] = 1ull;
+  if (other1) cand[(int64_t)(jb + big1) * kSelSmall + 1] = 1ull;
 }
 
 // One workgroup per small job: the k-th smallest of its candidates (and the next one) by
@@ -600,10 +649,28 @@ __global__ __launch_bounds__(256) void select_small_kernel(SelJob *__restrict__ 
                                                             const unsigned long long *__restrict__ cand,
                                                             const unsigned int *__restrict__ cnt,
                                                             double *__restrict__ out,
-                                                            unsigned long long *__restrict__ succ) {
+                                                            unsigned long long *__restrict__ succ,
+                                                            unsigned int *__restrict__ n_big) {
   __shared__ unsigned long long keys[kSelSmall];
   __shared__ unsigned long long next_key;
   const int job = blockIdx.x;
+  if (jobs[job].pad & 8) {
+    // more candidates than a workgroup settles: done all the same when they are ONE value
+    if (threadIdx.x == 0) {
+      const unsigned long long key = cand[(int64_t)job * kSelSmall];
+      if (key != ~0ull && cand[(int64_t)job * kSelSmall + 1] == 0ull) {
+        out[job] = key_to_double(key);
+        jobs[job].prefix = key;
+        if (jobs[job].pad & 1) {
+          if (jobs[job].k + 1 < (long long)cnt[job]) succ[job] = key;
+          else jobs[job].pad |= 2;
+        }
+        jobs[job].pad |= 4;
+        atomicSub(n_big, 1u);
+      }
+    }
+    return;
+  }
   if (!(jobs[job].pad & 4)) return;
   int n = (int)cnt[job];
   if (n > kSelSmall) n = kSelSmall;   // (cannot happen: the histogram counted the same elements)
@@ -712,12 +779,12 @@ hipError_t launch_select_ranks(void *jobs, int n_jobs, const void *groups, int n
     hipLaunchKernelGGL(select_hist_kernel, dim3((unsigned)bpj, (unsigned)n_groups), dim3(256), 0,
                        st, jb, gr, N, T, shift, hist);
     hipLaunchKernelGGL(select_pick_kernel, dim3((unsigned)n_jobs), dim3(64), 0, st, jb, shift,
-                       hist, out, succ, cand_count + n_jobs);
+                       hist, out, succ, cand_count + n_jobs, cand, cand_count);
     if (shift == kSelSmallShift) {
       hipLaunchKernelGGL(select_gather_kernel, dim3((unsigned)bpj, (unsigned)n_groups), dim3(256),
                          0, st, jb, gr, N, T, cand, cand_count);
       hipLaunchKernelGGL(select_small_kernel, dim3((unsigned)n_jobs), dim3(256), 0, st, jb, cand,
-                         cand_count, out, succ);
+                         cand_count, out, succ, cand_count + n_jobs);
       // no job left in the histogram passes (the usual case): the five remaining passes would
       // launch tens of thousands of workgroups only to return - ask the device
       unsigned int n_big = 1;
