@@ -20,6 +20,8 @@ from ..cache import SharedSeedCache
 from ..seed import Seed
 from .cache import CachePlan
 from .semiring import Arctic, Bayesian, Reals, Semiring
+
+_AUTO_PREPARE_BYTES = 64 << 20   # materialised output from which a plan is prepared unasked
 from .weighting import Weighting
 from .words.word import SimpleWord, Word
 
@@ -206,6 +208,16 @@ class ISS(Seed):
             self.transform_device(Xd, lookup_d=lookup_d, out=out[k0:], groups=groups,
                                   indices=indices[half:])
             return out
+        # A big materialising launch of a small plan: prepare it once (fr_plan_prepare compiles
+        # the plan's static program with hipRTC when no pre-compiled one matches - about a
+        # second the first time a word list is seen, milliseconds from the disk cache after).
+        # FRUITS_AMD_AUTO_PREPARE=0 leaves that to explicit Plan.prepare calls.
+        N, T = int(Xd.shape[0]), int(Xd.shape[2])
+        if (8 * plan.rows * N * T >= _AUTO_PREPARE_BYTES and not getattr(plan, "_prepared", False)
+                and os.environ.get("FRUITS_AMD_AUTO_PREPARE", "1") != "0"
+                and not nat.torch().cuda.is_current_stream_capturing()):
+            plan.prepare(N, T, groups)
+            plan._prepared = True
         return plan.run(Xd, lookup_d, out=out, layout="KNT", groups=groups)
 
     # ------------------------------------------------------------------ reference API
