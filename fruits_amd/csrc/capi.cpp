@@ -831,7 +831,11 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   // 287 -> 256 us).
   {
     const int64_t round = resident > 0 ? resident : 1536;
-    const int by_shape = fu ? 0 : ((N * (int64_t)gp.groups < 2 * round) ? 1 : 0);
+    int by_shape = fu ? 0 : ((N * (int64_t)gp.groups < 2 * round) ? 1 : 0);
+    // wave-per-series kernels (short series), materialising: T <= 128 without the persistent
+    // grid (16384 x 128: 86 -> 77 us, 32768 x 64: 120 -> 100 us), longer ones with (8192 x 256:
+    // 71 vs 75 us)
+    if (packed && !fu) by_shape = T > 192 ? 1 : 0;
     a.persistent = env_int("FRUITS_HIP_PERSIST", by_shape);
   }
   a.wave_rows = wave_rows ? 1 : 0;
