@@ -22,7 +22,8 @@ FR_W_NONE, FR_W_NONTOTAL, FR_W_TOTAL = 0, 1, 2
 FR_SIEVE_NPI, FR_SIEVE_MPI, FR_SIEVE_END = 0, 1, 2
 FR_SIEVE_SERIES_CUTS = 0x100   # OR-ed into a kind: the sieve's cuts are slots of a per-series table
 (FR_INFO_ROWS, FR_INFO_NODES, FR_INFO_LEVELS, FR_INFO_DIMS_USED, FR_INFO_MAX_DIM,
- FR_INFO_ALPHAS, FR_INFO_GROUPS, FR_INFO_SHARED, FR_INFO_STAGED_ROWS, FR_INFO_JIT_PROGRAMS) = range(10)
+ FR_INFO_ALPHAS, FR_INFO_GROUPS, FR_INFO_SHARED, FR_INFO_STAGED_ROWS, FR_INFO_JIT_PROGRAMS,
+ FR_INFO_AOT_PROGRAM) = range(11)
 FR_E_ARG, FR_E_DIM, FR_E_HIP, FR_E_NOMEM, FR_E_LIMIT, FR_E_INDEX = -1, -2, -3, -4, -5, -6
 
 EXPORTS = [
@@ -265,6 +266,10 @@ class Plan:
         rc = lib().fr_plan_jit(self._h, int(groups), 1 if compile_only else 0, buf, len(buf))
         check(rc, "fr_plan_jit")
         return int(rc), buf.value.decode(errors="replace")
+
+    def static_program_index(self, groups: int = 1) -> int:
+        """1 + index of the pre-compiled static program this plan's records equal (0: none)."""
+        return int(lib().fr_plan_info(self._h, FR_INFO_AOT_PROGRAM))
 
     def jit_loaded(self) -> int:
         """Number of run-time compiled static programs this plan holds on the device."""

@@ -481,6 +481,13 @@ int64_t fr_plan_info(const fr_plan_t *plan, int32_t what) {
     case FR_INFO_GROUPS: return p.units();
     case FR_INFO_SHARED: return p.shared ? 1 : 0;
     case FR_INFO_STAGED_ROWS: return p.cos ? 0 : p.rows_staged();
+    case FR_INFO_AOT_PROGRAM: {
+      fr::Plan &q = *plan->p;
+      if (q.cos) return 0;
+      std::lock_guard<std::mutex> lock(q.mu);
+      const fr::GroupedProgram &g1 = fr::grouped(q, 1);
+      return fr::static_program_for(g1.recs.data(), (int)g1.recs.size(), 1);
+    }
     case FR_INFO_JIT_PROGRAMS:
       return p.jit ? (int64_t)static_cast<const JitState *>(p.jit)->progs.size() : 0;
     default: return fail(FR_E_ARG, "fr_plan_info: unknown selector");

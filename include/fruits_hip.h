@@ -78,6 +78,8 @@ extern "C" {
                                 exp tables); fr_iss_run returns FR_E_LIMIT when they do not fit -
                                 the caller then splits the word list */
 #define FR_INFO_JIT_PROGRAMS 9 /* run-time compiled static programs loaded for this plan (fr_plan_jit) */
+#define FR_INFO_AOT_PROGRAM 10 /* 1 + index of the pre-compiled static program (one group per series)
+                                  the plan's records equal, 0: none */
 
 /* sieve kinds of fr_sieve_* and the fused pipeline */
 #define FR_SIEVE_NPI 0 /* fruits/sieving/increment.py:101-129 */

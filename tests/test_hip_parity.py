@@ -1495,3 +1495,40 @@ def test_jit_repeated_words(fr, monkeypatch, tmp_path):
     np.testing.assert_array_equal(got, interp)
     for i in range(15, 48):
         np.testing.assert_array_equal(got[i], got[i % 15])
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FRUITS_TEST_RANDOM_CASES", "24"))))
+def test_random_jit_differential(fr, seed, monkeypatch, tmp_path):
+    """Random small word lists (positive exponents, repeated words, shared prefixes, both modes)
+    through their run-time compiled static program (FRUITS_HIP_JIT=2: compiled at the first
+    run): bit-identical to the interpreter, equal to the C oracle.  Lists the scheduler does
+    not accept (more than 32 nodes, 4 rows or 4 open prefixes, letters of more than 4
+    factors) simply stay on the interpreter - also checked."""
+    from fruits_amd import _native as nat
+    monkeypatch.setenv("FRUITS_HIP_JIT_CACHE", str(tmp_path / "jit"))
+    rng = np.random.default_rng(7000 + seed)
+    D = int(rng.integers(1, 5))
+    N = int(rng.choice([1, 5, 8, 9, 24, 40, 777, 1600]))
+    T = int(rng.choice([514, 600, 700, 1000, 1022, 1024]))
+    words = [_random_word(rng, D).replace("-", "") for _ in range(int(rng.integers(1, 9)))]
+    if rng.random() < 0.4:
+        words += [words[0], words[-1], words[0]]            # repeated words: several output rows
+    mode = "EXTENDED" if rng.random() < 0.6 else "SINGLE"
+    dist = "uniform" if rng.random() < 0.5 else "normal"
+    X = gen_input({"seed": seed, "dist": dist, "shape": [N, D, T]})
+    if dist == "normal":
+        X = X / 2.0
+    Xd = nat.to_device(X)
+
+    def run(jit):
+        monkeypatch.setenv("FRUITS_HIP_JIT", jit)
+        iss = fr.ISS([fr.words.SimpleWord(s) for s in words], mode=getattr(fr.ISSMode, mode))
+        plan = iss._plan(0, len(words))
+        return nat.to_host(iss.transform_device(Xd)), plan
+    interp, _ = run("0")
+    got, plan = run("2")
+    qualifies = plan.static_schedule(1) is not None and plan.static_program_index(1) == 0
+    assert plan.jit_loaded() == (0 if not qualifies else min(2, 1 + (plan.info(nat.FR_INFO_GROUPS) > 1)))
+    np.testing.assert_array_equal(got, interp)
+    ref = corc.iss_transform(X, words, mode)
+    rowwise_close(got, ref)
