@@ -486,7 +486,8 @@ int64_t fr_plan_info(const fr_plan_t *plan, int32_t what) {
       if (q.cos) return 0;
       std::lock_guard<std::mutex> lock(q.mu);
       const fr::GroupedProgram &g1 = fr::grouped(q, 1);
-      return fr::static_program_for(g1.recs.data(), (int)g1.recs.size(), 1);
+      return fr::static_program_for(g1.recs.data(), (int)g1.recs.size(), 1, q.row_src.data(),
+                                    (int)q.row_src.size());
     }
     case FR_INFO_JIT_PROGRAMS:
       return p.jit ? (int64_t)static_cast<const JitState *>(p.jit)->progs.size() : 0;
@@ -577,7 +578,8 @@ int fr_plan_prepare(fr_plan_t *plan, int64_t N, int64_t T, int32_t groups) {
     if (p.static_prog[0] < 0) {
       const fr::GroupedProgram &g1 = fr::grouped(p, 1);
       for (int g = 1; g <= 3; ++g)
-        p.static_prog[g] = fr::static_program_for(g1.recs.data(), (int)g1.recs.size(), g);
+        p.static_prog[g] = fr::static_program_for(g1.recs.data(), (int)g1.recs.size(), g, p.row_src.data(),
+                                                       (int)p.row_src.size());
       p.static_prog[0] = 0;
     }
     if (p.static_prog[1] <= 0 && fr::static_schedule(p, 1).ok) ensure_jit(p);
@@ -749,7 +751,8 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
       if (p.static_prog[0] < 0) {
         const fr::GroupedProgram &g1 = fr::grouped(p, 1);
         for (int g = 1; g <= 3; ++g)
-          p.static_prog[g] = fr::static_program_for(g1.recs.data(), (int)g1.recs.size(), g);
+          p.static_prog[g] = fr::static_program_for(g1.recs.data(), (int)g1.recs.size(), g, p.row_src.data(),
+                                                       (int)p.row_src.size());
         p.static_prog[0] = 0;
       }
       // no ahead-of-time program: one compiled at run time by fr_plan_prepare - or right here

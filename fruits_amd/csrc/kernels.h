@@ -13,7 +13,7 @@ namespace fr {
 int walk_chunk_elems(int64_t T);
 bool wave_rows_supported(int64_t T, int levels, bool vec_ok);
 bool packed_supported(int64_t T, int levels, int semiring);
-int static_program_for(const NodeRec *recs, int n, int groups);
+int static_program_for(const NodeRec *recs, int n, int groups, const int32_t *row_src, int rows);
 hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st);
 hipError_t launch_mpi_finalize(double *feats, const double *cnt, int64_t N, int64_t stride,
                                const int32_t *cols, int n_cols, const int32_t *pairs, int n_pairs,

@@ -20,18 +20,22 @@ static_assert(kStaticPrograms == 23, "list the generated programs above and belo
 
 struct StaticEntry {
   const int32_t *src;
-  int n_src, groups;
+  const int32_t *row_src;   // staged row -> input dimension: part of the program's identity
+  int n_src, rows, groups;
   hipError_t (*launch)(const IssArgs &, hipStream_t);
 };
-#define SP_ENTRY(i) {StaticProg##i::src, StaticProg##i::n_src, StaticProg##i::groups, walk_static_launch_##i}
+#define SP_ENTRY(i) {StaticProg##i::src, StaticProg##i::row_src, StaticProg##i::n_src, StaticProg##i::rows, StaticProg##i::groups, walk_static_launch_##i}
 static const StaticEntry kStaticTable[kStaticPrograms] = {
     SP_ENTRY(0), SP_ENTRY(1), SP_ENTRY(2), SP_ENTRY(3), SP_ENTRY(4), SP_ENTRY(5), SP_ENTRY(6), SP_ENTRY(7), SP_ENTRY(8), SP_ENTRY(9), SP_ENTRY(10), SP_ENTRY(11), SP_ENTRY(12), SP_ENTRY(13), SP_ENTRY(14), SP_ENTRY(15), SP_ENTRY(16), SP_ENTRY(17), SP_ENTRY(18), SP_ENTRY(19), SP_ENTRY(20), SP_ENTRY(21), SP_ENTRY(22)};
 
 // 1 + index of the static program for `groups` groups per series whose interpreter records
-// (one group) equal `recs`, or 0
-int static_program_for(const NodeRec *recs, int n, int groups) {
+// (one group) equal `recs` AND whose staged rows come from the same input dimensions (the
+// records name LDS rows; `[4]` alone has the records of `[1]` alone), or 0
+int static_program_for(const NodeRec *recs, int n, int groups, const int32_t *row_src, int rows) {
   for (int i = 0; i < kStaticPrograms; ++i)
     if (groups == kStaticTable[i].groups && n == kStaticTable[i].n_src &&
+        rows == kStaticTable[i].rows &&
+        std::memcmp(row_src, kStaticTable[i].row_src, (size_t)rows * 4) == 0 &&
         std::memcmp(recs, kStaticTable[i].src, (size_t)n * 64) == 0)
       return i + 1;
   return 0;

@@ -1532,3 +1532,23 @@ def test_random_jit_differential(fr, seed, monkeypatch, tmp_path):
     np.testing.assert_array_equal(got, interp)
     ref = corc.iss_transform(X, words, mode)
     rowwise_close(got, ref)
+
+
+@pytest.mark.parametrize("words,D", [(["[4]"], 4), (["[3]"], 3), (["[2]", "[3]"], 3),
+                                     (["[22]", "[23]", "[33]", "[2][2]", "[2][3]", "[3][2]", "[3][3]"], 3),
+                                     (["[3]", "[1]"], 3)])
+def test_static_program_other_dimensions(fr, monkeypatch, words, D, tmp_path):
+    """Word lists with the SHAPE of a standard set on other input dimensions: they must not
+    run that set's pre-compiled program (whose row sources are baked in) - the interpreter
+    or their own run-time compiled program, equal to the oracle either way."""
+    from fruits_amd import _native as nat
+    monkeypatch.setenv("FRUITS_HIP_JIT_CACHE", str(tmp_path / "jit"))
+    X = gen_input({"seed": 5 + D, "dist": "uniform", "shape": [530, D, 1024]})
+    Xd = nat.to_device(X)
+    ref = corc.iss_transform(X, words, "EXTENDED")
+    for jit in ("0", "2"):
+        monkeypatch.setenv("FRUITS_HIP_JIT", jit)
+        iss = fr.ISS([fr.words.SimpleWord(s) for s in words], mode=fr.ISSMode.EXTENDED)
+        got = nat.to_host(iss.transform_device(Xd))
+        rowwise_close(got, ref)
+        np.testing.assert_allclose(got, ref, rtol=RTOL)

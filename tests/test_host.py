@@ -536,3 +536,19 @@ def test_jit_without_hiprtc_falls_back(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
     assert "refused: True" in r.stdout and r.stdout.strip().endswith("6")   # 5 nodes + sentinel
+
+
+def test_static_program_identity_includes_dimensions():
+    """The records of a plan name LDS rows, not input dimensions: `[4]` alone compiles to the
+    records of `[1]` alone.  Only a plan whose staged rows come from the SAME dimensions may
+    run a pre-compiled program (found by the soak of the run-time compiled programs)."""
+    def index(words, mode="EXTENDED"):
+        ws = [fr.words.SimpleWord(s) for s in words]
+        return fr.ISS(ws, mode=getattr(fr.ISSMode, mode))._plan(0, len(ws)).static_program_index()
+    assert index(["[1]"]) > 0
+    assert index(["[4]"]) == 0 and index(["[2]"]) == 0
+    assert index(["[1]", "[2]"]) > 0 and index(["[2]", "[3]"]) == 0
+    w22 = [str(w) for w in fr.words.of_weight(2, dim=2)]
+    assert index(w22) > 0
+    assert index([s.replace("2", "3") for s in w22]) == 0          # dimensions (1, 3)
+    assert index([s.replace("2", "3").replace("1", "2") for s in w22]) == 0   # dimensions (2, 3)
