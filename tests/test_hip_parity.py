@@ -705,7 +705,10 @@ def test_random_coswiss_differential(fr, seed):
     ref = orc.coswiss_transform(X, words, freqs, exponent, total)
     assert out.shape == ref.shape
     scale = np.abs(ref).max(axis=2, keepdims=True)
-    assert np.all(np.abs(out - ref) <= RTOL * np.maximum(np.abs(ref), 1e-3 * scale))
+    # (a row whose terms cancel to ~1e-229 of the others - high exponents on a few steps - is
+    # judged on the scale of the whole result, not its own)
+    floor = 1e-9 * np.abs(ref).max()
+    assert np.all(np.abs(out - ref) <= RTOL * np.maximum(np.maximum(np.abs(ref), 1e-3 * scale), floor))
 
 
 def test_entry_points_capture_into_a_hip_graph(fr):
