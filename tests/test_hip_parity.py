@@ -1555,3 +1555,42 @@ def test_static_program_other_dimensions(fr, monkeypatch, words, D, tmp_path):
         got = nat.to_host(iss.transform_device(Xd))
         rowwise_close(got, ref)
         np.testing.assert_allclose(got, ref, rtol=RTOL)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FRUITS_TEST_RANDOM_CASES", "12"))))
+def test_select_ranks_random(fr, seed):
+    """fr_select_ranks on random row blocks against a sort: sizes on both sides of the 2048
+    candidates a workgroup settles, heavy ties (one value many times - settled in the gather
+    pass; a few values many times - the histogram passes go on), plateaus of a running
+    maximum, tiny / huge / negative values, neighbouring ranks (the successor search) and the
+    extremes."""
+    from fruits_amd import _native as nat
+    rng = np.random.default_rng(4242 + seed)
+    R = int(rng.integers(1, 4))
+    N = int(rng.choice([1, 3, 17, 64, 300]))
+    T = int(rng.choice([2, 33, 257, 1024, 1500]))
+    A = rng.standard_normal((R, N, T))
+    kind = seed % 6
+    if kind == 1:
+        A = np.round(A * 2) / 2                              # a handful of distinct values
+    elif kind == 2:
+        A[rng.random(A.shape) < 0.7] = 0.0                   # mostly ONE value
+    elif kind == 3:
+        A = np.maximum.accumulate(A, axis=2)                 # plateaus
+    elif kind == 4:
+        A *= 10.0 ** rng.integers(-300, 300, size=(R, 1, 1))
+    elif kind == 5:
+        A[:, :, ::3] = 1.5
+        A[:, :, 1::3] = -2.25                                # two values many times + noise
+    Ad = nat.to_device(A)
+    rows, incs, ranks, want = [], [], [], []
+    for r in range(R):
+        for inc in (0, 1, 2):
+            flat = np.sort(orc.pre_transform(A[r], inc).ravel())
+            n = flat.size
+            ks = {0, n - 1, n // 2, max(n // 2 - 1, 0), min(n // 2 + 1, n - 1), n // 4, (3 * n) // 4,
+                  int(rng.integers(0, n)), int(rng.integers(0, n))}
+            for k in sorted(ks):
+                rows.append(r); incs.append(inc); ranks.append(k); want.append(flat[k])
+    got = nat.select_ranks(Ad, rows, incs, ranks)
+    np.testing.assert_array_equal(got, np.array(want))
