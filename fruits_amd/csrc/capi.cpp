@@ -962,9 +962,6 @@ fr_pipeline_t *fr_pipeline_create(fr_plan_t *plan, int32_t n_sieves, const int32
       else if (sv.inc < 0 || sv.inc > 2) {
         bad = "the fused epilogue supports inc 0, 1 and 2 only";
         code = FR_E_LIMIT;
-      } else if (sv.inc >= 1 && plan->p->weighting == FR_W_TOTAL) {
-        bad = "increments of totally weighted sums are not fused";
-        code = FR_E_LIMIT;
       }
     }
     if (!bad.empty()) {

@@ -320,6 +320,7 @@ __global__ __launch_bounds__(kWalkThreads) void coswiss_kernel(const IssArgs a) 
         cx.feat_row = a.feats + n * a.feat_stride;
         cx.cnt_row = a.cnt + n * a.feat_stride;
         cx.cut_row = a.series_cuts ? a.series_cuts + n * a.cut_slots : nullptr;
+      cx.series = n;
       }
       coswiss_unit<C, S>(cx, a.X + (int64_t)j * a.cw_x_unit_stride + n * a.D * a.T + t0,
                          a.aux + (int64_t)f * 2 * a.T + t0, lb, le, a.cw_total != 0, j, tot_all,
@@ -363,6 +364,7 @@ __global__ __launch_bounds__(kWalkThreads) void coswiss_packed_kernel(const IssA
       cx.feat_row = a.feats + n * a.feat_stride;
       cx.cnt_row = a.cnt + n * a.feat_stride;
       cx.cut_row = a.series_cuts ? a.series_cuts + n * a.cut_slots : nullptr;
+      cx.series = n;
     }
     coswiss_unit<C, S>(cx, a.X + (int64_t)j * a.cw_x_unit_stride + n * a.D * a.T,
                        a.aux + (int64_t)f * 2 * a.T, lb, le, a.cw_total != 0, j, nullptr,

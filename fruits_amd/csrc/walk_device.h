@@ -87,6 +87,7 @@ struct WalkCtx {
   double *feat_row;     // MODE 1: feats + n*feat_stride
   double *cnt_row;      // MODE 1: band population of MPI features
   const int32_t *cut_row;  // MODE 1: this series' row of IssArgs::series_cuts (or nullptr)
+  int64_t series;          // MODE 1: index of the series being walked
   double *carry;        // carry slots of this series (multi-chunk; LDS or global) or nullptr
   int64_t t0;           // first time index of the chunk
   int tid, lane, wave, team;   // wave = index inside the team
@@ -589,6 +590,40 @@ __device__ __forceinline__ void fused_all(WalkCtx &cx, const Rec &nd, const Ops2
   }
 }
 
+// Totally weighted sums in the fused epilogue: the row the sieves see is c[t] (x) w[t] (Reals /
+// Bayesian: c * exp(-g alpha); Arctic: c - g alpha), so its increment at t is
+// c[t] (x) w[t] - c[t-1] (x) w[t-1] - the second term formed here from the exclusive prefix
+// (x[t] = c[t-1] bit for bit) and the weight row read one element to the left (staged in LDS;
+// the element in front of the chunk from the table itself).  The result takes x's place in
+// fused_op, whose plain difference then is the increment of the stored row, rounded like it.
+template <class C>
+__device__ __forceinline__ void previous_weighted(const WalkCtx &cx, int emit_mul,
+                                                  const double (&x)[C::EP], double (&xs)[C::EP]) {
+  constexpr int E = C::E, P = C::P;
+  const IssArgs &a = *cx.a;
+  const double *row = cx.rows + emit_mul * C::CHUNK;
+#pragma unroll
+  for (int h = 0; h < P; ++h)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int idx = cx.wave * C::SPAN + h * C::PIECE + cx.lane * E + e;
+      double w = C::SEMI != 1 ? 1.0 : 0.0;
+      if (idx > 0) {
+        w = row[lds_pos<C>(idx - 1)];
+      } else if (cx.t0 > 0) {
+        const int src = as_const(a.row_src)[emit_mul];     // (an exp table: src < 0)
+        w = (a.aux + (int64_t)(-src - 1) * a.aux_tab_stride + cx.series * a.aux_n_stride)[cx.t0 - 1];
+      }
+      if constexpr (C::SEMI != 1) {
+        xs[h * E + e] = x[h * E + e] * w;
+      } else {
+#pragma clang fp contract(off)
+        const double neg = -1.0 * w;                        // (as mul_row forms c + (-1) * row)
+        xs[h * E + e] = x[h * E + e] + neg;
+      }
+    }
+}
+
 template <class C>
 __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd, int slot,
                                              const double (&pin)[C::EP],
@@ -654,9 +689,15 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd, int slo
       // total weighting: Reals emit c * exp(-g alpha_k), Arctic emit c - g alpha_k
       if (C::WEIGHTED && emit_mul >= 0)
         mul_row<C>(cx, C::SEMI != 1 ? emit_mul : fac_arctic(emit_mul, -1), c);
-      if constexpr (C::MODE == 1)
-        fused_all<C>(cx, nd, pre, c, x, s, !(C::WEIGHTED && emit_mul >= 0));
-      else
+      if constexpr (C::MODE == 1) {
+        if (C::WEIGHTED && emit_mul >= 0) {
+          double xs[EP];
+          previous_weighted<C>(cx, emit_mul, x, xs);
+          fused_all<C>(cx, nd, pre, c, xs, s, false);
+        } else {
+          fused_all<C>(cx, nd, pre, c, x, s, true);
+        }
+      } else
         emit_all<C>(cx, nd, c, more, n_more);
       STAMP(cx, 5);  // stores
     }
@@ -1034,6 +1075,7 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
         cx.feat_row = a.feats + n * a.feat_stride;
         cx.cnt_row = a.cnt + n * a.feat_stride;
         cx.cut_row = a.series_cuts ? a.series_cuts + n * a.cut_slots : nullptr;
+        cx.series = n;
       }
       if (!first_unit || chunk > 0) lds_barrier();  // all reads of the old rows are done
       // stage the referenced rows of this chunk: coalesced 16-byte units, the

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(kWalkThreads) void iss_walk_packed_kernel(const Iss
       cx.feat_row = a.feats + n * a.feat_stride;
       cx.cnt_row = a.cnt + n * a.feat_stride;
       cx.cut_row = a.series_cuts ? a.series_cuts + n * a.cut_slots : nullptr;
+      cx.series = n;
     }
     // stage: lane l keeps elements [h*128 + 2l, +2) of every row - the ones read_row
     // hands back to it (wave-local, no barrier)

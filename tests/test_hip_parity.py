@@ -308,8 +308,9 @@ def test_random_fruit_differential(fr, seed, monkeypatch):
         3 if Dp != D else int(rng.integers(0, 3))]
     words = sorted({_random_word(rng, Dp).replace("-", "") for _ in range(int(rng.integers(1, 10)))})
     semiring = str(rng.choice(["Reals", "Reals", "Arctic"]))
-    weighting = [None, None, {"kind": "Indices", "scale": 2.0}, {"kind": "L1", "scale": 2.0}][
-        int(rng.integers(0, 4))]
+    weighting = [None, None, {"kind": "Indices", "scale": 2.0}, {"kind": "L1", "scale": 2.0},
+                 {"kind": "Indices", "scale": 2.0, "total": True},
+                 {"kind": "L1", "scale": 2.0, "total": True}][int(rng.integers(0, 6))]
     sieves = []
     for _ in range(int(rng.integers(1, 5))):
         kind = str(rng.choice(["NPI", "MPI", "END"]))
@@ -1594,3 +1595,40 @@ def test_select_ranks_random(fr, seed):
                 rows.append(r); incs.append(inc); ranks.append(k); want.append(flat[k])
     got = nat.select_ranks(Ad, rows, incs, ranks)
     np.testing.assert_array_equal(got, np.array(want))
+
+
+@pytest.mark.parametrize("semiring", ["Reals", "Arctic", "Bayesian"])
+@pytest.mark.parametrize("T", [300, 1024, 2100])
+def test_total_weighting_increments_fused(fr, monkeypatch, semiring, T):
+    """Increments (inc = 1, 2) of TOTALLY weighted sums in the fused epilogue: the sieves see
+    c[t] (x) w[t], so the increment needs the weight one step to the left - same counts as the
+    materialising sieve kernels on the stored rows, one and several time chunks."""
+    rng = np.random.default_rng(T)
+    X = rng.standard_normal((19, 2, T)).cumsum(axis=2) / np.sqrt(T)
+    words = ["[1]", "[1][2]", "[12][1]", "[2][2][1]", "[2]"]
+
+    def build():
+        fruit = fr.Fruit()
+        fruit.add(fr.ISS([fr.words.SimpleWord(s) for s in words], mode=fr.ISSMode.EXTENDED,
+                         semiring=getattr(fr.iss.semiring, semiring)(),
+                         weighting=fr.iss.weighting.Indices(scale=2.0, total=True)))
+        fruit.add(fr.sieving.NPI(q=(0.5, 1.0), inc=1, cut=[T // 3, -1]))
+        fruit.add(fr.sieving.MPI(q=(0.25, 0.75), inc=2))
+        fruit.add(fr.sieving.NPI(inc=0), fr.sieving.END)
+        for slc in fruit:
+            slc.fit_sample_size = 1.0
+        return fruit
+    fused = build()
+    np.random.seed(1)
+    fused.fit(X)
+    assert fused.get_slice()._fused(T) is not None
+    a = fused.transform(X)
+    monkeypatch.setenv("FRUITS_AMD_FUSED", "0")
+    plain = build()
+    np.random.seed(1)
+    plain.fit(X)
+    b = plain.transform(X)
+    labels = [fused.label(i) for i in range(fused.nfeatures())]
+    counts = np.array([("NPI" in s) for s in labels])
+    np.testing.assert_array_equal(a[:, counts], b[:, counts])
+    np.testing.assert_allclose(a[:, ~counts], b[:, ~counts], rtol=1e-9, atol=1e-12)
