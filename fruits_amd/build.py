@@ -31,6 +31,8 @@ def units():
         for lv in (2, 4, 6, 8):
             out.append((f"walk_m{mode}_l{lv}", "walk_inst.hip",
                         [f"-DWALK_MODE={mode}", f"-DWALK_LV={lv}"]))
+    for lv in (2, 4, 6, 8):
+        out.append((f"walk_m1ti_l{lv}", "walk_inst.hip", ["-DWALK_MODE=1", f"-DWALK_LV={lv}", "-DWALK_TI"]))
     for mode in (0, 1):
         out.append((f"walk_packed_m{mode}", "walk_packed_inst.hip", [f"-DWALK_MODE={mode}"]))
     for s in (1, 2, 3, 4, 5, 6, 7, 8):

@@ -626,6 +626,7 @@ struct FusedArgs {          // non-null feats selects the fused sieve kernels
   int32_t n_ops = 0, n_ops_padded = 0;
   const int32_t *series_cuts = nullptr;   // device (N, cut_slots) per-series boundaries
   int32_t cut_slots = 0;
+  bool total_inc = false;   // a differencing sieve on a totally weighted plan
   // fused preparation: d_X is the raw input, the staging forms the prepared rows
   const int32_t *prep = nullptr;   // device (n_prep, 4) table
   const double *stats = nullptr;   // device (N, n_prep, 2) or nullptr (no STD)
@@ -732,7 +733,10 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
                                 " rows per time chunk (input dimensions + exp tables of " +
                                 std::to_string(p.alphas.size()) +
                                 " distinct alphas), more than the LDS holds - split the word list");
-  const bool packed = !wave_rows && shape.packed;
+  // (a totally weighted plan with differencing sieves runs the cooperative kernels, which have
+  // the instantiation for it, also on short series)
+  const bool packed = !wave_rows && shape.packed &&
+                      !(fu && fu->total_inc && p.weighting == FR_W_TOTAL);
   const bool auto_groups = !wave_rows && !packed && groups <= 0 && env_int("FRUITS_HIP_GROUPS", 0) <= 0;
   const int64_t resident = auto_groups ? query_resident(p, N, T, fu != nullptr, vec_ok_pre) : 0;
   fr::GroupedProgram *gpp = nullptr;
@@ -867,6 +871,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     a.n_ops_padded = fu->n_ops_padded;
     a.series_cuts = fu->series_cuts;
     a.cut_slots = fu->cut_slots;
+    a.total_inc = (fu->total_inc && p.weighting == FR_W_TOTAL) ? 1 : 0;
     if (fu->prep) {
       if (packed || wave_rows)
         return fail(FR_E_LIMIT, w + ": the fused preparation needs the cooperative kernel");
@@ -1209,6 +1214,8 @@ int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, 
   fu.feat_stride = feat_stride;
   fu.n_ops = pl->n_ops_eff;
   fu.n_ops_padded = pl->n_ops_padded;
+  for (const PipeSieve &sv : pl->sieves)
+    if (sv.kind != FR_SIEVE_END && sv.inc >= 1) fu.total_inc = true;
   if (pl->cut_slots_needed > 0) {
     if (!pl->d_series_cuts || pl->cuts_N != N || pl->cut_slots < pl->cut_slots_needed)
       return fail(FR_E_ARG, "fr_pipeline_run: a sieve has per-series cuts - call "

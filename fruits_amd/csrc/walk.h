@@ -11,9 +11,9 @@ namespace fr {
 
 // ---------------------------------------------------------------- launch
 template <int E, int P, int LV, int MULTI, bool VEC, bool W, int TEAM = 4, int MODE = 0,
-          int SEMI = 0, bool NT = false>
+          int SEMI = 0, bool NT = false, bool TI = false>
 static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
-  using C = WalkCfg<E, P, LV, MULTI, VEC, W, TEAM, MODE, SEMI, NT>;
+  using C = WalkCfg<E, P, LV, MULTI, VEC, W, TEAM, MODE, SEMI, NT, TI>;
   const size_t lds = ((size_t)a.R * C::CHUNK + 2 * C::NW + 2 * C::NW +
                       (MULTI == 1 ? a.carry_slots : 0)) *
                      sizeof(double);

@@ -24,8 +24,13 @@ namespace fr {
 // every piece.  So every 16-byte global access of a wave is lane-contiguous
 // (E = 2: 1 KiB per instruction) and only NW wave totals cross waves.
 template <int E_, int P_, int MAXLV_, int MULTI_, bool VEC_, bool WEIGHTED_, int TEAM_ = 4,
-          int MODE_ = 0, int SEMI_ = 0, bool NT_ = false>
+          int MODE_ = 0, int SEMI_ = 0, bool NT_ = false, bool TOTALINC_ = false>
 struct WalkCfg {
+  // TOTALINC: fused epilogue of a TOTALLY weighted plan with differencing sieves - the
+  // increments need the weight one step to the left (previous_weighted).  Its own
+  // instantiation: compiled into the common weighted kernels it costs them 130-400 more
+  // SGPR spills and 20 % of their speed (config 4: 21.5 -> 26.5 ms).
+  static constexpr bool TOTALINC = TOTALINC_;
   // NT: the rows of X are staged with non-temporal loads (load_input; the host asks for it
   // when every row is read once per launch and the batch is about the size of the cache)
   static constexpr bool NT = NT_;
@@ -689,14 +694,16 @@ __device__ __forceinline__ void process_node(WalkCtx &cx, const Rec &nd, int slo
       // total weighting: Reals emit c * exp(-g alpha_k), Arctic emit c - g alpha_k
       if (C::WEIGHTED && emit_mul >= 0)
         mul_row<C>(cx, C::SEMI != 1 ? emit_mul : fac_arctic(emit_mul, -1), c);
-      if constexpr (C::MODE == 1) {
-        if (C::WEIGHTED && emit_mul >= 0) {
+      if constexpr (C::MODE == 1 && C::TOTALINC) {
+        if (emit_mul >= 0) {
           double xs[EP];
           previous_weighted<C>(cx, emit_mul, x, xs);
           fused_all<C>(cx, nd, pre, c, xs, s, false);
         } else {
           fused_all<C>(cx, nd, pre, c, x, s, true);
         }
+      } else if constexpr (C::MODE == 1) {
+        fused_all<C>(cx, nd, pre, c, x, s, !(C::WEIGHTED && emit_mul >= 0));
       } else
         emit_all<C>(cx, nd, c, more, n_more);
       STAMP(cx, 5);  // stores

@@ -65,10 +65,40 @@ static hipError_t inst_p(const IssArgs &a, hipStream_t st) {
 }
 #define WALK_CAT2(a, b, c, d) a##b##c##d
 #define WALK_CAT(a, b, c, d) WALK_CAT2(a, b, c, d)
+#ifdef WALK_TI
+// Translation unit of the TOTALINC instantiations (WalkCfg::TOTALINC: fused epilogue of a
+// totally weighted plan with differencing sieves), apart from the common fused kernels so the
+// build stays parallel.
+template <int P, int MULTI>
+static hipError_t inst_ti(const IssArgs &a, hipStream_t st) {
+  constexpr int E = WALK_E(P), PP = WALK_P(P);
+  if (a.semiring == kSemiArctic)
+    return launch_walk_cfg<E, PP, WALK_LV, MULTI, true, true, 4, 1, 1, false, true>(a, st);
+  if (a.semiring == kSemiBayesian)
+    return launch_walk_cfg<E, PP, WALK_LV, MULTI, true, true, 4, 1, 2, false, true>(a, st);
+  return launch_walk_cfg<E, PP, WALK_LV, MULTI, true, true, 4, 1, 0, false, true>(a, st);
+}
+template <int P>
+static hipError_t inst_ti_p(const IssArgs &a, hipStream_t st) {
+  const int multi = a.nchunks > 1 ? (a.carry_in_lds ? 1 : 2) : 0;
+  if (multi == 1) return inst_ti<P, 1>(a, st);
+  return multi == 2 ? inst_ti<P, 2>(a, st) : inst_ti<P, 0>(a, st);
+}
+hipError_t WALK_CAT(walk_inst_ti, , _l, WALK_LV)(const IssArgs &a, int chunk, hipStream_t st) {
+  return chunk == 512 ? inst_ti_p<1>(a, st) : inst_ti_p<2>(a, st);
+}
+#else
+#if WALK_MODE == 1
+hipError_t WALK_CAT(walk_inst_ti, , _l, WALK_LV)(const IssArgs &, int, hipStream_t);
+#endif
 hipError_t WALK_CAT(walk_inst_m, WALK_MODE, _l, WALK_LV)(const IssArgs &a, int chunk,
                                                           hipStream_t st) {
+#if WALK_MODE == 1
+  if (a.aux && a.total_inc) return WALK_CAT(walk_inst_ti, , _l, WALK_LV)(a, chunk, st);
+#endif
   return chunk == 512 ? inst_p<1>(a, st) : inst_p<2>(a, st);
 }
+#endif
 #endif
 
 }  // namespace fr
