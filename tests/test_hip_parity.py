@@ -1430,7 +1430,8 @@ def test_float_cuts_run_fused(fr, monkeypatch):
     assert slc._fusable() and slc._fused(T) is not None and slc._fused(T)._cut_slots == 4 + 2 + 4
     a = fused.transform(X)
     b = fused.transform(X[:7])                 # another batch size: the table follows
-    np.testing.assert_array_equal(a[:7], b)
+    # (band means are sums of atomics: their last bit may depend on the launch shape)
+    np.testing.assert_allclose(a[:7], b, rtol=1e-12, atol=1e-13)
     monkeypatch.setenv("FRUITS_AMD_FUSED", "0")
     plain = build()
     np.random.seed(3)
