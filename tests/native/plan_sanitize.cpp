@@ -50,6 +50,12 @@ int main() {
         checksum += (long)gp.recs.size() + gp.group_begin.back() + gp.groups;
         for (const fr::NodeRec &r : gp.recs) checksum += r.w[0] + r.w[6];
       }
+      // the static scheduler (frames, staged rows, output-row continuation entries)
+      for (int G : {1, 2, 3}) {
+        const fr::StaticSchedule sc = fr::static_schedule(*p, G);
+        checksum += sc.ok ? (long)sc.entries.size() + sc.frames + sc.rows : -1;
+        for (const fr::NodeRec &r : sc.entries) checksum += r.w[0] & 0xff;
+      }
     } else {
       checksum += p->cos->factors.size() + p->cos->letter_begin.back();
       delete p->cos;
