@@ -289,8 +289,7 @@ class FruitSlice:
         for prep in self._preparateurs:
             prep._cache = cache
             if fit_on is not None:
-                needs_host = type(prep)._fit is not Preparateur._fit
-                prep.fit(nat.to_host(Xd) if needs_host else fit_on)
+                prep.fit(nat.to_host(Xd) if prep._fit_needs_data() else fit_on)
             Xd = prep._transform_device(Xd)
             for cb in callbacks:
                 cb.on_preparateur(nat.to_host(Xd))

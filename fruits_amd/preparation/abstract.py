@@ -14,6 +14,11 @@ class Preparateur(Seed, ABC):
     def _fit(self, X: np.ndarray) -> None:
         pass
 
+    def _fit_needs_data(self) -> bool:
+        """False when ``fit`` looks at nothing but the call itself: a fruit then does not
+        download the (prepared) fit sample for it."""
+        return type(self)._fit is not Preparateur._fit
+
     def _transform_device(self, Xd):
         """Device tensors in, device tensor out (never mutates ``Xd``)."""
         raise NotImplementedError

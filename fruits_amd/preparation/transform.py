@@ -83,6 +83,9 @@ class STD(Preparateur):
         self._std = None
         self._eps = std_eps
 
+    def _fit_needs_data(self) -> bool:
+        return not self._separately
+
     def _fit(self, X: np.ndarray) -> None:
         if not self._separately:
             self._mean = np.mean(X)

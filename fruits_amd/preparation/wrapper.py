@@ -22,6 +22,9 @@ class NEW(Preparateur):
     def requires_fitting(self) -> bool:
         return False if self._preparateur is None else self._preparateur.requires_fitting
 
+    def _fit_needs_data(self) -> bool:
+        return self._preparateur is not None and self._preparateur._fit_needs_data()
+
     def _fit(self, X: np.ndarray) -> None:
         if self._preparateur is not None:
             self._preparateur.fit(X)
