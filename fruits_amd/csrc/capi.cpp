@@ -370,7 +370,7 @@ extern "C" {
 
 const char *fr_last_error(void) { return g_err.c_str(); }
 
-int fr_version(void) { return 120; }
+int fr_version(void) { return 130; }
 
 int fr_device_count(void) {
   int n = 0;
