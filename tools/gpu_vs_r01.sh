@@ -1,5 +1,7 @@
 #!/bin/bash
-# same-box A/B against the round-1 tree (_variants/r01, built there): alternating processes
+# same-box A/B against an earlier tree: alternating processes.  _variants/r01 = a checkout of the
+# commit to compare with (git worktree add _variants/r01 <commit> && (cd _variants/r01 && python -m
+# fruits_amd.build)); git-ignored, not kept in the repository
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$1; mkdir -p $O
