@@ -964,8 +964,8 @@ fr_pipeline_t *fr_pipeline_create(fr_plan_t *plan, int32_t n_sieves, const int32
     int code = FR_E_ARG;
     if (bad.empty() && sv.kind != FR_SIEVE_END) {
       if (sv.Q1 < 2) bad = "a band sieve needs >= 2 thresholds";
-      else if (sv.inc < 0 || sv.inc > 2) {
-        bad = "the fused epilogue supports inc 0, 1 and 2 only";
+      else if (sv.inc < 0 || sv.inc > 8 || (sv.inc > 2 && T > fr::walk_chunk_elems(T))) {
+        bad = "the fused epilogue supports inc 0, 1 and 2 (3 to 8 on series of one time chunk)";
         code = FR_E_LIMIT;
       }
     }

@@ -536,7 +536,7 @@ __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w,
         if (C::SEMI == 0 && seq_steps) step = (x[i] + s[i]) - x[i];
         d[i] = (t_first + h * C::PIECE + e == 0) ? 0.0 : step;
       }
-    if (inc == 2) {
+    if (inc >= 2) {
       if (!sc.have_dp) {
         prev_first_differences<C>(cx, d, sc.dp);
         sc.have_dp = true;
@@ -546,6 +546,21 @@ __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w,
 #pragma unroll
         for (int e = 0; e < E; ++e)
           d[h * E + e] = (t_first + h * C::PIECE + e == 0) ? 0.0 : d[h * E + e] - sc.dp[h * E + e];
+      if constexpr (C::MULTI == 0) {
+        // third to eighth differences (IncrementSieve._pre_transform applies _increments inc
+        // times, fruits/sieving/increment.py:63-71): one more neighbour exchange per order.
+        // Single-chunk series only (the host refuses longer ones: an order needs its own
+        // carry between chunks).
+        for (int k = 3; k <= inc; ++k) {
+          double dq[EP];
+          prev_first_differences<C>(cx, d, dq);
+#pragma unroll
+          for (int h = 0; h < P; ++h)
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+              d[h * E + e] = (t_first + h * C::PIECE + e == 0) ? 0.0 : d[h * E + e] - dq[h * E + e];
+        }
+      }
     }
   }
   int cnt = 0;

@@ -324,7 +324,7 @@ def test_random_fruit_differential(fr, seed, monkeypatch):
             q = [[0.0, 1.0], [-1.0, 1.0], [0.5, 1.0], [0.25, 0.5, 1.0], [-1.0, 0.3, 0.7, 1.0]][
                 int(rng.integers(0, 5))]
             sieves.append({"kind": kind, "cut": cut, "q": q,
-                           "inc": int(rng.integers(0, 5 if seed % 3 == 2 else 3))})
+                           "inc": int(rng.integers(0, 6))})   # 3..5: fused on one-chunk series
     spec = {"slices": [{"preps": preps,
                         "iss": [{"words": words, "mode": str(rng.choice(["EXTENDED", "SINGLE"])),
                                  "semiring": semiring, "weighting": weighting}],
@@ -1633,3 +1633,44 @@ def test_total_weighting_increments_fused(fr, monkeypatch, semiring, T):
     counts = np.array([("NPI" in s) for s in labels])
     np.testing.assert_array_equal(a[:, counts], b[:, counts])
     np.testing.assert_allclose(a[:, ~counts], b[:, ~counts], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("T", [200, 700, 1024])
+def test_high_order_increments_fused(fr, monkeypatch, T):
+    """NPI / MPI with inc = 3 ... 8 (IncrementSieve._pre_transform applies the increments inc
+    times): fused on series of one time chunk - same counts as the materialising kernels;
+    longer series keep the unfused path."""
+    rng = np.random.default_rng(T)
+    X = rng.standard_normal((13, 2, T)).cumsum(axis=2)
+
+    def build():
+        fruit = fr.Fruit()
+        fruit.add(fr.ISS([fr.words.SimpleWord(s) for s in ["[1]", "[1][2]", "[12][1]", "[2][2][1]"]],
+                         mode=fr.ISSMode.EXTENDED))
+        for inc in (3, 4, 8):
+            fruit.add(fr.sieving.NPI(q=(0.5, 1.0), inc=inc, cut=[T // 2, -1]))
+        fruit.add(fr.sieving.MPI(q=(0.25, 0.75), inc=5), fr.sieving.NPI(inc=6), fr.sieving.END)
+        for slc in fruit:
+            slc.fit_sample_size = 1.0
+        return fruit
+    fused = build()
+    np.random.seed(2)
+    fused.fit(X)
+    assert fused.get_slice()._fused(T) is not None
+    a = fused.transform(X)
+    monkeypatch.setenv("FRUITS_AMD_FUSED", "0")
+    plain = build()
+    np.random.seed(2)
+    plain.fit(X)
+    b = plain.transform(X)
+    labels = [fused.label(i) for i in range(fused.nfeatures())]
+    counts = np.array([("NPI" in s) for s in labels])
+    np.testing.assert_array_equal(a[:, counts], b[:, counts])
+    np.testing.assert_allclose(a[:, ~counts], b[:, ~counts], rtol=1e-9, atol=1e-9)
+    monkeypatch.delenv("FRUITS_AMD_FUSED")
+    long_fruit = build()
+    XL = rng.standard_normal((5, 2, 2100)).cumsum(axis=2)
+    np.random.seed(2)
+    long_fruit.fit(XL)
+    assert long_fruit.get_slice()._fused(2100) is None        # an order needs its own carry
+    assert long_fruit.transform(XL).shape == (5, long_fruit.nfeatures())
