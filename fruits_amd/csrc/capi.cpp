@@ -964,8 +964,9 @@ fr_pipeline_t *fr_pipeline_create(fr_plan_t *plan, int32_t n_sieves, const int32
     int code = FR_E_ARG;
     if (bad.empty() && sv.kind != FR_SIEVE_END) {
       if (sv.Q1 < 2) bad = "a band sieve needs >= 2 thresholds";
-      else if (sv.inc < 0 || sv.inc > 8 || (sv.inc > 2 && T > fr::walk_chunk_elems(T))) {
-        bad = "the fused epilogue supports inc 0, 1 and 2 (3 to 8 on series of one time chunk)";
+      else if (sv.inc < -8 || sv.inc > 8 ||
+               ((sv.inc > 2 || sv.inc < 0) && T > fr::walk_chunk_elems(T))) {
+        bad = "the fused epilogue supports inc 0, 1 and 2 (-8 to 8 on series of one time chunk)";
         code = FR_E_LIMIT;
       }
     }
@@ -1068,7 +1069,7 @@ int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
         const double *q = h_quant + (size_t)k * pl->q_stride + sv.q_off;
         for (int j = 0; j < C; ++j)
           for (int b = 0; b + 1 < sv.Q1; ++b)
-            row.push_back(fr::FeatOp{sv.kind | (sv.inc << 8) | (sv.series_cuts ? (1 << 16) : 0),
+            row.push_back(fr::FeatOp{sv.kind | ((sv.inc & 0xff) << 8) | (sv.series_cuts ? (1 << 16) : 0),
                                      k * pl->per_sum + sv.col + j * (sv.Q1 - 1) + b, sv.cuts[j],
                                      sv.cuts[j + 1], q[b], q[b + 1]});
       }

@@ -487,7 +487,7 @@ __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w,
                                          const double (&s)[C::EP], bool seq_steps,
                                          FusedScratch<C::EP> &sc) {
   constexpr int E = C::E, P = C::P, EP = C::EP;
-  const int kind = w[0] & 0xff, inc = (w[0] >> 8) & 0xff, col = w[1];
+  const int kind = w[0] & 0xff, inc = (int)(int8_t)((w[0] >> 8) & 0xff), col = w[1];   // inc: signed
   // per-series cuts (coquantile positions): lo / hi name slots of the series' cut row
   const bool series_cuts = (w[0] >> 16) & 1;
   if (kind == FR_SIEVE_END_K) {
@@ -522,9 +522,21 @@ __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w,
   const double qlo = bits_to_double(w[4], w[5]), qhi = bits_to_double(w[6], w[7]);
   const int t_first = (int)cx.t0 + cx.wave * C::SPAN + cx.lane * E;  // element (h=0, e=0)
   double d[EP];
-  if (inc == 0) {
+  if (inc <= 0) {
 #pragma unroll
     for (int i = 0; i < EP; ++i) d[i] = c[i];
+    if constexpr (C::MULTI == 0) {
+      // inc < 0: the row cumulated -inc times (np.cumsum, fruits/sieving/increment.py:68-70) -
+      // a plain sum whatever the semiring of the plan; one-chunk series only (the host
+      // refuses longer ones: every cumulation would need its own carry)
+      using CR = WalkCfg<C::E, C::P, C::MAXLV, 0, C::VEC, C::WEIGHTED, C::TEAM, C::MODE, 0>;
+      for (int k = inc; k < 0; ++k) {
+        double cs[EP], xs[EP];
+        block_scan<CR>(cx, d, cs, xs, 0);
+#pragma unroll
+        for (int i = 0; i < EP; ++i) d[i] = cs[i];
+      }
+    }
   } else {
     // increments are zero-padded at t = 0 (fruits/cache.py:8-13)
 #pragma unroll

@@ -377,8 +377,8 @@ class FruitSlice:
         for sv in self._sieves:
             if type(sv) not in (NPI, MPI, END):
                 return False
-            if type(sv) is not END and not 0 <= sv._inc <= 8:
-                return False     # (3..8: series of one time chunk; the pipeline says if not)
+            if type(sv) is not END and not -8 <= sv._inc <= 8:
+                return False     # (beyond 0..2: series of one time chunk; the pipeline says if not)
         return True
 
     def _fused(self, T: int, indices=None):

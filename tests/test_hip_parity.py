@@ -1674,3 +1674,35 @@ def test_high_order_increments_fused(fr, monkeypatch, T):
     long_fruit.fit(XL)
     assert long_fruit.get_slice()._fused(2100) is None        # an order needs its own carry
     assert long_fruit.transform(XL).shape == (5, long_fruit.nfeatures())
+
+
+@pytest.mark.parametrize("semiring", ["Reals", "Arctic"])
+@pytest.mark.parametrize("T", [200, 1024])
+def test_cumulated_rows_fused(fr, monkeypatch, semiring, T):
+    """NPI / MPI with inc < 0 (the row cumulated -inc times, fruits/sieving/increment.py:68-70):
+    fused on one-chunk series; against the materialising path, whose cumulation is the
+    same parallel sum in another association (counts on exact ties may move by one)."""
+    rng = np.random.default_rng(T + len(semiring))
+    X = rng.standard_normal((11, 2, T)) / np.sqrt(T)
+
+    def build():
+        fruit = fr.Fruit()
+        fruit.add(fr.ISS([fr.words.SimpleWord(s) for s in ["[1]", "[1][2]", "[2][1][1]"]],
+                         mode=fr.ISSMode.EXTENDED, semiring=getattr(fr.iss.semiring, semiring)()))
+        fruit.add(fr.sieving.NPI(q=(0.5, 1.0), inc=-1, cut=[T // 2, -1]))
+        fruit.add(fr.sieving.MPI(q=(0.25, 0.75), inc=-2), fr.sieving.NPI(q=(0.3, 1.0), inc=-3), fr.sieving.END)
+        for slc in fruit:
+            slc.fit_sample_size = 1.0
+        return fruit
+    fused = build()
+    np.random.seed(4)
+    fused.fit(X)
+    assert fused.get_slice()._fused(T) is not None
+    a = fused.transform(X)
+    monkeypatch.setenv("FRUITS_AMD_FUSED", "0")
+    plain = build()
+    np.random.seed(4)
+    plain.fit(X)
+    b = plain.transform(X)
+    labels = [fused.label(i) for i in range(fused.nfeatures())]
+    compare_features(a, b, labels, count_frac=0.02)
