@@ -740,6 +740,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   const bool auto_groups = !wave_rows && !packed && groups <= 0 && env_int("FRUITS_HIP_GROUPS", 0) <= 0;
   const int64_t resident = auto_groups ? query_resident(p, N, T, fu != nullptr, vec_ok_pre) : 0;
   fr::GroupedProgram *gpp = nullptr;
+  int static_lds_pad = 0;
   int static_prog = 0;                      // > 0: ahead-of-time program, -1: run-time compiled
   const fr::JitProgram *jit_prog = nullptr;
   {
@@ -778,6 +779,12 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
       const bool cache_sized = N >= env_int("FRUITS_HIP_STATIC_SPLIT_BELOW", 768) &&
                                footprint <= 2.0 * 256.0 * 1024.0 * 1024.0;
       static_groups = asked > 0 ? asked : (cache_sized ? 1 : gmax);
+      // Batches that stream through HBM (beyond twice the cache): FOUR resident workgroups per
+      // CU instead of six - fewer concurrent write streams suit the memory system better
+      // (N = 4096 / 8192 / 16384: 134 -> 122, 263 -> 241, 525 -> 493 us); 16 KB of unused LDS
+      // per workgroup is how a launch asks for that.  Cache-sized and small batches keep six
+      // (N = 2048: 56.2 vs 58.6 us with four).
+      static_lds_pad = (!cache_sized && N >= env_int("FRUITS_HIP_STATIC_SPLIT_BELOW", 768)) ? 16384 : 0;
       if (have(static_groups)) {
         static_prog = p.static_prog[static_groups] > 0 ? p.static_prog[static_groups] : -1;
         if (static_prog < 0) {
@@ -881,6 +888,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     }
   }
   a.static_prog = static_prog > 0 ? static_prog : 0;
+  a.lds_pad = env_int("FRUITS_HIP_STATIC_LDS_PAD", static_lds_pad);
   // The interpreter's share of the same finding, in the window where it was measured to pay:
   // one group per series and a batch just above the Infinity Cache (1 to 1.5 times its
   // 256 MiB - config 2: 70 -> 65 us; 264 MB: 43 -> 45 us, 440 MB: 88 -> 93 us, so not there).

@@ -254,7 +254,7 @@ hipError_t jit_launch(const JitProgram &p, const IssArgs &a, hipStream_t st) {
   IssArgs args = a;
   void *params[] = {&args};
   return hipModuleLaunchKernel(p.fn, (unsigned)blocks, 1, 1, kWalkThreads, 1, 1,
-                               (unsigned)p.lds_bytes, st, params, nullptr);
+                               (unsigned)(p.lds_bytes + (size_t)a.lds_pad), st, params, nullptr);
 }
 
 }  // namespace fr

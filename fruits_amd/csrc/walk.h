@@ -49,7 +49,7 @@ static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
 // launch of a static program: same persistent grid as the interpreter's
 template <class C, class PG>
 static hipError_t launch_walk_static(const IssArgs &a, hipStream_t st) {
-  const size_t lds = ((size_t)PG::rows * C::CHUNK + 4 * C::NW) * sizeof(double);
+  const size_t lds = ((size_t)PG::rows * C::CHUNK + 4 * C::NW) * sizeof(double) + (size_t)a.lds_pad;
   static LaunchCache cache;
   int per_cu = 1;
   hipError_t e = cache.facts(iss_walk_static_kernel<C, PG>, kWalkThreads, lds, &per_cu);

@@ -125,6 +125,7 @@ struct IssArgs {
   const double *cw_mask;
   int64_t cw_x_unit_stride;
   int32_t cw_Lmax;
+  int32_t lds_pad;          // experiments: extra dynamic LDS bytes per workgroup (fewer resident ones)
   int32_t total_inc;        // 1: totally weighted plan whose fused sieves difference (WalkCfg::TOTALINC)
   int32_t nt_input;         // 1: stage the rows of X with non-temporal loads (interpreter, one group)
   int32_t static_prog;      // != 0: the records equal pre-compiled static program #n (walk_static_inst.hip)
