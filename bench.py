@@ -392,6 +392,12 @@ def main() -> None:
     device_index = local_rank if backend == "nccl" else local_rank % n_dev
     torch.cuda.set_device(device_index)
     dist = None
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version
+    # banner when its first communicator comes up, gloo its connection lines): everything but
+    # the result goes to stderr - file descriptor 1 is pointed at 2 until the line is written.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if distributed:
         import torch.distributed as dist
         if backend == "nccl":
@@ -510,8 +516,11 @@ def main() -> None:
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(json_fd, 1)
+    os.close(json_fd)
     if rank == 0:
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
