@@ -221,6 +221,34 @@ bool carries_fit_lds(const fr::Plan &p, int64_t T, int G) {
          rows_bytes + (size_t)carry_slots_for(p, G) * 8 <= 40 * 1024;
 }
 
+// LDS feature window of a fused cooperative launch (walk_device.h, feat_flush): as many slots
+// as fit next to the rows and carries while four workgroups still share a CU's 160 KiB, at
+// least what the widest node needs (output rows x feature ops).  `fits`: every group's
+// features fit, so a unit flushes once.  0: the widest node does not fit the LDS at all.
+int feat_window_for(const fr::GroupedProgram &gp, size_t other_lds_bytes, int n_ops, bool mpi,
+                    bool &fits) {
+  int widest = 0, largest_group = 0;
+  for (int g = 0; g < gp.groups; ++g) {
+    int total = 0;
+    for (int i = gp.group_begin[g]; i < gp.group_begin[g + 1]; ++i) {
+      if ((gp.recs[i].w[0] & 0xff) == fr::kRecSentinelLevel) continue;
+      const int need = gp.recs[i].w[6] * n_ops;
+      widest = std::max(widest, need);
+      total += need;
+    }
+    largest_group = std::max(largest_group, total);
+  }
+  const size_t budget = 38 * 1024;
+  int W = 64;
+  while (W < 1024 && W < largest_group &&
+         other_lds_bytes + fr::feat_window_bytes(2 * W, mpi) <= budget)
+    W *= 2;
+  if (W < widest) W = (widest + 1) / 2 * 2;
+  if (other_lds_bytes + fr::feat_window_bytes(W, mpi) > 160 * 1024) return 0;
+  fits = largest_group <= W;
+  return W;
+}
+
 // Resident workgroups of the cooperative walk kernel instance that (plan, T, fused,
 // vec_ok) selects: a dry run of the launcher (nothing is enqueued).
 int64_t query_resident(const fr::Plan &p, int64_t N, int64_t T, bool fused, bool vec_ok) {
@@ -242,6 +270,7 @@ int64_t query_resident(const fr::Plan &p, int64_t N, int64_t T, bool fused, bool
   a.carry_slots = carry_slots_for(p, 1);
   a.carry_in_lds = carries_fit_lds(p, T, 1) ? 1 : 0;
   a.feats = fused ? dummy : nullptr;
+  a.feat_window = fused ? 128 : 0;   // (the launch's own window may differ a little)
   a.resident_out = &resident;
   if (fr::launch_iss_walk(a, p.levels, nullptr) != hipSuccess) {
     (void)hipGetLastError();
@@ -624,6 +653,7 @@ struct FusedArgs {          // non-null feats selects the fused sieve kernels
   double *feats = nullptr, *cnt = nullptr;
   int64_t feat_stride = 0;
   int32_t n_ops = 0, n_ops_padded = 0;
+  bool has_mpi = false;     // cnt is a population table of its own
   const int32_t *series_cuts = nullptr;   // device (N, cut_slots) per-series boundaries
   int32_t cut_slots = 0;
   bool total_inc = false;   // a differencing sieve on a totally weighted plan
@@ -699,6 +729,12 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
       a.n_ops_padded = fu->n_ops_padded;
       a.series_cuts = fu->series_cuts;
       a.cut_slots = fu->cut_slots;
+      // feature window of the cooperative kernel: the ops of the unit's one output row
+      a.has_mpi = fu->has_mpi ? 1 : 0;
+      a.feat_window = (fu->n_ops + 1) / 2 * 2;
+      a.feat_fits = 1;
+      if (a.feat_window > 4096)
+        return fail(FR_E_LIMIT, w + ": too many sieve features per iterated sum for the fused launch");
     }
     // one short-lived workgroup per (series, word, frequency) unit: 0-2.5 % faster than a
     // persistent grid (exponent 2: 1515 -> 1478 us)
@@ -879,6 +915,17 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     a.series_cuts = fu->series_cuts;
     a.cut_slots = fu->cut_slots;
     a.total_inc = (fu->total_inc && p.weighting == FR_W_TOTAL) ? 1 : 0;
+    a.has_mpi = fu->has_mpi ? 1 : 0;
+    if (!packed) {
+      const int64_t chunk = fr::walk_chunk_elems(T);
+      const size_t other = ((size_t)a.R * chunk + 16 + (a.carry_in_lds && T > chunk ? a.carry_slots : 0)) * 8;
+      bool fits = false;
+      a.feat_window = feat_window_for(gp, other, fu->n_ops, fu->has_mpi, fits);
+      a.feat_fits = fits ? 1 : 0;
+      if (a.feat_window == 0)
+        return fail(FR_E_LIMIT, w + ": the features of one node (output rows x sieve features) "
+                                    "do not fit the LDS - split the word list");
+    }
     if (fu->prep) {
       if (packed || wave_rows)
         return fail(FR_E_LIMIT, w + ": the fused preparation needs the cooperative kernel");
@@ -1248,11 +1295,11 @@ int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, 
                               std::to_string(D_words));
   if (p.weighting != 0 && !p.cos && (!d_lookup || (lookup_rows != 1 && lookup_rows != N)))
     return fail(FR_E_ARG, "fr_pipeline_run: weighted plan needs a lookup of 1 or N rows");
-  // features accumulate with atomics: clear them (memset nodes, graph-capturable)
-  HIP_TRY(hipMemset2DAsync(d_feats, (size_t)feat_stride * 8, 0, (size_t)F * 8, (size_t)N, st));
+  // (every feature column - and population entry - is written exactly once by the unit that
+  // owns it: nothing to clear)
   if (!pl->mpi_cols.empty()) {
     fu.cnt = reinterpret_cast<double *>(static_cast<char *>(d_work) + plan_ws);
-    HIP_TRY(hipMemsetAsync(fu.cnt, 0, (size_t)N * F * 8, st));
+    fu.has_mpi = true;
   } else {
     fu.cnt = d_feats;  // never touched without MPI sieves
   }

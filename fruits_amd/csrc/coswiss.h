@@ -303,6 +303,20 @@ __global__ __launch_bounds__(kWalkThreads) void coswiss_kernel(const IssArgs a) 
   cx.buf = 0;
   cx.tail_buf = 0;
   cx.pc_begin = 0;
+  if constexpr (C::MODE == 1) {
+    // feature window (walk_device.h, feat_flush): the features of the unit's ONE output row,
+    // kept over its time chunks and flushed behind the last one
+    double *fw = cx.carry + (kCosMaxLetters * (S + 1) + 8);
+    cx.fl_val = (lds_f64 *)fw;
+    cx.fl_cnt = (lds_f64 *)(fw + a.feat_window);
+    cx.fl_col = (lds_i32 *)(fw + (a.has_mpi ? 2 : 1) * a.feat_window);
+    for (int sl = tid; sl < a.feat_window; sl += kWalkThreads) {
+      cx.fl_val[sl] = 0.0;
+      if (a.has_mpi) cx.fl_cnt[sl] = 0.0;
+    }
+    cx.fslot = 0;
+    cx.fused_used = 0;
+  }
   const int64_t per_series = (int64_t)a.cw_W * a.cw_F;
   const int64_t units = a.N * per_series;
   for (int64_t u = blockIdx.x; u < units; u += gridDim.x) {
@@ -325,6 +339,10 @@ __global__ __launch_bounds__(kWalkThreads) void coswiss_kernel(const IssArgs a) 
       coswiss_unit<C, S>(cx, a.X + (int64_t)j * a.cw_x_unit_stride + n * a.D * a.T + t0,
                          a.aux + (int64_t)f * 2 * a.T + t0, lb, le, a.cw_total != 0, j, tot_all,
                          a.cw_mask ? a.cw_mask + (int64_t)j * a.cw_Lmax * a.T + t0 : nullptr);
+    }
+    if constexpr (C::MODE == 1) {
+      cx.fused_used = a.n_ops;
+      feat_flush<C>(cx, false);
     }
   }
 }
@@ -396,7 +414,8 @@ static hipError_t launch_coswiss_cfg(const IssArgs &a, hipStream_t st) {
   // the S+1 scans of a letter already overlap their DPP latencies)
   using C = WalkCfg<(P == 2 ? 4 : 2), (P == 2 ? 1 : P), 1, MULTI, VEC, false, 4, MODE, 0>;
   const size_t lds = (2 * C::NW * (S + 1) + 4 * C::NW + (kCosMaxLetters * (S + 1) + 8)) *
-                     sizeof(double);
+                         sizeof(double) +
+                     (MODE == 1 ? feat_window_bytes(a.feat_window, a.has_mpi != 0) : 0);
   const int64_t units = a.N * a.cw_W * a.cw_F;
   static LaunchCache cache;  // per instantiation; per-device entries, thread-safe
   int per_cu = 1;

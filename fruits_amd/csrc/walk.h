@@ -14,9 +14,12 @@ template <int E, int P, int LV, int MULTI, bool VEC, bool W, int TEAM = 4, int M
           int SEMI = 0, bool NT = false, bool TI = false>
 static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
   using C = WalkCfg<E, P, LV, MULTI, VEC, W, TEAM, MODE, SEMI, NT, TI>;
+  // rows, wave totals, LDS carries, then (fused, cooperative) the feature window: value,
+  // population (MPI) and column of every slot
   const size_t lds = ((size_t)a.R * C::CHUNK + 2 * C::NW + 2 * C::NW +
                       (MULTI == 1 ? a.carry_slots : 0)) *
-                     sizeof(double);
+                         sizeof(double) +
+                     ((MODE == 1 && TEAM != 1) ? feat_window_bytes(a.feat_window, a.has_mpi != 0) : 0);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static LaunchCache cache;  // per instantiation; per-device entries, thread-safe
   int per_cu = 1;

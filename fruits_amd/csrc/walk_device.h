@@ -91,6 +91,14 @@ struct WalkCtx {
   double *out_base;     // out + n*out_n_stride + t0
   double *feat_row;     // MODE 1: feats + n*feat_stride
   double *cnt_row;      // MODE 1: band population of MPI features
+  // MODE 1, cooperative kernels: the features of a unit accumulate in an LDS window (value,
+  // MPI population, column of every slot) and leave with plain stores (feat_flush); a unit
+  // owns its feature columns, so nothing in global memory is ever added to atomically
+  lds_f64 *fl_val;
+  lds_f64 *fl_cnt;
+  lds_i32 *fl_col;
+  int fslot;            // first window slot of the node being processed
+  int fused_used;       // slots of the window in use
   const int32_t *cut_row;  // MODE 1: this series' row of IssArgs::series_cuts (or nullptr)
   int64_t series;          // MODE 1: index of the series being walked
   double *carry;        // carry slots of this series (multi-chunk; LDS or global) or nullptr
@@ -482,7 +490,7 @@ struct FusedScratch {
 // two parallel-scan values is +-1 ulp of noise - which "number of positive increments"
 // (NPI with its default q = (0, 1)) would count at random.
 template <class C>
-__device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w,
+__device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w, int slot,
                                          const double (&c)[C::EP], const double (&x)[C::EP],
                                          const double (&s)[C::EP], bool seq_steps,
                                          FusedScratch<C::EP> &sc) {
@@ -490,6 +498,10 @@ __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w,
   const int kind = w[0] & 0xff, inc = (int)(int8_t)((w[0] >> 8) & 0xff), col = w[1];   // inc: signed
   // per-series cuts (coquantile positions): lo / hi name slots of the series' cut row
   const bool series_cuts = (w[0] >> 16) & 1;
+  if constexpr (C::TEAM != 1) {
+    // (the flush needs the column of every slot, also of one no lane adds to)
+    if (cx.wave == 0 && cx.lane == 0) cx.fl_col[slot] = col;
+  }
   if (kind == FR_SIEVE_END_K) {
     int pick = w[2];                    // index of the value to pick
     if (series_cuts) {                  // X[:, cut - 1], index -1 wrapping like numpy
@@ -500,16 +512,22 @@ __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w,
     if (rel >= 0 && rel < C::CHUNK) {
       const int wv = rel / C::SPAN;
       if (cx.wave == wv) {
-        // every lane compares the positions of its own elements (static register
-        // indices: a computed index into c[] would send the array through scratch).
-        // An add onto the zero-initialised feature, so that this buffer only ever sees
-        // atomics: a plain store here would make the compiler drain vmcnt first.
-        const int in = rel - wv * C::SPAN - cx.lane * E;
+        // the position is uniform: pick the register with uniform selects (static register
+        // indices: a computed index into c[] would send the array through scratch), then ONE
+        // lane stores it
+        const int r = rel - wv * C::SPAN;
+        const int hu = r / C::PIECE, q = r - hu * C::PIECE;
+        const int owner = q / E, eu = q - owner * E;
+        double v = c[0];
 #pragma unroll
         for (int h = 0; h < P; ++h)
 #pragma unroll
           for (int e = 0; e < E; ++e)
-            if (in == h * C::PIECE + e) unsafeAtomicAdd(&cx.feat_row[col], c[h * E + e]);
+            if (h * E + e > 0 && hu == h && eu == e) v = c[h * E + e];
+        if (cx.lane == owner) {
+          if constexpr (C::TEAM != 1) cx.fl_val[slot] = v;
+          else cx.feat_row[col] = v;
+        }
       }
     }
     return;
@@ -587,16 +605,61 @@ __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w,
       cnt += __popcll(__ballot(in));
       if (kind == FR_SIEVE_MPI_K) sum += in ? v : 0.0;
     }
-  if (cnt == 0) return;
-  if (kind == FR_SIEVE_MPI_K) {
+  // every op leaves its result, zero counts included: every feature column is written exactly
+  // once per series and the feature tensor needs no clearing
+  if (kind == FR_SIEVE_MPI_K)
     sum = wave_last_lane(wave_inclusive_scan<0>(sum));  // wave total by DPP (no LDS permutes)
-    if (cx.lane == 0) {
-      unsafeAtomicAdd(&cx.feat_row[col], sum);
-      unsafeAtomicAdd(&cx.cnt_row[col], (double)cnt);
+  if (cx.lane == 0) {
+    if constexpr (C::TEAM != 1) {
+      // one LDS add per wave (ds_add_f64, nothing returned)
+      if (kind == FR_SIEVE_MPI_K) {
+        lds_add(cx.fl_val + slot, sum);
+        lds_add(cx.fl_cnt + slot, (double)cnt);
+      } else {
+        lds_add(cx.fl_val + slot, (double)cnt);
+      }
+    } else {
+      // wave-per-unit kernels: the wave holds the whole (single-chunk) row
+      if (kind == FR_SIEVE_MPI_K) {
+        cx.feat_row[col] = sum;
+        cx.cnt_row[col] = (double)cnt;
+      } else {
+        cx.feat_row[col] = (double)cnt;
+      }
     }
-  } else if (cx.lane == 0) {
-    unsafeAtomicAdd(&cx.feat_row[col], (double)cnt);
   }
+}
+
+// Flushes the LDS feature window of a cooperative kernel: slot s -> column fl_col[s] of the
+// series' feature row with plain stores (`add`: onto what earlier time chunks of the unit left
+// there - the unit owns its columns, so a plain read-modify-write by the thread that wrote them),
+// and clears the window.  The next adds come behind the next node's scan barrier.
+template <class C>
+__device__ __forceinline__ void feat_flush(WalkCtx &cx, bool add) {
+  lds_barrier();   // the adds of every wave are in
+  const bool mpi = cx.a->has_mpi != 0;
+  for (int sl = cx.tid; sl < cx.fused_used; sl += kWalkThreads) {
+    const int col = cx.fl_col[sl];
+    double v = cx.fl_val[sl];
+    if (add) v = cx.feat_row[col] + v;
+    cx.feat_row[col] = v;
+    cx.fl_val[sl] = 0.0;
+    if (mpi) {
+      double n = cx.fl_cnt[sl];
+      if (add) n = cx.cnt_row[col] + n;
+      cx.cnt_row[col] = n;
+      cx.fl_cnt[sl] = 0.0;
+    }
+  }
+  cx.fused_used = 0;
+}
+
+// Window slots of the next node (`need` = output rows x feature ops); a full window leaves first.
+template <class C>
+__device__ __forceinline__ void feat_reserve(WalkCtx &cx, int need) {
+  if (!cx.a->feat_fits && cx.fused_used + need > cx.a->feat_window) feat_flush<C>(cx, !cx.first_chunk);
+  cx.fslot = cx.fused_used;
+  cx.fused_used += need;
 }
 
 template <class C>
@@ -608,15 +671,17 @@ __device__ __forceinline__ void fused_all(WalkCtx &cx, const Rec &nd, const Ops2
   int64_t k = nd.w[7];
   Ops2 o = pre;  // ops 0-1 of the first row were requested at the start of the node
   FusedScratch<C::EP> sc;
+  int slot = cx.fslot;   // window slot of (output row j, op i): fslot + j * n + i
   for (int j = 0;;) {
     for (int i = 0;;) {
-      fused_op<C>(cx, o.w, c, x, s, seq_steps, sc);
-      if (i + 1 < n) fused_op<C>(cx, o.w + 8, c, x, s, seq_steps, sc);
+      fused_op<C>(cx, o.w, slot + i, c, x, s, seq_steps, sc);
+      if (i + 1 < n) fused_op<C>(cx, o.w + 8, slot + i + 1, c, x, s, seq_steps, sc);
       i += 2;
       if (i >= n) break;
       o = load_ops2(a, k, i);
     }
     if (++j >= ne) break;
+    slot += n;
     k = j == 1 ? (int64_t)nd.w[8] : (int64_t)as_const(a.emit_rows)[nd.emit_begin() + j];
     o = load_ops2(a, k, 0);
   }
@@ -775,12 +840,14 @@ __device__ __forceinline__ void walk(WalkCtx &cx, Rec &cur, int &pc,
       cur = load_rec(a.recs, pc);
       double pout[C::EP];
       STAMP(cx, 0);  // interpreter: record decode / prefetch issue
+      if constexpr (C::MODE == 1 && C::TEAM != 1) feat_reserve<C>(cx, nd.emit_count() * a.n_ops);
       process_node<C>(cx, nd, slot, pin, pout);
       while (cur.level() == LV && (cur.flags() & F_CHAIN)) {
         const Rec nc = cur;
         const int slot2 = carry_slot_of<C>(cx, nc, pc);
         ++pc;
         cur = load_rec(a.recs, pc);
+        if constexpr (C::MODE == 1 && C::TEAM != 1) feat_reserve<C>(cx, nc.emit_count() * a.n_ops);
         process_node<C>(cx, nc, slot2, pout, pout);
       }
       if constexpr (LV + 1 < C::MAXLV) {
@@ -808,6 +875,7 @@ __device__ __forceinline__ void walk(WalkCtx &cx, Rec &cur, int &pc,
         for (int i = 0; i < C::EP; ++i) src[i] = pin[i];
       }
       STAMP(cx, 0);  // interpreter: record decode / prefetch issue
+      if constexpr (C::MODE == 1 && C::TEAM != 1) feat_reserve<C>(cx, nd.emit_count() * a.n_ops);
       process_node<C>(cx, nd, slot, src, pout);
       if constexpr (LV + 1 < C::MAXLV) {
         if (cur.level() == LV + 1) walk<C, LV + 1>(cx, cur, pc, pout);
@@ -1052,6 +1120,20 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
   cx.tail_buf = 0;
   double *rows_w = lds;
   bool first_unit = true;
+  if constexpr (C::MODE == 1 && C::TEAM != 1) {
+    // feature window behind the rows, the wave totals and the LDS carries: values,
+    // populations, columns; cleared here and by every flush
+    double *fw = lds + (int64_t)a.R * C::CHUNK + 4 * C::NW + (C::MULTI == 1 ? a.carry_slots : 0);
+    cx.fl_val = (lds_f64 *)fw;
+    cx.fl_cnt = (lds_f64 *)(fw + a.feat_window);
+    cx.fl_col = (lds_i32 *)(fw + (a.has_mpi ? 2 : 1) * a.feat_window);
+    for (int sl = tid; sl < a.feat_window; sl += kWalkThreads) {
+      cx.fl_val[sl] = 0.0;
+      if (a.has_mpi) cx.fl_cnt[sl] = 0.0;
+    }
+    cx.fused_used = 0;
+    cx.fslot = 0;
+  }
 #ifdef FRUITS_HIP_TIMING_BUILD
   if (a.debug & 4) return;
   for (int i = 0; i < 8; ++i) cx.seg[i] = 0;
@@ -1217,7 +1299,13 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
       for (int i = 0; i < C::EP; ++i) ones[i] = C::SEMI != 1 ? 1.0 : 0.0;
       int pc = node_begin;
       Rec cur = load_rec(a.recs, pc);
+      if constexpr (C::MODE == 1 && C::TEAM != 1) cx.fused_used = 0;  // same slots in every chunk
       walk<C, 0>(cx, cur, pc, ones);
+      if constexpr (C::MODE == 1 && C::TEAM != 1) {
+        // a unit whose features fit the window keeps them there over its time chunks; else
+        // every chunk leaves its share (added onto the earlier chunks' in global memory)
+        if (!a.feat_fits || chunk + 1 == a.nchunks) feat_flush<C>(cx, !a.feat_fits && chunk > 0);
+      }
     }
     first_unit = false;
   }

@@ -20,6 +20,14 @@ __device__ __forceinline__ cptr<T> as_const(const T *p) {
   return (cptr<T>)(p);
 }
 
+// Pointers the compiler KNOWS to be LDS: an add through one is a ds_add_f64 (no return value,
+// counted by lgkmcnt), through a generic pointer it would be a flat atomic.
+typedef double __attribute__((address_space(3))) lds_f64;
+typedef int __attribute__((address_space(3))) lds_i32;
+__device__ __forceinline__ void lds_add(lds_f64 *p, double v) {
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // ---------------------------------------------------------------- wave scan
 // The scan is written for both semirings: SEMI 0 = Reals (the "sum" is +, identity
 // 0.0), SEMI 1 = Arctic and SEMI 2 = Bayesian (the "sum" is max, identity -inf).

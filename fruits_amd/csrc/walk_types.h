@@ -59,6 +59,12 @@ constexpr int kStaticMaxNodes = 32;
 
 constexpr int kWalkThreads = 256;
 
+// LDS bytes of a feature window of `slots` slots (8-byte value, 8-byte population with MPI
+// sieves, 4-byte column; slots even)
+constexpr uint64_t feat_window_bytes(int slots, bool mpi) {
+  return (uint64_t)slots * (mpi ? 20u : 12u);
+}
+
 constexpr int FR_SIEVE_NPI_K = 0;
 constexpr int FR_SIEVE_MPI_K = 1;
 constexpr int FR_SIEVE_END_K = 2;
@@ -104,10 +110,14 @@ struct IssArgs {
   int32_t wave_rows;        // TEAM = 1 kernel: one wave per row, 4 groups per workgroup
   // fused sieve epilogue (MODE 1 kernels): features instead of the (K,N,T) tensor
   const FeatOp *ops;        // (K, n_ops_padded) feature ops per output row, 64-byte aligned rows
-  double *feats;            // (N, feat_stride) zero-initialised features
+  double *feats;            // (N, feat_stride) features; every column is written, none is read first
   double *cnt;              // same shape: band population of MPI features
   int64_t feat_stride;
   int32_t n_ops, n_ops_padded;
+  // LDS feature window of the cooperative kernels (walk_device.h, feat_flush): slots of
+  // {value, population (has_mpi), column}; feat_fits: every group's features fit the window,
+  // so a unit flushes once, after its last time chunk
+  int32_t feat_window, feat_fits, has_mpi;
   // per-series segment boundaries (coquantile cuts, fruits/sieving/segment.py:51-64): (N,
   // cut_slots) int32 in [0, T], the rows of every such sieve sorted; nullptr: none
   const int32_t *series_cuts;
