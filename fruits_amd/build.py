@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libfruits_hip.so")
-HEADERS = ["kernels.h", "plan.h", "jit.h", "walk.h", "walk_device.h", "walk_types.h", "walk_scan.h", "coswiss.h", "walk_packed.h",
+HEADERS = ["kernels.h", "plan.h", "jit.h", "walk.h", "walk_device.h", "walk_fused.h", "walk_types.h", "walk_scan.h", "coswiss.h", "walk_packed.h",
            "launch_cache.h", "static_programs.h",
            os.path.join("..", "..", "include", "fruits_hip.h")]
 

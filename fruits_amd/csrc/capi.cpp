@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -268,7 +269,7 @@ int64_t query_resident(const fr::Plan &p, int64_t N, int64_t T, bool fused, bool
   a.persistent = 1;
   a.semiring = p.semiring;
   a.carry_slots = carry_slots_for(p, 1);
-  a.carry_in_lds = carries_fit_lds(p, T, 1) ? 1 : 0;
+  a.carry_in_lds = (fused || carries_fit_lds(p, T, 1)) ? 1 : 0;   // (the fused walk: always)
   a.feats = fused ? dummy : nullptr;
   a.feat_window = fused ? 128 : 0;   // (the launch's own window may differ a little)
   a.resident_out = &resident;
@@ -905,6 +906,13 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   a.xcd_map = (a.G > 1 && N % 8 == 0) ? 1 : 0;
   a.carry_slots = carry_slots_for(p, gp.groups);
   a.carry_in_lds = carries_fit_lds(p, T, gp.groups) ? 1 : 0;
+  if (fu && !packed) {
+    // the fused walk keeps its chunk carries in LDS, three slots per record of the largest group
+    int most = 0;
+    for (int g = 0; g < gp.groups; ++g) most = std::max(most, gp.group_begin[g + 1] - gp.group_begin[g]);
+    a.carry_slots = 3 * most;
+    a.carry_in_lds = 1;
+  }
   if (fu) {
     a.ops = fu->ops;
     a.feats = fu->feats;
@@ -918,13 +926,15 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     a.has_mpi = fu->has_mpi ? 1 : 0;
     if (!packed) {
       const int64_t chunk = fr::walk_chunk_elems(T);
-      const size_t other = ((size_t)a.R * chunk + 16 + (a.carry_in_lds && T > chunk ? a.carry_slots : 0)) * 8;
+      const size_t other = ((size_t)a.R * chunk + 24 + (T > chunk ? a.carry_slots : 0)) * 8;
       bool fits = false;
       a.feat_window = feat_window_for(gp, other, fu->n_ops, fu->has_mpi, fits);
       a.feat_fits = fits ? 1 : 0;
       if (a.feat_window == 0)
-        return fail(FR_E_LIMIT, w + ": the features of one node (output rows x sieve features) "
-                                    "do not fit the LDS - split the word list");
+        return fail(FR_E_LIMIT, w + ": the chunk carries and the features of one node (output rows "
+                                    "x sieve features) do not fit the LDS - split the word list");
+      if (p.letter_sum)
+        return fail(FR_E_LIMIT, w + ": letter-sum (argmax) plans have no fused walk");
     }
     if (fu->prep) {
       if (packed || wave_rows)
@@ -1123,10 +1133,17 @@ int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
         }
         const double *q = h_quant + (size_t)k * pl->q_stride + sv.q_off;
         for (int j = 0; j < C; ++j)
-          for (int b = 0; b + 1 < sv.Q1; ++b)
-            row.push_back(fr::FeatOp{sv.kind | ((sv.inc & 0xff) << 8) | (sv.series_cuts ? (1 << 16) : 0),
+          for (int b = 0; b + 1 < sv.Q1; ++b) {
+            // what the epilogue may skip (walk_fused.h, OPF_*): the range test of a band over
+            // the whole series, the comparison with an infinite threshold
+            int32_t flags = sv.series_cuts ? (1 << 16) : 0;
+            if (!sv.series_cuts && sv.cuts[j] <= 0 && sv.cuts[j + 1] >= pl->T) flags |= 1 << 17;
+            if (q[b + 1] == std::numeric_limits<double>::infinity()) flags |= 1 << 18;
+            if (q[b] == -std::numeric_limits<double>::infinity()) flags |= 1 << 19;
+            row.push_back(fr::FeatOp{sv.kind | ((sv.inc & 0xff) << 8) | flags,
                                      k * pl->per_sum + sv.col + j * (sv.Q1 - 1) + b, sv.cuts[j],
                                      sv.cuts[j + 1], q[b], q[b + 1]});
+          }
       }
       std::vector<int32_t> row_pairs;
       std::vector<char> drop(row.size(), 0), used(row.size(), 0);

@@ -338,7 +338,8 @@ GroupedProgram &grouped(Plan &p, int G) {
         for (int j = 0; j < nd.fac_count; ++j)
           if (p.multiplicative() && (p.factors[nd.fac_begin + j] & FAC_DIV)) slow = true;
         r.w[0] = (nd.level & 0xff) | (((nd.flags | (slow ? F_SLOW : 0)) & 0xff) << 8);
-        r.w[1] = nd.fac_count;
+        // (the first half of a record serves a multiply-only node alone: walk_fused.h)
+        r.w[1] = (nd.fac_count & 0xffff) | ((nd.z_mul + 1) << 16) | ((nd.emit_mul + 1) << 24);
         for (int j = 0; j < kRecInlineFactors && j < nd.fac_count; ++j)
           r.w[2 + j] = p.multiplicative() ? (p.factors[nd.fac_begin + j] & FAC_ROW_MASK)
                                                 : p.factors[nd.fac_begin + j];
@@ -373,11 +374,11 @@ static bool schedule_group(const NodeRec *recs, int n, int R, bool prefetch,
   for (int i = 0; i < n; ++i) {
     const NodeRec &r = recs[i];
     const int lv = r.w[0] & 0xff, fl = r.w[0] >> 8;
-    if ((fl & F_SLOW) || r.w[1] > kRecInlineFactors || lv >= kMaxLevels) return false;
+    if ((fl & F_SLOW) || (r.w[1] & 0xffff) > kRecInlineFactors || lv >= kMaxLevels) return false;
     parent[i] = (fl & F_CHAIN) ? last_at[lv] : (lv > 0 ? last_at[lv - 1] : -1);
     last_at[lv] = i;
     if (parent[i] >= 0) ++pending[parent[i]];
-    for (int j = 0; j < r.w[1]; ++j) need[i] |= 1 << (r.w[2 + j] & FAC_ROW_MASK);
+    for (int j = 0; j < (r.w[1] & 0xffff); ++j) need[i] |= 1 << (r.w[2 + j] & FAC_ROW_MASK);
     need_all |= need[i];
   }
   need_mask = need_all;

@@ -6,6 +6,7 @@
 #include "kernels.h"
 #include "launch_cache.h"
 #include "walk_device.h"
+#include "walk_fused.h"
 
 namespace fr {
 
@@ -46,6 +47,30 @@ static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
   }
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(iss_walk_kernel<C>, dim3((unsigned)blocks), dim3(kWalkThreads), lds, st, a);
+  return hipGetLastError();
+}
+
+// launch of the fused walk (walk_fused.h): one workgroup per (series, group) unit
+template <int E, int LV, int MULTI, bool W, int SEMI = 0, bool TI = false>
+static hipError_t launch_fused_cfg(const IssArgs &a, hipStream_t st) {
+  using C = WalkCfg<E, 1, LV, MULTI, true, W, 4, 1, SEMI, false, TI>;
+  const size_t lds = ((size_t)a.R * C::CHUNK + 16 + 8 + (MULTI == 1 ? a.carry_slots : 0)) * sizeof(double) +
+                     feat_window_bytes(a.feat_window, a.has_mpi != 0);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static LaunchCache cache;  // per instantiation; per-device entries, thread-safe
+  int per_cu = 1;
+  hipError_t e = cache.facts(iss_fused_kernel<C>, kWalkThreads, lds,
+                             a.resident_out != nullptr ? &per_cu : nullptr);
+  if (e != hipSuccess) return e;
+  if (a.resident_out != nullptr) {  // the host only asks how many workgroups are resident
+    int64_t resident = (int64_t)per_cu * device_cu_count();
+    resident -= resident % 8;
+    *a.resident_out = (int32_t)(resident < 8 ? 8 : resident);
+    return hipSuccess;
+  }
+  const int64_t units = a.N * a.G;
+  if (units > 0x7fffffffLL) return hipErrorInvalidValue;  // unit indices are 32-bit in the kernel
+  hipLaunchKernelGGL(iss_fused_kernel<C>, dim3((unsigned)units), dim3(kWalkThreads), lds, st, a);
   return hipGetLastError();
 }
 

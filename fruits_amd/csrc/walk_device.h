@@ -302,7 +302,7 @@ struct Rec {
   int32_t w[16];
   __device__ __forceinline__ int level() const { return w[0] & 0xff; }
   __device__ __forceinline__ int flags() const { return w[0] >> 8; }
-  __device__ __forceinline__ int fac_count() const { return w[1]; }
+  __device__ __forceinline__ int fac_count() const { return w[1] & 0xffff; }
   __device__ __forceinline__ int emit_count() const { return w[6]; }
   __device__ __forceinline__ int node_id() const { return w[9]; }
   __device__ __forceinline__ int emit_mul() const { return w[10]; }

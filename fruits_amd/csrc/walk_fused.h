@@ -1,0 +1,591 @@
+// The fused walk: INC -> ISS -> NPI / MPI / END as ONE launch (what FruitSlice.transform runs,
+// fruits/fruit.py:538-550 - K x |sieves| Python calls over a materialised (K,N,T) tensor there).
+//
+// Same plan, records and arithmetic as the materialising walk (walk_device.h); what differs is
+// the shape of the code.  These kernels write almost nothing, so they are bound by instruction
+// issue, and the interpreter that serves the materialising walk well spent as many scalar as
+// vector instructions per node here (and 100-500 SGPR spills).  This kernel is written for
+// the fused case alone:
+//   * one short-lived workgroup per (series, group) unit, no persistent loop;
+//   * the first 8 dwords of a record hold everything a node of a multiply-only letter needs
+//     (the rest is fetched on demand), so two records in flight cost 16 SGPRs, not 32;
+//   * ONE node body for every register level (the interpreter's recursion over levels copies
+//     it once per level): frames are indexed through two small uniform switches, one around
+//     the first factor's multiply, one around the hand-over to the children;
+//   * the cross-wave step of a scan reads a zero-padded WINDOW of the wave totals
+//     (wave w reads slots w .. w+2 of {Z, Z, Z, t0, t1, t2, t3}), so the exclusive prefix of
+//     the totals is two adds for every wave and no select; lane 63 publishes its wave's
+//     total straight from the scan register (no readlane / broadcast);
+//   * feature ops carry host-resolved flags (whole series, one-sided band), the epilogue
+//     takes the short path for them;
+//   * features accumulate in the LDS window of walk_device.h (feat_flush) and leave with
+//     plain stores.
+// Results are bit-identical to the interpreter's (same association everywhere).
+#pragma once
+#include "walk_device.h"
+
+namespace fr {
+
+// feature-op flags (FeatOp::kind_inc), resolved by the host (capi.cpp, fr_pipeline_set_quantiles)
+constexpr int32_t OPF_SERIES_CUTS = 1 << 16;
+constexpr int32_t OPF_FULL_RANGE = 1 << 17;   // lo <= 0 and hi >= T: every element of the series
+constexpr int32_t OPF_NO_HI = 1 << 18;        // qhi = +inf
+constexpr int32_t OPF_NO_LO = 1 << 19;        // qlo = -inf
+
+// the first half of a NodeRec (w[0..7]): level | flags, factor count | weights, four inline
+// factors, emit count, first output row
+struct Rec8 {
+  int32_t w[8];
+  __device__ __forceinline__ int level() const { return w[0] & 0xff; }
+  __device__ __forceinline__ int flags() const { return w[0] >> 8; }
+  __device__ __forceinline__ int fac_count() const { return w[1] & 0xffff; }
+  __device__ __forceinline__ int z_mul() const { return ((w[1] >> 16) & 0xff) - 1; }
+  __device__ __forceinline__ int emit_mul() const { return ((w[1] >> 24) & 0xff) - 1; }
+  __device__ __forceinline__ int emit_count() const { return w[6]; }
+};
+
+__device__ __forceinline__ Rec8 load_rec8(const NodeRec *recs, int pc) {
+  cptr<int32_t> q = as_const(reinterpret_cast<const int32_t *>(
+      __builtin_assume_aligned(recs + pc, 64)));
+  Rec8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.w[i] = q[i];
+  return r;
+}
+
+// a field of the second half of record pc (second output row, factor / emit table offsets)
+__device__ __forceinline__ int rec_field(const NodeRec *recs, int pc, int i) {
+  return as_const(reinterpret_cast<const int32_t *>(recs + pc))[i];
+}
+
+// s = src (x) factor: the first factor of a letter reads the prefix it continues
+template <class C>
+__device__ __forceinline__ void mul_row_from(const WalkCtx &cx, int code, const double (&src)[C::EP],
+                                             double (&s)[C::EP]) {
+  double v[C::EP];
+  read_row<C>(cx, code & FAC_ROW_MASK, v);
+  if constexpr (C::SEMI != 1) {
+#pragma unroll
+    for (int i = 0; i < C::EP; ++i) s[i] = src[i] * v[i];
+  } else {
+#pragma clang fp contract(off)  // the product must round before the add (no FMA)
+    const double el = (double)(int)(int8_t)((code >> 8) & 0xff);
+#pragma unroll
+    for (int i = 0; i < C::EP; ++i) {
+      const double prod = el * v[i];
+      s[i] = src[i] + prod;
+    }
+  }
+}
+
+// Inclusive scan of one chunk row over the workgroup (P = 1: lane l holds E consecutive
+// elements, wave w the span [w * 64 E, (w + 1) * 64 E)).  Same sums in the same order as
+// block_scan; the cross-wave step reads the totals window (see the file comment).
+// WINDOW = false: the identity slots hold another semiring's zero (the plain sums of a max-plus
+// plan's cumulated rows, inc < 0) - select instead.
+template <class C, bool WINDOW = true>
+__device__ __forceinline__ void fscan(WalkCtx &cx, const double (&s)[C::EP], double (&c)[C::EP],
+                                      double (&x)[C::EP], int carry_slot) {
+  static_assert(C::P == 1 && C::NW == 4, "fused kernels: one piece per wave, four waves");
+  constexpr int E = C::E;
+  double l[E];
+  l[0] = s[0];
+#pragma unroll
+  for (int e = 1; e < E; ++e) l[e] = semi_add<C::SEMI>(l[e - 1], s[e]);
+  const double incl = wave_inclusive_scan<C::SEMI>(l[E - 1]);
+  const double excl = wave_shift_right1<C::SEMI>(incl);
+  double carry_in = semi_zero<C::SEMI>();
+  if constexpr (C::MULTI != 0) {
+    if (!cx.first_chunk) carry_in = cx.carry[carry_slot];
+  }
+  double *tw = cx.tot + cx.buf * 8;   // {Z, Z, Z, t0, t1, t2, t3, -}
+  if (cx.lane == 63) tw[3 + cx.wave] = incl;
+  lds_barrier();
+  double base;
+  if constexpr (WINDOW) {
+    const double a0 = tw[cx.wave], a1 = tw[cx.wave + 1], a2 = tw[cx.wave + 2];
+    base = semi_add<C::SEMI>(semi_add<C::SEMI>(a0, a1), a2);
+  } else {
+    const double t0 = tw[3], t1 = tw[4], t2 = tw[5];
+    const double p2 = semi_add<C::SEMI>(t0, t1), p3 = semi_add<C::SEMI>(p2, t2);
+    base = cx.wave == 0 ? semi_zero<C::SEMI>() : (cx.wave == 1 ? t0 : (cx.wave == 2 ? p2 : p3));
+  }
+  cx.buf ^= 1;
+  if constexpr (C::MULTI != 0) {
+    // the carry of earlier chunks: every wave read it before the barrier, the last lane of the
+    // chunk advances it
+    if (cx.wave == 3 && cx.lane == 63)
+      cx.carry[carry_slot] = semi_add<C::SEMI>(carry_in, semi_add<C::SEMI>(base, incl));
+    base = semi_add<C::SEMI>(base, carry_in);
+  }
+  const double off = semi_add<C::SEMI>(base, excl);
+  x[0] = off;
+#pragma unroll
+  for (int e = 0; e + 1 < E; ++e) {
+    c[e] = semi_add<C::SEMI>(off, l[e]);
+    x[e + 1] = c[e];
+  }
+  c[E - 1] = semi_add<C::SEMI>(base, incl);
+}
+
+// c[eu] for a uniform eu: a chain of uniform branches (the empty asm keeps the arms apart: as
+// selects, or as an index, the compiler would send the whole array through scratch memory)
+template <int E, int K>
+__device__ __forceinline__ double pick_uniform(int eu, const double (&c)[E]) {
+  if constexpr (K + 1 >= E) {
+    return c[K];
+  } else {
+    double v;
+    if (eu == K) {
+      v = c[K];
+      asm volatile("" : "+v"(v));
+    } else {
+      v = pick_uniform<E, K + 1>(eu, c);
+    }
+    return v;
+  }
+}
+
+// Band count (and sum) of the differenced values d of one op; the three shapes the host flags
+// are separate straight-line loops.
+template <class C>
+__device__ __forceinline__ void band_count(const WalkCtx &cx, int flags, int lo, int hi, double qlo,
+                                           double qhi, const double (&d)[C::EP], bool want_sum,
+                                           int &cnt, double &sum) {
+  constexpr int E = C::E;
+  const int t_first = (int)cx.t0 + cx.wave * C::SPAN + cx.lane * E;
+  cnt = 0;
+  sum = 0.0;
+  const bool whole = (flags & OPF_FULL_RANGE) && cx.full_chunk;
+  if (whole && (flags & OPF_NO_HI) && !want_sum) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) cnt += __popcll(__ballot(qlo < d[e]));
+  } else if (whole && !want_sum) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) cnt += __popcll(__ballot(qlo < d[e] && d[e] <= qhi));
+  } else {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int t = t_first + e;
+      const double v = d[e];
+      const bool in = t >= lo && t < hi && qlo < v && v <= qhi;
+      cnt += __popcll(__ballot(in));
+      if (want_sum) sum += in ? v : 0.0;
+    }
+  }
+}
+
+template <class C>
+__device__ __forceinline__ void fop(WalkCtx &cx, const int32_t *w, int slot, const double (&c)[C::EP],
+                                    const double (&x)[C::EP], const double (&s)[C::EP],
+                                    bool seq_steps, FusedScratch<C::EP> &sc) {
+  constexpr int E = C::E;
+  const int kind = w[0] & 0xff, inc = (int)(int8_t)((w[0] >> 8) & 0xff), col = w[1];   // inc: signed
+  const bool series_cuts = (w[0] & OPF_SERIES_CUTS) != 0;
+  // (the flush needs the column of every slot, also of one no lane adds to)
+  if (cx.wave == 0 && cx.lane == 0) cx.fl_col[slot] = col;
+  if (kind == FR_SIEVE_END_K) {
+    int pick = w[2];                    // index of the value to pick
+    if (series_cuts) {                  // X[:, cut - 1], index -1 wrapping like numpy
+      pick = as_const(cx.cut_row)[w[2]] - 1;
+      if (pick < 0) pick += (int)cx.a->T;
+    }
+    const int rel = pick - (int)cx.t0;
+    if (rel >= 0 && rel < C::CHUNK) {
+      const int wv = rel / C::SPAN;
+      if (cx.wave == wv) {
+        // the position is uniform: uniform selects of the register, ONE lane stores
+        const int q = rel - wv * C::SPAN;
+        const int owner = q / E, eu = q - owner * E;
+        const double v = pick_uniform<E, 0>(eu, c);
+        if (cx.lane == owner) cx.fl_val[slot] = v;
+      }
+    }
+    return;
+  }
+  int lo = w[2], hi = w[3];
+  if (series_cuts) {
+    lo = as_const(cx.cut_row)[w[2]];
+    hi = as_const(cx.cut_row)[w[3]];
+  }
+  const double qlo = bits_to_double(w[4], w[5]), qhi = bits_to_double(w[6], w[7]);
+  // element 0 of the series: increments are zero-padded there (fruits/cache.py:8-13)
+  const bool at0 = cx.first_chunk && cx.wave == 0 && cx.lane == 0;
+  double d[E];
+  if (inc <= 0) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) d[i] = c[i];
+    if constexpr (C::MULTI == 0) {
+      // inc < 0: the row cumulated -inc times (np.cumsum, fruits/sieving/increment.py:68-70) -
+      // a plain sum whatever the semiring of the plan; one-chunk series only
+      using CR = WalkCfg<C::E, C::P, C::MAXLV, 0, C::VEC, C::WEIGHTED, C::TEAM, C::MODE, 0>;
+      for (int k = inc; k < 0; ++k) {
+        double cs[E], xs[E];
+        fscan<CR, false>(cx, d, cs, xs, 0);
+#pragma unroll
+        for (int i = 0; i < E; ++i) d[i] = cs[i];
+      }
+    }
+  } else {
+    // Reals: fl(x + s) - x, the step a SEQUENTIAL cumsum takes from the same prefix (see
+    // fused_op in walk_device.h)
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      double step = c[i] - x[i];
+      if (C::SEMI == 0 && seq_steps) step = (x[i] + s[i]) - x[i];
+      d[i] = step;
+    }
+    d[0] = at0 ? 0.0 : d[0];
+    if (inc >= 2) {
+      if (!sc.have_dp) {
+        prev_first_differences<C>(cx, d, sc.dp);
+        sc.have_dp = true;
+      }
+#pragma unroll
+      for (int e = 0; e < E; ++e) d[e] = d[e] - sc.dp[e];
+      d[0] = at0 ? 0.0 : d[0];
+      if constexpr (C::MULTI == 0) {
+        // third to eighth differences: one more neighbour exchange per order (one-chunk series)
+        for (int k = 3; k <= inc; ++k) {
+          double dq[E];
+          prev_first_differences<C>(cx, d, dq);
+#pragma unroll
+          for (int e = 0; e < E; ++e) d[e] = d[e] - dq[e];
+          d[0] = at0 ? 0.0 : d[0];
+        }
+      }
+    }
+  }
+  int cnt;
+  double sum;
+  const bool mpi = kind == FR_SIEVE_MPI_K;
+  band_count<C>(cx, w[0], lo, hi, qlo, qhi, d, mpi, cnt, sum);
+  if (mpi) sum = wave_last_lane(wave_inclusive_scan<0>(sum));  // wave total by DPP
+  if (cx.lane == 0) {
+    // one LDS add per wave (ds_add_f64, nothing returned)
+    if (mpi) {
+      lds_add(cx.fl_val + slot, sum);
+      lds_add(cx.fl_cnt + slot, (double)cnt);
+    } else {
+      lds_add(cx.fl_val + slot, (double)cnt);
+    }
+  }
+}
+
+// one feature op (32 bytes = one s_load_dwordx8)
+struct Op1 {
+  int32_t w[8];
+};
+__device__ __forceinline__ Op1 load_op1(const IssArgs &a, int64_t k, int i) {
+  cptr<int32_t> q = as_const(reinterpret_cast<const int32_t *>(
+      __builtin_assume_aligned(a.ops + (k * a.n_ops_padded + i), 32)));
+  Op1 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o.w[j] = q[j];
+  return o;
+}
+
+// The feature ops of every output row of a node: ONE code site for an op, the next op
+// requested while the current one is evaluated.
+template <class C>
+__device__ __forceinline__ void fops_all(WalkCtx &cx, const Rec8 &nd, int pc, const Op1 &pre,
+                                         const double (&c)[C::EP], const double (&x)[C::EP],
+                                         const double (&s)[C::EP], bool seq_steps) {
+  const IssArgs &a = *cx.a;
+  const int ne = nd.emit_count(), n = a.n_ops;
+  int64_t k = nd.w[7];
+  Op1 nx = pre;  // op 0 of the first row was requested at the start of the node
+  FusedScratch<C::EP> sc;
+  int slot = cx.fslot;   // window slot of (output row j, op i): fslot + j * n + i
+  for (int j = 0;;) {
+    for (int i = 0; i < n; ++i) {
+      const Op1 o = nx;
+      if (i + 1 < n) nx = load_op1(a, k, i + 1);
+      fop<C>(cx, o.w, slot + i, c, x, s, seq_steps, sc);
+    }
+    if (++j >= ne) break;
+    slot += n;
+    k = j == 1 ? (int64_t)rec_field(a.recs, pc, 8)
+               : (int64_t)as_const(a.emit_rows)[rec_field(a.recs, pc, 13) + j];
+    nx = load_op1(a, k, 0);
+  }
+}
+
+// Register frames: f[k] holds the prefix the children of the open node of level k continue
+// from.  They are only ever indexed by compile-time constants - the level of a node selects a
+// case of a small switch (deepest level first: that is where most nodes are).
+template <class C, int K>
+__device__ __forceinline__ void frame_mul(const WalkCtx &cx, int rd, int code,
+                                          const double (&f)[C::MAXLV][C::EP], double (&s)[C::EP]) {
+  if constexpr (K < 0) {
+    double ones[C::EP];  // identity of the semiring's product: 1 (Reals, Bayesian), 0 (Arctic)
+#pragma unroll
+    for (int i = 0; i < C::EP; ++i) ones[i] = C::SEMI != 1 ? 1.0 : 0.0;
+    mul_row_from<C>(cx, code, ones, s);
+  } else {
+    if (rd == K) {
+      mul_row_from<C>(cx, code, f[K], s);
+      asm volatile("" ::: "memory");  // (keeps the cases apart: merged, they cost selects)
+    } else {
+      frame_mul<C, K - 1>(cx, rd, code, f, s);
+    }
+  }
+}
+template <class C, int K>
+__device__ __forceinline__ void frame_get(int rd, const double (&f)[C::MAXLV][C::EP], double (&s)[C::EP]) {
+  if constexpr (K < 0) {
+#pragma unroll
+    for (int i = 0; i < C::EP; ++i) s[i] = C::SEMI != 1 ? 1.0 : 0.0;
+  } else {
+    if (rd == K) {
+#pragma unroll
+      for (int i = 0; i < C::EP; ++i) s[i] = f[K][i];
+      asm volatile("" ::: "memory");
+    } else {
+      frame_get<C, K - 1>(rd, f, s);
+    }
+  }
+}
+template <class C, int K>
+__device__ __forceinline__ void frame_put(int lv, double (&f)[C::MAXLV][C::EP], const double (&x)[C::EP]) {
+  if constexpr (K >= 0) {
+    if (lv == K) {
+#pragma unroll
+      for (int i = 0; i < C::EP; ++i) f[K][i] = x[i];
+      asm volatile("" ::: "memory");
+    } else {
+      frame_put<C, K - 1>(lv, f, x);
+    }
+  }
+}
+
+// Walks the records of one group (DFS order, sentinel at the end): per node the letters into
+// the prefix it continues (the frame of the level below; its own level's for an only child,
+// F_CHAIN), the scan, the feature ops, the hand-over to the children.
+template <class C>
+__device__ __forceinline__ void fwalk(WalkCtx &cx, int node_begin) {
+  constexpr int EP = C::EP;
+  const IssArgs &a = *cx.a;
+  double f[C::MAXLV][EP];
+#pragma unroll
+  for (int k = 0; k < C::MAXLV; ++k)
+#pragma unroll
+    for (int i = 0; i < EP; ++i) f[k][i] = 0.0;
+  int pc = node_begin;
+  Rec8 cur = load_rec8(a.recs, pc);
+  while (cur.level() != kRecSentinelLevel) {
+    const Rec8 nd = cur;
+    const int me = pc;
+    const int slot = kCarrySlots * (pc - node_begin);
+    ++pc;
+    cur = load_rec8(a.recs, pc);  // (its latency hides behind this node's vector work)
+    const int ne = nd.emit_count();
+    feat_reserve<C>(cx, ne * a.n_ops);
+    cx.slot = slot;
+    Op1 pre;
+    if (ne > 0) pre = load_op1(a, nd.w[7], 0);
+    const int nf = nd.fac_count(), flags = nd.flags(), lv = nd.level();
+    const int rd = (flags & F_CHAIN) ? lv : lv - 1;
+    double s[EP];
+    if (flags & F_SLOW) {
+      // a reciprocal factor or more than four: the factor table, one factor at a time
+      frame_get<C, C::MAXLV - 1>(rd, f, s);
+      slow_factors<C>(cx, rec_field(a.recs, me, 12), nf, s, s, false);
+    } else {
+      frame_mul<C, C::MAXLV - 1>(cx, rd, nd.w[2], f, s);
+      if (nf > 1) {
+        mul_row<C>(cx, nd.w[3], s);
+        if (nf > 2) mul_row<C>(cx, nd.w[4], s);
+        if (nf > 3) mul_row<C>(cx, nd.w[5], s);
+      }
+    }
+    const bool has_children = (flags & F_CHILDREN) != 0;
+    const int z_mul = nd.z_mul(), emit_mul = nd.emit_mul();
+    const bool need2 = C::WEIGHTED && has_children && z_mul >= 0;
+    const bool need1 = ne > 0 || (has_children && !need2);
+    double hand[EP];   // what the children continue from
+    if (need1) {
+      double c[EP], x[EP];
+      fscan<C>(cx, s, c, x, slot);
+      // Reals: children start from the exclusive shift; Arctic / Bayesian: from the inclusive
+      // maximum (taken before the emitted values are rescaled)
+#pragma unroll
+      for (int i = 0; i < EP; ++i) hand[i] = C::SEMI == 0 ? x[i] : c[i];
+      if (ne > 0) {
+        // total weighting: the sieves see c * exp(-g alpha_k) (Arctic: c - g alpha_k)
+        if (C::WEIGHTED && emit_mul >= 0)
+          mul_row<C>(cx, C::SEMI != 1 ? emit_mul : fac_arctic(emit_mul, -1), c);
+        if constexpr (C::TOTALINC) {
+          if (emit_mul >= 0) {
+            double xs[EP];
+            previous_weighted<C>(cx, emit_mul, x, xs);
+            fops_all<C>(cx, nd, me, pre, c, xs, s, false);
+          } else {
+            fops_all<C>(cx, nd, me, pre, c, x, s, true);
+          }
+        } else {
+          fops_all<C>(cx, nd, me, pre, c, x, s, !(C::WEIGHTED && emit_mul >= 0));
+        }
+      }
+    }
+    if constexpr (C::WEIGHTED) {
+      if (need2) {
+        // non-total weighting: the children continue from the scan of s * exp(+g alpha_k)
+        double c2[EP], x2[EP];
+        mul_row<C>(cx, C::SEMI != 1 ? z_mul : fac_arctic(z_mul, 1), s);
+        fscan<C>(cx, s, c2, x2, slot + 1);
+#pragma unroll
+        for (int i = 0; i < EP; ++i) hand[i] = C::SEMI == 0 ? x2[i] : c2[i];
+      }
+    }
+    if (has_children) frame_put<C, C::MAXLV - 1>(lv, f, hand);
+  }
+}
+
+// Stages the rows of one time chunk of series n into LDS (coalesced 16-byte units, the loads of
+// kStageRows rows in flight before the first LDS write); with a fused preparation the rows are
+// formed from the RAW input on the way (INC / NEW(INC) / STD, see IssArgs::prep).
+template <class C>
+__device__ __forceinline__ void stage_chunk(const WalkCtx &cx, const IssArgs &a, int64_t n, int64_t t0,
+                                            double *rows_w) {
+  const int tid = cx.tid;
+  for (int r0 = 0; r0 < a.R; r0 += kStageRows) {
+    constexpr int U = C::CHUNK / 2 / kWalkThreads;
+    vd2 v[kStageRows][U];
+#pragma unroll
+    for (int rr = 0; rr < kStageRows; ++rr) {
+      if (r0 + rr < a.R) {
+        const int src = as_const(a.row_src)[r0 + rr];
+        if (a.prep != nullptr && src >= 0) {
+          // INC (x[t] - x[t - lag], zero-padded: fruits/cache.py:8-13), NEW(INC) (the prepared
+          // dimension names a raw dimension and a lag) and STD's apply step ((x - mean) /
+          // (std + eps), fruits/preparation/transform.py:141-147; statistics: row_stats_kernel)
+          const int raw = as_const(a.prep)[4 * src], lag = as_const(a.prep)[4 * src + 1];
+          const bool standardise = as_const(a.prep)[4 * src + 2] != 0;
+          const double *gp = a.X + (n * a.D + raw) * a.T;
+          double mean = 0.0, den = 1.0;
+          if (standardise) {
+            mean = as_const(a.stats)[(n * a.n_prep + src) * 2];
+            den = as_const(a.stats)[(n * a.n_prep + src) * 2 + 1];
+          }
+#pragma unroll
+          for (int k = 0; k < U; ++k) {
+            const int i = 2 * (k * kWalkThreads + tid);
+            const int64_t t = t0 + i;
+            double e0 = 0.0, e1 = 0.0;
+            if (t < a.T) e0 = gp[t];
+            if (t + 1 < a.T) e1 = gp[t + 1];
+            if (lag > 0) {
+              e0 = (t >= lag && t < a.T) ? e0 - gp[t - lag] : 0.0;
+              e1 = (t + 1 >= lag && t + 1 < a.T) ? e1 - gp[t + 1 - lag] : 0.0;
+            }
+            if (standardise) {
+              e0 = (e0 - mean) / den;
+              e1 = (e1 - mean) / den;
+            }
+            // (elements beyond T stay what the unfused path stages there: zeros)
+            v[rr][k] = vd2{t < a.T ? e0 : 0.0, t + 1 < a.T ? e1 : 0.0};
+          }
+        } else {
+          const double *gp =
+              src >= 0 ? a.X + (n * a.D + src) * a.T
+                       : a.aux + (int64_t)(-src - 1) * a.aux_tab_stride + n * a.aux_n_stride;
+#pragma unroll
+          for (int k = 0; k < U; ++k) {
+            const int i = 2 * (k * kWalkThreads + tid);
+            const int64_t t = t0 + i;
+            v[rr][k] = vd2{0.0, 0.0};
+            if (a.vec_ok) {
+              if (cx.full_chunk || t < a.T) v[rr][k] = *reinterpret_cast<const vd2 *>(gp + t);
+            } else {
+              if (t < a.T) v[rr][k].x = gp[t];
+              if (t + 1 < a.T) v[rr][k].y = gp[t + 1];
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < kStageRows; ++rr) {
+      if (r0 + rr < a.R) {
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          const int i = 2 * (k * kWalkThreads + tid);
+          *reinterpret_cast<vd2 *>(rows_w + (r0 + rr) * C::CHUNK + lds_pos<C>(i)) = v[rr][k];
+        }
+      }
+    }
+  }
+}
+
+// LDS of the fused kernel: rows [R][CHUNK] | totals window [2][8] | tails [2][4] | carries
+// [carry_slots] (MULTI) | feature window (values, populations, columns)
+template <class C>
+__global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(4)))
+void iss_fused_kernel(const IssArgs a) {
+  static_assert(C::MODE == 1 && C::TEAM == 4 && C::P == 1 && C::MULTI != 2, "fused configuration");
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x;
+  WalkCtx cx;
+  cx.a = &a;
+  cx.rows = lds;
+  cx.tot = lds + (int64_t)a.R * C::CHUNK;
+  cx.tail = cx.tot + 16;
+  cx.carry = cx.tail + 8;
+  cx.tid = tid;
+  cx.lane = tid & 63;
+  cx.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  cx.team = 0;
+  cx.buf = 0;
+  cx.tail_buf = 0;
+  {
+    double *fw = cx.carry + (C::MULTI == 1 ? a.carry_slots : 0);
+    cx.fl_val = (lds_f64 *)fw;
+    cx.fl_cnt = (lds_f64 *)(fw + a.feat_window);
+    cx.fl_col = (lds_i32 *)(fw + (a.has_mpi ? 2 : 1) * a.feat_window);
+    for (int sl = tid; sl < a.feat_window; sl += kWalkThreads) {
+      cx.fl_val[sl] = 0.0;
+      if (a.has_mpi) cx.fl_cnt[sl] = 0.0;
+    }
+    // the identity slots of both totals windows
+    if (tid < 6) cx.tot[(tid / 3) * 8 + tid % 3] = semi_zero<C::SEMI>();
+    cx.fused_used = 0;
+    cx.fslot = 0;
+  }
+  // one workgroup per unit (series n, group g0); with the xcd numbering the groups of one
+  // series meet in one XCD's L2 (speed only)
+  const int u = blockIdx.x;
+  int64_t n;
+  int g0;
+  if (a.xcd_map) {
+    const int q = u >> 3, r = u & 7;
+    n = (int64_t)(q / a.G) * 8 + r;
+    g0 = q % a.G;
+  } else {
+    const int ni = u / a.G;
+    n = ni;
+    g0 = u - ni * a.G;
+  }
+  const int node_begin = as_const(a.group_begin)[g0];
+  cx.pc_begin = node_begin;
+  cx.feat_row = a.feats + n * a.feat_stride;
+  cx.cnt_row = a.cnt + n * a.feat_stride;
+  cx.cut_row = a.series_cuts ? a.series_cuts + n * a.cut_slots : nullptr;
+  cx.series = n;
+  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    const int64_t t0 = (int64_t)chunk * C::CHUNK;
+    cx.t0 = t0;
+    cx.first_chunk = chunk == 0;
+    cx.full_chunk = t0 + C::CHUNK <= a.T;
+    if (chunk > 0) lds_barrier();  // all reads of the old rows are done
+    stage_chunk<C>(cx, a, n, t0, lds);
+    __syncthreads();
+    cx.fused_used = 0;  // same slots in every chunk
+    fwalk<C>(cx, node_begin);
+    // a unit whose features fit the window keeps them there over its time chunks; else every
+    // chunk leaves its share (added onto the earlier chunks' in global memory)
+    if (!a.feat_fits || chunk + 1 == a.nchunks) feat_flush<C>(cx, !a.feat_fits && chunk > 0);
+  }
+}
+
+}  // namespace fr

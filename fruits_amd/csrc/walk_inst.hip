@@ -19,33 +19,43 @@ hipError_t walk_inst_team1(const IssArgs &a, int levels, int chunk, hipStream_t 
   return chunk == 512 ? team1_p<4>(a, levels, st) : team1_p<8>(a, levels, st);
 }
 #else
-// Fused kernels (vector-issue bound by the sieve epilogue) use 4 consecutive elements per
-// lane in one piece for 1024-element chunks: half the wave-scan chains of the 2 x 2 layout
-// the materialising kernels interleave to hide DPP latency.
 #if WALK_MODE == 1
-#define WALK_E(P) ((P) == 2 ? 4 : 2)
-#define WALK_P(P) ((P) == 2 ? 1 : (P))
+// The fused walk (walk_fused.h): 4 consecutive elements per lane for 1024-element chunks, 2 for
+// 512-element ones; carries of a multi-chunk walk always live in LDS (the host sizes the groups
+// for that).
+template <int E, int MULTI>
+static hipError_t inst_f(const IssArgs &a, hipStream_t st) {
+  if (a.semiring == kSemiArctic)
+    return a.aux ? launch_fused_cfg<E, WALK_LV, MULTI, true, 1>(a, st)
+                 : launch_fused_cfg<E, WALK_LV, MULTI, false, 1>(a, st);
+  if (a.semiring == kSemiBayesian)
+    return a.aux ? launch_fused_cfg<E, WALK_LV, MULTI, true, 2>(a, st)
+                 : launch_fused_cfg<E, WALK_LV, MULTI, false, 2>(a, st);
+  return a.aux ? launch_fused_cfg<E, WALK_LV, MULTI, true, 0>(a, st)
+               : launch_fused_cfg<E, WALK_LV, MULTI, false, 0>(a, st);
+}
+template <int P>
+static hipError_t inst_p(const IssArgs &a, hipStream_t st) {
+  constexpr int E = P == 2 ? 4 : 2;
+  if (a.nchunks > 1 && !a.carry_in_lds) return hipErrorInvalidValue;
+  return a.nchunks > 1 ? inst_f<E, 1>(a, st) : inst_f<E, 0>(a, st);
+}
 #else
-#define WALK_E(P) 2
-#define WALK_P(P) (P)
-#endif
 template <int P, int MULTI, bool VEC>
 static hipError_t inst_w(const IssArgs &a, hipStream_t st) {
-  constexpr int E = WALK_E(P), PP = WALK_P(P);
+  constexpr int E = 2, PP = P;
   if (a.semiring == kSemiArctic)
     return a.aux ? launch_walk_cfg<E, PP, WALK_LV, MULTI, VEC, true, 4, WALK_MODE, 1>(a, st)
                  : launch_walk_cfg<E, PP, WALK_LV, MULTI, VEC, false, 4, WALK_MODE, 1>(a, st);
   if (a.semiring == kSemiBayesian)
     return a.aux ? launch_walk_cfg<E, PP, WALK_LV, MULTI, VEC, true, 4, WALK_MODE, 2>(a, st)
                  : launch_walk_cfg<E, PP, WALK_LV, MULTI, VEC, false, 4, WALK_MODE, 2>(a, st);
-#if WALK_MODE == 0
   // unweighted Reals, one aligned chunk, one group per series on a cache-sized batch: the
   // input is staged with non-temporal loads (capi.cpp sets nt_input)
   if constexpr (MULTI == 0 && VEC) {
     if (a.nt_input && !a.aux)
       return launch_walk_cfg<E, PP, WALK_LV, MULTI, VEC, false, 4, WALK_MODE, 0, true>(a, st);
   }
-#endif
   return a.aux ? launch_walk_cfg<E, PP, WALK_LV, MULTI, VEC, true, 4, WALK_MODE>(a, st)
                : launch_walk_cfg<E, PP, WALK_LV, MULTI, VEC, false, 4, WALK_MODE>(a, st);
 }
@@ -53,36 +63,28 @@ template <int P>
 static hipError_t inst_p(const IssArgs &a, hipStream_t st) {
   // carries of a multi-chunk walk live in LDS when the group's slots fit (see WalkCfg)
   const int multi = a.nchunks > 1 ? (a.carry_in_lds ? 1 : 2) : 0;
-#if WALK_MODE == 1
-  // no tensor stores in fused mode: the VEC template parameter is irrelevant
-  if (multi == 1) return inst_w<P, 1, true>(a, st);
-  return multi == 2 ? inst_w<P, 2, true>(a, st) : inst_w<P, 0, true>(a, st);
-#else
   if (multi == 1) return a.vec_ok ? inst_w<P, 1, true>(a, st) : inst_w<P, 1, false>(a, st);
   if (multi == 2) return a.vec_ok ? inst_w<P, 2, true>(a, st) : inst_w<P, 2, false>(a, st);
   return a.vec_ok ? inst_w<P, 0, true>(a, st) : inst_w<P, 0, false>(a, st);
-#endif
 }
+#endif
 #define WALK_CAT2(a, b, c, d) a##b##c##d
 #define WALK_CAT(a, b, c, d) WALK_CAT2(a, b, c, d)
 #ifdef WALK_TI
 // Translation unit of the TOTALINC instantiations (WalkCfg::TOTALINC: fused epilogue of a
 // totally weighted plan with differencing sieves), apart from the common fused kernels so the
 // build stays parallel.
-template <int P, int MULTI>
+template <int E, int MULTI>
 static hipError_t inst_ti(const IssArgs &a, hipStream_t st) {
-  constexpr int E = WALK_E(P), PP = WALK_P(P);
-  if (a.semiring == kSemiArctic)
-    return launch_walk_cfg<E, PP, WALK_LV, MULTI, true, true, 4, 1, 1, false, true>(a, st);
-  if (a.semiring == kSemiBayesian)
-    return launch_walk_cfg<E, PP, WALK_LV, MULTI, true, true, 4, 1, 2, false, true>(a, st);
-  return launch_walk_cfg<E, PP, WALK_LV, MULTI, true, true, 4, 1, 0, false, true>(a, st);
+  if (a.semiring == kSemiArctic) return launch_fused_cfg<E, WALK_LV, MULTI, true, 1, true>(a, st);
+  if (a.semiring == kSemiBayesian) return launch_fused_cfg<E, WALK_LV, MULTI, true, 2, true>(a, st);
+  return launch_fused_cfg<E, WALK_LV, MULTI, true, 0, true>(a, st);
 }
 template <int P>
 static hipError_t inst_ti_p(const IssArgs &a, hipStream_t st) {
-  const int multi = a.nchunks > 1 ? (a.carry_in_lds ? 1 : 2) : 0;
-  if (multi == 1) return inst_ti<P, 1>(a, st);
-  return multi == 2 ? inst_ti<P, 2>(a, st) : inst_ti<P, 0>(a, st);
+  constexpr int E = P == 2 ? 4 : 2;
+  if (a.nchunks > 1 && !a.carry_in_lds) return hipErrorInvalidValue;
+  return a.nchunks > 1 ? inst_ti<E, 1>(a, st) : inst_ti<E, 0>(a, st);
 }
 hipError_t WALK_CAT(walk_inst_ti, , _l, WALK_LV)(const IssArgs &a, int chunk, hipStream_t st) {
   return chunk == 512 ? inst_ti_p<1>(a, st) : inst_ti_p<2>(a, st);

@@ -42,7 +42,7 @@ constexpr int32_t F_SLOW = 4;          // a division or more than kRecInlineFact
                                        // the factor table is walked instead
 struct NodeRec {
   int32_t w[16];
-  // w[0]  level | flags << 8          w[1]  fac_count
+  // w[0]  level | flags << 8          w[1]  fac_count | (z_mul + 1) << 16 | (emit_mul + 1) << 24
   // w[2..5]  inline factor rows       w[6]  emit_count
   // w[7..8]  inline emit rows         w[9]  node id (carry slot)
   // w[10] emit_mul row or -1          w[11] z_mul row or -1
