@@ -27,12 +27,16 @@ def units():
     out = [("kernels_misc", "kernels_misc.hip", []), ("plan", "plan.cpp", []),
            ("capi", "capi.cpp", []), ("jit", "jit.cpp", []),
            ("walk_static_reg", "walk_static_inst.hip", ["-DSTATIC_REGISTRY"]), ("walk_team1", "walk_inst.hip", ["-DWALK_TEAM1"])]
+    # the fused walk (mode 1) without a*b+c contraction: the reference rounds a letter's product
+    # before the cumulative sum adds it (fruits/iss/semiring.py:143-149), and so do the static
+    # programs below
     for mode in (0, 1):
         for lv in (2, 4, 6, 8):
             out.append((f"walk_m{mode}_l{lv}", "walk_inst.hip",
-                        [f"-DWALK_MODE={mode}", f"-DWALK_LV={lv}"]))
+                        [f"-DWALK_MODE={mode}", f"-DWALK_LV={lv}"] + (["-ffp-contract=off"] if mode else [])))
     for lv in (2, 4, 6, 8):
-        out.append((f"walk_m1ti_l{lv}", "walk_inst.hip", ["-DWALK_MODE=1", f"-DWALK_LV={lv}", "-DWALK_TI"]))
+        out.append((f"walk_m1ti_l{lv}", "walk_inst.hip",
+                    ["-DWALK_MODE=1", f"-DWALK_LV={lv}", "-DWALK_TI", "-ffp-contract=off"]))
     for mode in (0, 1):
         out.append((f"walk_packed_m{mode}", "walk_packed_inst.hip", [f"-DWALK_MODE={mode}"]))
     for s in (1, 2, 3, 4, 5, 6, 7, 8):

@@ -99,6 +99,7 @@ struct WalkCtx {
   lds_i32 *fl_col;
   int fslot;            // first window slot of the node being processed
   int fused_used;       // slots of the window in use
+  int feat_window;      // slots of the window (a huge number when every group's features fit)
   const int32_t *cut_row;  // MODE 1: this series' row of IssArgs::series_cuts (or nullptr)
   int64_t series;          // MODE 1: index of the series being walked
   double *carry;        // carry slots of this series (multi-chunk; LDS or global) or nullptr
@@ -630,6 +631,8 @@ __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w, int slot
   }
 }
 
+// (The IssArgs struct is the only kernel argument of every kernel that flushes: it starts the
+// kernel-argument segment.)
 // Flushes the LDS feature window of a cooperative kernel: slot s -> column fl_col[s] of the
 // series' feature row with plain stores (`add`: onto what earlier time chunks of the unit left
 // there - the unit owns its columns, so a plain read-modify-write by the thread that wrote them),
@@ -637,17 +640,23 @@ __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w, int slot
 template <class C>
 __device__ __forceinline__ void feat_flush(WalkCtx &cx, bool add) {
   lds_barrier();   // the adds of every wave are in
-  const bool mpi = cx.a->has_mpi != 0;
+  // (the kernel arguments through a pointer the optimiser cannot look through: loaded here,
+  // where they are used, not kept in scalar registers over the whole walk)
+  cptr<IssArgs> ap = (cptr<IssArgs>)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ap));
+  const bool mpi = ap->has_mpi != 0;
+  double *feat_row = ap->feats + cx.series * ap->feat_stride;
+  double *cnt_row = ap->cnt + cx.series * ap->feat_stride;
   for (int sl = cx.tid; sl < cx.fused_used; sl += kWalkThreads) {
     const int col = cx.fl_col[sl];
     double v = cx.fl_val[sl];
-    if (add) v = cx.feat_row[col] + v;
-    cx.feat_row[col] = v;
+    if (add) v = feat_row[col] + v;
+    feat_row[col] = v;
     cx.fl_val[sl] = 0.0;
     if (mpi) {
       double n = cx.fl_cnt[sl];
-      if (add) n = cx.cnt_row[col] + n;
-      cx.cnt_row[col] = n;
+      if (add) n = cnt_row[col] + n;
+      cnt_row[col] = n;
       cx.fl_cnt[sl] = 0.0;
     }
   }
@@ -657,7 +666,7 @@ __device__ __forceinline__ void feat_flush(WalkCtx &cx, bool add) {
 // Window slots of the next node (`need` = output rows x feature ops); a full window leaves first.
 template <class C>
 __device__ __forceinline__ void feat_reserve(WalkCtx &cx, int need) {
-  if (!cx.a->feat_fits && cx.fused_used + need > cx.a->feat_window) feat_flush<C>(cx, !cx.first_chunk);
+  if (cx.fused_used + need > cx.feat_window) feat_flush<C>(cx, !cx.first_chunk);
   cx.fslot = cx.fused_used;
   cx.fused_used += need;
 }
@@ -840,14 +849,12 @@ __device__ __forceinline__ void walk(WalkCtx &cx, Rec &cur, int &pc,
       cur = load_rec(a.recs, pc);
       double pout[C::EP];
       STAMP(cx, 0);  // interpreter: record decode / prefetch issue
-      if constexpr (C::MODE == 1 && C::TEAM != 1) feat_reserve<C>(cx, nd.emit_count() * a.n_ops);
       process_node<C>(cx, nd, slot, pin, pout);
       while (cur.level() == LV && (cur.flags() & F_CHAIN)) {
         const Rec nc = cur;
         const int slot2 = carry_slot_of<C>(cx, nc, pc);
         ++pc;
         cur = load_rec(a.recs, pc);
-        if constexpr (C::MODE == 1 && C::TEAM != 1) feat_reserve<C>(cx, nc.emit_count() * a.n_ops);
         process_node<C>(cx, nc, slot2, pout, pout);
       }
       if constexpr (LV + 1 < C::MAXLV) {
@@ -875,7 +882,6 @@ __device__ __forceinline__ void walk(WalkCtx &cx, Rec &cur, int &pc,
         for (int i = 0; i < C::EP; ++i) src[i] = pin[i];
       }
       STAMP(cx, 0);  // interpreter: record decode / prefetch issue
-      if constexpr (C::MODE == 1 && C::TEAM != 1) feat_reserve<C>(cx, nd.emit_count() * a.n_ops);
       process_node<C>(cx, nd, slot, src, pout);
       if constexpr (LV + 1 < C::MAXLV) {
         if (cur.level() == LV + 1) walk<C, LV + 1>(cx, cur, pc, pout);
@@ -1120,20 +1126,6 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
   cx.tail_buf = 0;
   double *rows_w = lds;
   bool first_unit = true;
-  if constexpr (C::MODE == 1 && C::TEAM != 1) {
-    // feature window behind the rows, the wave totals and the LDS carries: values,
-    // populations, columns; cleared here and by every flush
-    double *fw = lds + (int64_t)a.R * C::CHUNK + 4 * C::NW + (C::MULTI == 1 ? a.carry_slots : 0);
-    cx.fl_val = (lds_f64 *)fw;
-    cx.fl_cnt = (lds_f64 *)(fw + a.feat_window);
-    cx.fl_col = (lds_i32 *)(fw + (a.has_mpi ? 2 : 1) * a.feat_window);
-    for (int sl = tid; sl < a.feat_window; sl += kWalkThreads) {
-      cx.fl_val[sl] = 0.0;
-      if (a.has_mpi) cx.fl_cnt[sl] = 0.0;
-    }
-    cx.fused_used = 0;
-    cx.fslot = 0;
-  }
 #ifdef FRUITS_HIP_TIMING_BUILD
   if (a.debug & 4) return;
   for (int i = 0; i < 8; ++i) cx.seg[i] = 0;
@@ -1299,13 +1291,7 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
       for (int i = 0; i < C::EP; ++i) ones[i] = C::SEMI != 1 ? 1.0 : 0.0;
       int pc = node_begin;
       Rec cur = load_rec(a.recs, pc);
-      if constexpr (C::MODE == 1 && C::TEAM != 1) cx.fused_used = 0;  // same slots in every chunk
       walk<C, 0>(cx, cur, pc, ones);
-      if constexpr (C::MODE == 1 && C::TEAM != 1) {
-        // a unit whose features fit the window keeps them there over its time chunks; else
-        // every chunk leaves its share (added onto the earlier chunks' in global memory)
-        if (!a.feat_fits || chunk + 1 == a.nchunks) feat_flush<C>(cx, !a.feat_fits && chunk > 0);
-      }
     }
     first_unit = false;
   }

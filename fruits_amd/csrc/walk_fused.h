@@ -32,6 +32,58 @@ constexpr int32_t OPF_FULL_RANGE = 1 << 17;   // lo <= 0 and hi >= T: every elem
 constexpr int32_t OPF_NO_HI = 1 << 18;        // qhi = +inf
 constexpr int32_t OPF_NO_LO = 1 << 19;        // qlo = -inf
 
+// Single-lane LDS operations of a whole wave in uniform control flow (EXEC all ones before and
+// after): the lane is selected by writing EXEC, not by a compare + saved mask + branch - two
+// scalar instructions, no mask registers kept alive.  `off` is an LDS BYTE address.
+__device__ __forceinline__ void lds_store_lane63(int off, double v) {
+  asm volatile("s_lshl_b64 exec, 1, 63\n\tds_write_b64 %0, %1\n\ts_mov_b64 exec, -1"
+               :: "v"(off), "v"(v) : "memory", "scc");   // (s_lshl_b64 writes SCC)
+}
+__device__ __forceinline__ void lds_store_lane(int lane, int off, double v) {
+  asm volatile("s_lshl_b64 exec, 1, %2\n\tds_write_b64 %0, %1\n\ts_mov_b64 exec, -1"
+               :: "v"(off), "v"(v), "s"(__builtin_amdgcn_readfirstlane(lane)) : "memory", "scc");
+}
+__device__ __forceinline__ void lds_store_lane0_i32(int off, int v) {
+  asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1"
+               :: "v"(off), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_add_lane0(int off, double v) {
+  asm volatile("s_mov_b64 exec, 1\n\tds_add_f64 %0, %1\n\ts_mov_b64 exec, -1"
+               :: "v"(off), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_add2_lane63(int off0, double v0, int off1, double v1) {
+  asm volatile("s_lshl_b64 exec, 1, 63\n\tds_add_f64 %0, %1\n\tds_add_f64 %2, %3\n\ts_mov_b64 exec, -1"
+               :: "v"(off0), "v"(v0), "v"(off1), "v"(v1) : "memory", "scc");
+}
+__device__ __forceinline__ int lds_offset(const void __attribute__((address_space(3))) *p) {
+  return (int)(unsigned)(uintptr_t)p;
+}
+
+// The kernel arguments as seen from code that rarely runs (flushes, reciprocal factors, further
+// output rows, per-series cuts): read through a pointer the optimiser cannot look through, so
+// that they are loaded where they are used instead of being hoisted out of the node loop into
+// scalar registers - there are only 102 of those, and the hot path needs them.
+// (The kernel's only argument is the IssArgs struct: it starts the kernel-argument segment.)
+__device__ __forceinline__ cptr<IssArgs> cold_args() {
+  cptr<IssArgs> ap = (cptr<IssArgs>)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ap));
+  return ap;
+}
+
+__device__ __forceinline__ const void *uniform_ptr(const void *p) {
+  const uint64_t u = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return reinterpret_cast<const void *>(((uint64_t)hi << 32) | lo);
+}
+
+// One dword of a table line, loaded a node ahead of the real access: the line is then in the
+// scalar cache and the real load (issued right where its registers are needed - prefetching INTO
+// registers keeps 16 SGPRs alive across the node and ends in spills) is a cache hit.
+__device__ __forceinline__ int touch(const void *p) {
+  return *as_const(reinterpret_cast<const int32_t *>(p));
+}
+
 // the first half of a NodeRec (w[0..7]): level | flags, factor count | weights, four inline
 // factors, emit count, first output row
 struct Rec8 {
@@ -98,8 +150,8 @@ __device__ __forceinline__ void fscan(WalkCtx &cx, const double (&s)[C::EP], dou
   if constexpr (C::MULTI != 0) {
     if (!cx.first_chunk) carry_in = cx.carry[carry_slot];
   }
-  double *tw = cx.tot + cx.buf * 8;   // {Z, Z, Z, t0, t1, t2, t3, -}
-  if (cx.lane == 63) tw[3 + cx.wave] = incl;
+  lds_f64 *tw = (lds_f64 *)(cx.tot + cx.buf * 8);   // {Z, Z, Z, t0, t1, t2, t3, -}
+  lds_store_lane63(lds_offset(tw + 3 + cx.wave), incl);
   lds_barrier();
   double base;
   if constexpr (WINDOW) {
@@ -114,8 +166,9 @@ __device__ __forceinline__ void fscan(WalkCtx &cx, const double (&s)[C::EP], dou
   if constexpr (C::MULTI != 0) {
     // the carry of earlier chunks: every wave read it before the barrier, the last lane of the
     // chunk advances it
-    if (cx.wave == 3 && cx.lane == 63)
-      cx.carry[carry_slot] = semi_add<C::SEMI>(carry_in, semi_add<C::SEMI>(base, incl));
+    if (cx.wave == 3)
+      lds_store_lane63(lds_offset((lds_f64 *)cx.carry + carry_slot),
+                       semi_add<C::SEMI>(carry_in, semi_add<C::SEMI>(base, incl)));
     base = semi_add<C::SEMI>(base, carry_in);
   }
   const double off = semi_add<C::SEMI>(base, excl);
@@ -182,13 +235,15 @@ __device__ __forceinline__ void fop(WalkCtx &cx, const int32_t *w, int slot, con
   constexpr int E = C::E;
   const int kind = w[0] & 0xff, inc = (int)(int8_t)((w[0] >> 8) & 0xff), col = w[1];   // inc: signed
   const bool series_cuts = (w[0] & OPF_SERIES_CUTS) != 0;
-  // (the flush needs the column of every slot, also of one no lane adds to)
-  if (cx.wave == 0 && cx.lane == 0) cx.fl_col[slot] = col;
+  // (the flush needs the column of every slot, also of one no lane adds to; every wave
+  // writes the same word - cheaper than asking which wave is first)
+  lds_store_lane0_i32(lds_offset(cx.fl_col + slot), col);
   if (kind == FR_SIEVE_END_K) {
     int pick = w[2];                    // index of the value to pick
     if (series_cuts) {                  // X[:, cut - 1], index -1 wrapping like numpy
-      pick = as_const(cx.cut_row)[w[2]] - 1;
-      if (pick < 0) pick += (int)cx.a->T;
+      cptr<IssArgs> ca = cold_args();
+      pick = as_const(ca->series_cuts + cx.series * ca->cut_slots)[w[2]] - 1;
+      if (pick < 0) pick += (int)ca->T;
     }
     const int rel = pick - (int)cx.t0;
     if (rel >= 0 && rel < C::CHUNK) {
@@ -198,15 +253,17 @@ __device__ __forceinline__ void fop(WalkCtx &cx, const int32_t *w, int slot, con
         const int q = rel - wv * C::SPAN;
         const int owner = q / E, eu = q - owner * E;
         const double v = pick_uniform<E, 0>(eu, c);
-        if (cx.lane == owner) cx.fl_val[slot] = v;
+        lds_store_lane(owner, lds_offset(cx.fl_val + slot), v);
       }
     }
     return;
   }
   int lo = w[2], hi = w[3];
   if (series_cuts) {
-    lo = as_const(cx.cut_row)[w[2]];
-    hi = as_const(cx.cut_row)[w[3]];
+    cptr<IssArgs> ca = cold_args();
+    cptr<int32_t> cut_row = as_const(ca->series_cuts + cx.series * ca->cut_slots);
+    lo = cut_row[w[2]];
+    hi = cut_row[w[3]];
   }
   const double qlo = bits_to_double(w[4], w[5]), qhi = bits_to_double(w[6], w[7]);
   // element 0 of the series: increments are zero-padded there (fruits/cache.py:8-13)
@@ -260,23 +317,25 @@ __device__ __forceinline__ void fop(WalkCtx &cx, const int32_t *w, int slot, con
   double sum;
   const bool mpi = kind == FR_SIEVE_MPI_K;
   band_count<C>(cx, w[0], lo, hi, qlo, qhi, d, mpi, cnt, sum);
-  if (mpi) sum = wave_last_lane(wave_inclusive_scan<0>(sum));  // wave total by DPP
-  if (cx.lane == 0) {
-    // one LDS add per wave (ds_add_f64, nothing returned)
-    if (mpi) {
-      lds_add(cx.fl_val + slot, sum);
-      lds_add(cx.fl_cnt + slot, (double)cnt);
-    } else {
-      lds_add(cx.fl_val + slot, (double)cnt);
-    }
-  }
+  if (mpi) sum = wave_inclusive_scan<0>(sum);  // lane 63 holds the wave total
+  // one LDS add per wave (ds_add_f64, nothing returned)
+  if (mpi)
+    lds_add2_lane63(lds_offset(cx.fl_val + slot), sum, lds_offset(cx.fl_cnt + slot), (double)cnt);
+  else
+    lds_add_lane0(lds_offset(cx.fl_val + slot), (double)cnt);
 }
 
 // one feature op (32 bytes = one s_load_dwordx8)
 struct Op1 {
   int32_t w[8];
 };
-__device__ __forceinline__ Op1 load_op1(const IssArgs &a, int64_t k, int i) {
+// what the node loop reads of the kernel arguments, as scalars of their own
+struct Hot {
+  const NodeRec *recs;
+  const FeatOp *ops;
+  int n_ops, n_ops_padded;
+};
+__device__ __forceinline__ Op1 load_op1(const Hot &a, int64_t k, int i) {
   cptr<int32_t> q = as_const(reinterpret_cast<const int32_t *>(
       __builtin_assume_aligned(a.ops + (k * a.n_ops_padded + i), 32)));
   Op1 o;
@@ -288,12 +347,11 @@ __device__ __forceinline__ Op1 load_op1(const IssArgs &a, int64_t k, int i) {
 // The feature ops of every output row of a node: ONE code site for an op, the next op
 // requested while the current one is evaluated.
 template <class C>
-__device__ __forceinline__ void fops_all(WalkCtx &cx, const Rec8 &nd, int pc, const Op1 &pre,
-                                         const double (&c)[C::EP], const double (&x)[C::EP],
-                                         const double (&s)[C::EP], bool seq_steps) {
-  const IssArgs &a = *cx.a;
-  const int ne = nd.emit_count(), n = a.n_ops;
-  int64_t k = nd.w[7];
+__device__ __forceinline__ void fops_all(WalkCtx &cx, const Hot &a, int ne, int64_t k, int pc,
+                                         const Op1 &pre, const double (&c)[C::EP],
+                                         const double (&x)[C::EP], const double (&s)[C::EP],
+                                         bool seq_steps) {
+  const int n = a.n_ops;
   Op1 nx = pre;  // op 0 of the first row was requested at the start of the node
   FusedScratch<C::EP> sc;
   int slot = cx.fslot;   // window slot of (output row j, op i): fslot + j * n + i
@@ -306,16 +364,18 @@ __device__ __forceinline__ void fops_all(WalkCtx &cx, const Rec8 &nd, int pc, co
     if (++j >= ne) break;
     slot += n;
     k = j == 1 ? (int64_t)rec_field(a.recs, pc, 8)
-               : (int64_t)as_const(a.emit_rows)[rec_field(a.recs, pc, 13) + j];
+               : (int64_t)as_const(cold_args()->emit_rows)[rec_field(a.recs, pc, 13) + j];
     nx = load_op1(a, k, 0);
   }
 }
 
 // Register frames: f[k] holds the prefix the children of the open node of level k continue
-// from.  They are only ever indexed by compile-time constants - the level of a node selects a
-// case of a small switch (deepest level first: that is where most nodes are).
+// from.  They are only ever indexed by compile-time constants: a node's level selects a case
+// through a chain of single-bit tests of 1 << level, deepest level first (that is where most
+// nodes are; as a chain of equality tests the compiler builds a balanced switch with flag
+// variables out of it).  Case K < 0 is the semiring's one (a first letter).
 template <class C, int K>
-__device__ __forceinline__ void frame_mul(const WalkCtx &cx, int rd, int code,
+__device__ __forceinline__ void frame_mul(const WalkCtx &cx, unsigned rd_bit, int code,
                                           const double (&f)[C::MAXLV][C::EP], double (&s)[C::EP]) {
   if constexpr (K < 0) {
     double ones[C::EP];  // identity of the semiring's product: 1 (Reals, Bayesian), 0 (Arctic)
@@ -323,38 +383,40 @@ __device__ __forceinline__ void frame_mul(const WalkCtx &cx, int rd, int code,
     for (int i = 0; i < C::EP; ++i) ones[i] = C::SEMI != 1 ? 1.0 : 0.0;
     mul_row_from<C>(cx, code, ones, s);
   } else {
-    if (rd == K) {
+    if (rd_bit & (2u << K)) {
       mul_row_from<C>(cx, code, f[K], s);
       asm volatile("" ::: "memory");  // (keeps the cases apart: merged, they cost selects)
     } else {
-      frame_mul<C, K - 1>(cx, rd, code, f, s);
+      frame_mul<C, K - 1>(cx, rd_bit, code, f, s);
     }
   }
 }
 template <class C, int K>
-__device__ __forceinline__ void frame_get(int rd, const double (&f)[C::MAXLV][C::EP], double (&s)[C::EP]) {
+__device__ __forceinline__ void frame_get(unsigned rd_bit, const double (&f)[C::MAXLV][C::EP],
+                                          double (&s)[C::EP]) {
   if constexpr (K < 0) {
 #pragma unroll
     for (int i = 0; i < C::EP; ++i) s[i] = C::SEMI != 1 ? 1.0 : 0.0;
   } else {
-    if (rd == K) {
+    if (rd_bit & (2u << K)) {
 #pragma unroll
       for (int i = 0; i < C::EP; ++i) s[i] = f[K][i];
       asm volatile("" ::: "memory");
     } else {
-      frame_get<C, K - 1>(rd, f, s);
+      frame_get<C, K - 1>(rd_bit, f, s);
     }
   }
 }
 template <class C, int K>
-__device__ __forceinline__ void frame_put(int lv, double (&f)[C::MAXLV][C::EP], const double (&x)[C::EP]) {
+__device__ __forceinline__ void frame_put(unsigned lv_bit, double (&f)[C::MAXLV][C::EP],
+                                          const double (&x)[C::EP]) {
   if constexpr (K >= 0) {
-    if (lv == K) {
+    if (lv_bit & (1u << K)) {
 #pragma unroll
       for (int i = 0; i < C::EP; ++i) f[K][i] = x[i];
       asm volatile("" ::: "memory");
     } else {
-      frame_put<C, K - 1>(lv, f, x);
+      frame_put<C, K - 1>(lv_bit, f, x);
     }
   }
 }
@@ -363,82 +425,97 @@ __device__ __forceinline__ void frame_put(int lv, double (&f)[C::MAXLV][C::EP], 
 // the prefix it continues (the frame of the level below; its own level's for an only child,
 // F_CHAIN), the scan, the feature ops, the hand-over to the children.
 template <class C>
-__device__ __forceinline__ void fwalk(WalkCtx &cx, int node_begin) {
+__device__ __forceinline__ void fwalk(WalkCtx &cx, int node_begin, int &sink) {
   constexpr int EP = C::EP;
-  const IssArgs &a = *cx.a;
+  Hot a;
+  {
+    const IssArgs &ka = *cx.a;
+    // (through readfirstlane: scalars of their own, not pieces of one wide kernel-argument load
+    // that is spilled and restored as a whole)
+    a.recs = reinterpret_cast<const NodeRec *>(uniform_ptr(ka.recs));
+    a.ops = reinterpret_cast<const FeatOp *>(uniform_ptr(ka.ops));
+    a.n_ops = __builtin_amdgcn_readfirstlane(ka.n_ops);
+    a.n_ops_padded = __builtin_amdgcn_readfirstlane(ka.n_ops_padded);
+  }
   double f[C::MAXLV][EP];
 #pragma unroll
   for (int k = 0; k < C::MAXLV; ++k)
 #pragma unroll
     for (int i = 0; i < EP; ++i) f[k][i] = 0.0;
   int pc = node_begin;
-  Rec8 cur = load_rec8(a.recs, pc);
-  while (cur.level() != kRecSentinelLevel) {
-    const Rec8 nd = cur;
+  Rec8 nd = load_rec8(a.recs, pc);
+  while (nd.level() != kRecSentinelLevel) {
     const int me = pc;
     const int slot = kCarrySlots * (pc - node_begin);
     ++pc;
-    cur = load_rec8(a.recs, pc);  // (its latency hides behind this node's vector work)
     const int ne = nd.emit_count();
+    const int64_t k0 = nd.w[7];
+    // the lines of the next record and of this node's ops, on their way to the scalar cache
+    const int t_rec = touch(a.recs + pc);
+    int t_ops = 0;
+    if (ne > 0) t_ops = touch(a.ops + k0 * a.n_ops_padded);
     feat_reserve<C>(cx, ne * a.n_ops);
     cx.slot = slot;
-    Op1 pre;
-    if (ne > 0) pre = load_op1(a, nd.w[7], 0);
     const int nf = nd.fac_count(), flags = nd.flags(), lv = nd.level();
-    const int rd = (flags & F_CHAIN) ? lv : lv - 1;
+    const unsigned lv_bit = 1u << lv;
+    const unsigned rd_bit = (flags & F_CHAIN) ? (lv_bit << 1) : lv_bit;   // 2 << (level read)
     double s[EP];
     if (flags & F_SLOW) {
       // a reciprocal factor or more than four: the factor table, one factor at a time
-      frame_get<C, C::MAXLV - 1>(rd, f, s);
+      frame_get<C, C::MAXLV - 1>(rd_bit, f, s);
       slow_factors<C>(cx, rec_field(a.recs, me, 12), nf, s, s, false);
     } else {
-      frame_mul<C, C::MAXLV - 1>(cx, rd, nd.w[2], f, s);
+      frame_mul<C, C::MAXLV - 1>(cx, rd_bit, nd.w[2], f, s);
       if (nf > 1) {
         mul_row<C>(cx, nd.w[3], s);
         if (nf > 2) mul_row<C>(cx, nd.w[4], s);
         if (nf > 3) mul_row<C>(cx, nd.w[5], s);
       }
     }
-    const bool has_children = (flags & F_CHILDREN) != 0;
-    const int z_mul = nd.z_mul(), emit_mul = nd.emit_mul();
-    const bool need2 = C::WEIGHTED && has_children && z_mul >= 0;
-    const bool need1 = ne > 0 || (has_children && !need2);
-    double hand[EP];   // what the children continue from
-    if (need1) {
+    const int w1 = nd.w[1];
+    const bool kids = (flags & F_CHILDREN) != 0;
+    if (flags & F_NEED1) {
       double c[EP], x[EP];
       fscan<C>(cx, s, c, x, slot);
+      Op1 pre;
+      if (ne > 0) pre = load_op1(a, k0, 0);   // (a scalar-cache hit: its line was touched above)
       // Reals: children start from the exclusive shift; Arctic / Bayesian: from the inclusive
       // maximum (taken before the emitted values are rescaled)
-#pragma unroll
-      for (int i = 0; i < EP; ++i) hand[i] = C::SEMI == 0 ? x[i] : c[i];
+      if (kids && !(flags & F_NEED2)) {
+        if constexpr (C::SEMI == 0) frame_put<C, C::MAXLV - 1>(lv_bit, f, x);
+        else frame_put<C, C::MAXLV - 1>(lv_bit, f, c);
+      }
       if (ne > 0) {
         // total weighting: the sieves see c * exp(-g alpha_k) (Arctic: c - g alpha_k)
+        const int emit_mul = ((w1 >> 24) & 0xff) - 1;
         if (C::WEIGHTED && emit_mul >= 0)
           mul_row<C>(cx, C::SEMI != 1 ? emit_mul : fac_arctic(emit_mul, -1), c);
         if constexpr (C::TOTALINC) {
           if (emit_mul >= 0) {
             double xs[EP];
             previous_weighted<C>(cx, emit_mul, x, xs);
-            fops_all<C>(cx, nd, me, pre, c, xs, s, false);
+            fops_all<C>(cx, a, ne, k0, me, pre, c, xs, s, false);
           } else {
-            fops_all<C>(cx, nd, me, pre, c, x, s, true);
+            fops_all<C>(cx, a, ne, k0, me, pre, c, x, s, true);
           }
         } else {
-          fops_all<C>(cx, nd, me, pre, c, x, s, !(C::WEIGHTED && emit_mul >= 0));
+          fops_all<C>(cx, a, ne, k0, me, pre, c, x, s, !(C::WEIGHTED && emit_mul >= 0));
         }
       }
     }
+    sink += t_rec + t_ops;
+    nd = load_rec8(a.recs, pc);   // (a scalar-cache hit; in flight over the second scan)
     if constexpr (C::WEIGHTED) {
-      if (need2) {
+      if (flags & F_NEED2) {
         // non-total weighting: the children continue from the scan of s * exp(+g alpha_k)
+        const int z_mul = ((w1 >> 16) & 0xff) - 1;
         double c2[EP], x2[EP];
         mul_row<C>(cx, C::SEMI != 1 ? z_mul : fac_arctic(z_mul, 1), s);
         fscan<C>(cx, s, c2, x2, slot + 1);
-#pragma unroll
-        for (int i = 0; i < EP; ++i) hand[i] = C::SEMI == 0 ? x2[i] : c2[i];
+        if constexpr (C::SEMI == 0) frame_put<C, C::MAXLV - 1>(lv_bit, f, x2);
+        else frame_put<C, C::MAXLV - 1>(lv_bit, f, c2);
       }
     }
-    if (has_children) frame_put<C, C::MAXLV - 1>(lv, f, hand);
   }
 }
 
@@ -551,6 +628,7 @@ void iss_fused_kernel(const IssArgs a) {
     if (tid < 6) cx.tot[(tid / 3) * 8 + tid % 3] = semi_zero<C::SEMI>();
     cx.fused_used = 0;
     cx.fslot = 0;
+    cx.feat_window = a.feat_fits ? 0x3fffffff : a.feat_window;
   }
   // one workgroup per unit (series n, group g0); with the xcd numbering the groups of one
   // series meet in one XCD's L2 (speed only)
@@ -567,6 +645,7 @@ void iss_fused_kernel(const IssArgs a) {
     g0 = u - ni * a.G;
   }
   const int node_begin = as_const(a.group_begin)[g0];
+  int sink = 0;
   cx.pc_begin = node_begin;
   cx.feat_row = a.feats + n * a.feat_stride;
   cx.cnt_row = a.cnt + n * a.feat_stride;
@@ -581,11 +660,12 @@ void iss_fused_kernel(const IssArgs a) {
     stage_chunk<C>(cx, a, n, t0, lds);
     __syncthreads();
     cx.fused_used = 0;  // same slots in every chunk
-    fwalk<C>(cx, node_begin);
+    fwalk<C>(cx, node_begin, sink);
     // a unit whose features fit the window keeps them there over its time chunks; else every
     // chunk leaves its share (added onto the earlier chunks' in global memory)
     if (!a.feat_fits || chunk + 1 == a.nchunks) feat_flush<C>(cx, !a.feat_fits && chunk > 0);
   }
+  if (sink == 0x7fffffff) cx.feat_row[0] = 0.0;   // (keeps the cache-touching loads alive)
 }
 
 }  // namespace fr

@@ -18,6 +18,11 @@ namespace fr {
 // node flags
 constexpr int32_t F_CHAIN = 1;     // only child: processed in place in its parent's frame
 constexpr int32_t F_CHILDREN = 2;  // the exclusive prefix of this node is consumed by children
+// what a node scans (resolved by the host, read by the fused walk): NEED1 - its letters' sum (it
+// has output rows, or children that continue from it); NEED2 - non-total weighting: a second
+// scan over s * exp(+g alpha) for the children
+constexpr int32_t F_NEED1 = 8;
+constexpr int32_t F_NEED2 = 16;
 // factor code: LDS row in the low 7 bits.  Reals: bit 7 = divide instead of multiply
 // (one code per occurrence of a letter).  Arctic: bits 8-15 = signed multiplier el of
 // the ADDED term el * row (one code per dimension of the extended letter).
