@@ -27,16 +27,18 @@ def units():
     out = [("kernels_misc", "kernels_misc.hip", []), ("plan", "plan.cpp", []),
            ("capi", "capi.cpp", []), ("jit", "jit.cpp", []),
            ("walk_static_reg", "walk_static_inst.hip", ["-DSTATIC_REGISTRY"]), ("walk_team1", "walk_inst.hip", ["-DWALK_TEAM1"])]
-    # the fused walk (mode 1) without a*b+c contraction: the reference rounds a letter's product
+    # The fused walk (mode 1): no a*b+c contraction - the reference rounds a letter's product
     # before the cumulative sum adds it (fruits/iss/semiring.py:143-149), and so do the static
-    # programs below
+    # programs below; and its uniform branches stay branches - structurised like divergent ones,
+    # every case of its level dispatch costs six scalar instructions and a speculative copy
+    fused = ["-ffp-contract=off", "-mllvm", "-structurizecfg-skip-uniform-regions"]
     for mode in (0, 1):
         for lv in (2, 4, 6, 8):
             out.append((f"walk_m{mode}_l{lv}", "walk_inst.hip",
-                        [f"-DWALK_MODE={mode}", f"-DWALK_LV={lv}"] + (["-ffp-contract=off"] if mode else [])))
+                        [f"-DWALK_MODE={mode}", f"-DWALK_LV={lv}"] + (fused if mode else [])))
     for lv in (2, 4, 6, 8):
         out.append((f"walk_m1ti_l{lv}", "walk_inst.hip",
-                    ["-DWALK_MODE=1", f"-DWALK_LV={lv}", "-DWALK_TI", "-ffp-contract=off"]))
+                    ["-DWALK_MODE=1", f"-DWALK_LV={lv}", "-DWALK_TI"] + fused))
     for mode in (0, 1):
         out.append((f"walk_packed_m{mode}", "walk_packed_inst.hip", [f"-DWALK_MODE={mode}"]))
     for s in (1, 2, 3, 4, 5, 6, 7, 8):
@@ -67,7 +69,8 @@ def hipcc() -> str:
 
 
 def _newest_header() -> float:
-    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    # (this file holds the units' compile flags: a change of it rebuilds like a header's)
+    return max([os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS] + [os.path.getmtime(__file__)])
 
 
 STAMP = LIB + ".flags"

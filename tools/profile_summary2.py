@@ -3,7 +3,7 @@ import collections, csv, glob, json, os, sys
 root, tag = sys.argv[1], sys.argv[2]
 out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "profiles_" + tag)
 os.makedirs(out_dir, exist_ok=True)
-KERNELS = ("iss_walk", "coswiss")
+KERNELS = ("iss_walk", "iss_fused", "coswiss")
 
 def stats(sub):
     f = glob.glob(f"{root}/{sub}/**/*kernel_stats.csv", recursive=True)
