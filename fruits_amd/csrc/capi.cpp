@@ -923,7 +923,10 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     a.series_cuts = fu->series_cuts;
     a.cut_slots = fu->cut_slots;
     a.total_inc = (fu->total_inc && p.weighting == FR_W_TOTAL) ? 1 : 0;
+    a.total_weighting = p.weighting == FR_W_TOTAL ? 1 : 0;
     a.has_mpi = fu->has_mpi ? 1 : 0;
+    if ((int64_t)p.K * fu->n_ops_padded * 32 >= (int64_t(1) << 32) || gp.recs.size() >= (size_t(1) << 26))
+      return fail(FR_E_LIMIT, w + ": the program tables exceed 4 GiB - split the word list");
     if (!packed) {
       const int64_t chunk = fr::walk_chunk_elems(T);
       const size_t other = ((size_t)a.R * chunk + 24 + (T > chunk ? a.carry_slots : 0)) * 8;

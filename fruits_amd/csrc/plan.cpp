@@ -340,7 +340,8 @@ GroupedProgram &grouped(Plan &p, int G) {
         const bool kids = (nd.flags & F_CHILDREN) != 0;
         const bool need2 = kids && nd.z_mul >= 0;
         const bool need1 = nd.emit_count > 0 || (kids && !need2);
-        const int fl = nd.flags | (slow ? F_SLOW : 0) | (need1 ? F_NEED1 : 0) | (need2 ? F_NEED2 : 0);
+        const int fl = nd.flags | (slow ? F_SLOW : 0) | (need1 ? F_NEED1 : 0) | (need2 ? F_NEED2 : 0) |
+                       (nd.emit_count > 0 ? F_EMIT : 0);
         r.w[0] = (nd.level & 0xff) | ((fl & 0xff) << 8);
         // (the first half of a record serves a multiply-only node alone: walk_fused.h)
         r.w[1] = (nd.fac_count & 0xffff) | ((nd.z_mul + 1) << 16) | ((nd.emit_mul + 1) << 24);

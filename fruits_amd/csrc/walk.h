@@ -51,15 +51,15 @@ static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
 }
 
 // launch of the fused walk (walk_fused.h): one workgroup per (series, group) unit
-template <int E, int LV, int MULTI, bool W, int SEMI = 0, bool TI = false>
-static hipError_t launch_fused_cfg(const IssArgs &a, hipStream_t st) {
+template <int E, int LV, int MULTI, bool W, int SEMI, bool TI, bool TOTAL>
+static hipError_t launch_fused_mode(const IssArgs &a, hipStream_t st) {
   using C = WalkCfg<E, 1, LV, MULTI, true, W, 4, 1, SEMI, false, TI>;
   const size_t lds = ((size_t)a.R * C::CHUNK + 16 + 8 + (MULTI == 1 ? a.carry_slots : 0)) * sizeof(double) +
                      feat_window_bytes(a.feat_window, a.has_mpi != 0);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static LaunchCache cache;  // per instantiation; per-device entries, thread-safe
   int per_cu = 1;
-  hipError_t e = cache.facts(iss_fused_kernel<C>, kWalkThreads, lds,
+  hipError_t e = cache.facts(iss_fused_kernel<C, TOTAL>, kWalkThreads, lds,
                              a.resident_out != nullptr ? &per_cu : nullptr);
   if (e != hipSuccess) return e;
   if (a.resident_out != nullptr) {  // the host only asks how many workgroups are resident
@@ -70,8 +70,17 @@ static hipError_t launch_fused_cfg(const IssArgs &a, hipStream_t st) {
   }
   const int64_t units = a.N * a.G;
   if (units > 0x7fffffffLL) return hipErrorInvalidValue;  // unit indices are 32-bit in the kernel
-  hipLaunchKernelGGL(iss_fused_kernel<C>, dim3((unsigned)units), dim3(kWalkThreads), lds, st, a);
+  hipLaunchKernelGGL((iss_fused_kernel<C, TOTAL>), dim3((unsigned)units), dim3(kWalkThreads), lds, st, a);
   return hipGetLastError();
+}
+// (the weighting mode of a plan - total or not - is a compile-time property of the fused walk)
+template <int E, int LV, int MULTI, bool W, int SEMI = 0, bool TI = false>
+static hipError_t launch_fused_cfg(const IssArgs &a, hipStream_t st) {
+  if constexpr (TI) return launch_fused_mode<E, LV, MULTI, W, SEMI, true, true>(a, st);
+  if constexpr (W) {
+    if (a.total_weighting) return launch_fused_mode<E, LV, MULTI, true, SEMI, false, true>(a, st);
+  }
+  return launch_fused_mode<E, LV, MULTI, W, SEMI, false, false>(a, st);
 }
 
 // launch of a static program: same persistent grid as the interpreter's

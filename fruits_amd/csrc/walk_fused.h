@@ -32,6 +32,12 @@ constexpr int32_t OPF_FULL_RANGE = 1 << 17;   // lo <= 0 and hi >= T: every elem
 constexpr int32_t OPF_NO_HI = 1 << 18;        // qhi = +inf
 constexpr int32_t OPF_NO_LO = 1 << 19;        // qlo = -inf
 
+// Table reads of the node loop: base pointer + unsigned 32-bit BYTE offset (one scalar load with
+// a register offset; a 64-bit index costs five scalar instructions of address arithmetic).
+__device__ __forceinline__ cptr<int32_t> at_offset(const void *base, uint32_t off) {
+  return (cptr<int32_t>)((cptr<char>)(base) + off);
+}
+
 // Single-lane LDS operations of a whole wave in uniform control flow (EXEC all ones before and
 // after): the lane is selected by writing EXEC, not by a compare + saved mask + branch - two
 // scalar instructions, no mask registers kept alive.  `off` is an LDS BYTE address.
@@ -80,8 +86,8 @@ __device__ __forceinline__ const void *uniform_ptr(const void *p) {
 // One dword of a table line, loaded a node ahead of the real access: the line is then in the
 // scalar cache and the real load (issued right where its registers are needed - prefetching INTO
 // registers keeps 16 SGPRs alive across the node and ends in spills) is a cache hit.
-__device__ __forceinline__ int touch(const void *p) {
-  return *as_const(reinterpret_cast<const int32_t *>(p));
+__device__ __forceinline__ int touch(const void *base, uint32_t off) {
+  return at_offset(base, off)[0];
 }
 
 // the first half of a NodeRec (w[0..7]): level | flags, factor count | weights, four inline
@@ -96,18 +102,17 @@ struct Rec8 {
   __device__ __forceinline__ int emit_count() const { return w[6]; }
 };
 
-__device__ __forceinline__ Rec8 load_rec8(const NodeRec *recs, int pc) {
-  cptr<int32_t> q = as_const(reinterpret_cast<const int32_t *>(
-      __builtin_assume_aligned(recs + pc, 64)));
+__device__ __forceinline__ Rec8 load_rec8(const NodeRec *recs, uint32_t rec_off) {
+  cptr<int32_t> q = at_offset(recs, rec_off);
   Rec8 r;
 #pragma unroll
   for (int i = 0; i < 8; ++i) r.w[i] = q[i];
   return r;
 }
 
-// a field of the second half of record pc (second output row, factor / emit table offsets)
-__device__ __forceinline__ int rec_field(const NodeRec *recs, int pc, int i) {
-  return as_const(reinterpret_cast<const int32_t *>(recs + pc))[i];
+// a field of the second half of a record (second output row, factor / emit table offsets)
+__device__ __forceinline__ int rec_field(const NodeRec *recs, uint32_t rec_off, int i) {
+  return at_offset(recs, rec_off)[i];
 }
 
 // s = src (x) factor: the first factor of a letter reads the prefix it continues
@@ -115,7 +120,8 @@ template <class C>
 __device__ __forceinline__ void mul_row_from(const WalkCtx &cx, int code, const double (&src)[C::EP],
                                              double (&s)[C::EP]) {
   double v[C::EP];
-  read_row<C>(cx, code & FAC_ROW_MASK, v);
+  // (multiply-only codes of Reals / Bayesian records are bare row numbers: nothing to mask)
+  read_row<C>(cx, C::SEMI != 1 ? code : (code & FAC_ROW_MASK), v);
   if constexpr (C::SEMI != 1) {
 #pragma unroll
     for (int i = 0; i < C::EP; ++i) s[i] = src[i] * v[i];
@@ -127,6 +133,20 @@ __device__ __forceinline__ void mul_row_from(const WalkCtx &cx, int code, const 
       const double prod = el * v[i];
       s[i] = src[i] + prod;
     }
+  }
+}
+
+// s (x)= factor for the codes the fused walk meets outside the factor table: bare row numbers
+// (Reals / Bayesian), row | multiplier << 8 (Arctic)
+template <class C>
+__device__ __forceinline__ void mul_rowp(const WalkCtx &cx, int code, double (&s)[C::EP]) {
+  if constexpr (C::SEMI == 1) {
+    mul_row<C>(cx, code, s);
+  } else {
+    double v[C::EP];
+    read_row<C>(cx, code, v);
+#pragma unroll
+    for (int i = 0; i < C::EP; ++i) s[i] = s[i] * v[i];
   }
 }
 
@@ -333,39 +353,36 @@ struct Op1 {
 struct Hot {
   const NodeRec *recs;
   const FeatOp *ops;
-  int n_ops, n_ops_padded;
+  int n_ops;
+  uint32_t op_row_bytes;   // bytes of one output row's ops (the host checks the table < 4 GiB)
 };
-__device__ __forceinline__ Op1 load_op1(const Hot &a, int64_t k, int i) {
-  cptr<int32_t> q = as_const(reinterpret_cast<const int32_t *>(
-      __builtin_assume_aligned(a.ops + (k * a.n_ops_padded + i), 32)));
+__device__ __forceinline__ Op1 load_op1(const Hot &a, uint32_t op_off) {
+  cptr<int32_t> q = at_offset(a.ops, op_off);
   Op1 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) o.w[j] = q[j];
   return o;
 }
 
-// The feature ops of every output row of a node: ONE code site for an op, the next op
-// requested while the current one is evaluated.
-template <class C>
-__device__ __forceinline__ void fops_all(WalkCtx &cx, const Hot &a, int ne, int64_t k, int pc,
-                                         const Op1 &pre, const double (&c)[C::EP],
-                                         const double (&x)[C::EP], const double (&s)[C::EP],
-                                         bool seq_steps) {
+// The feature ops of every output row of a node: ONE code site for an op; an op is loaded where
+// it is evaluated (its line was touched at the start of the node: a scalar-cache hit).
+template <class C, bool SEQ>
+__device__ __forceinline__ void fops_all(WalkCtx &cx, const Hot &a, int ne, uint32_t op_off,
+                                         uint32_t rec_off, const double (&c)[C::EP],
+                                         const double (&x)[C::EP], const double (&s)[C::EP]) {
   const int n = a.n_ops;
-  Op1 nx = pre;  // op 0 of the first row was requested at the start of the node
   FusedScratch<C::EP> sc;
   int slot = cx.fslot;   // window slot of (output row j, op i): fslot + j * n + i
   for (int j = 0;;) {
     for (int i = 0; i < n; ++i) {
-      const Op1 o = nx;
-      if (i + 1 < n) nx = load_op1(a, k, i + 1);
-      fop<C>(cx, o.w, slot + i, c, x, s, seq_steps, sc);
+      const Op1 o = load_op1(a, op_off + 32u * (uint32_t)i);
+      fop<C>(cx, o.w, slot + i, c, x, s, SEQ, sc);
     }
     if (++j >= ne) break;
     slot += n;
-    k = j == 1 ? (int64_t)rec_field(a.recs, pc, 8)
-               : (int64_t)as_const(cold_args()->emit_rows)[rec_field(a.recs, pc, 13) + j];
-    nx = load_op1(a, k, 0);
+    const int k = j == 1 ? rec_field(a.recs, rec_off, 8)
+                         : as_const(cold_args()->emit_rows)[rec_field(a.recs, rec_off, 13) + j];
+    op_off = (uint32_t)k * a.op_row_bytes;
   }
 }
 
@@ -424,7 +441,7 @@ __device__ __forceinline__ void frame_put(unsigned lv_bit, double (&f)[C::MAXLV]
 // Walks the records of one group (DFS order, sentinel at the end): per node the letters into
 // the prefix it continues (the frame of the level below; its own level's for an only child,
 // F_CHAIN), the scan, the feature ops, the hand-over to the children.
-template <class C>
+template <class C, bool TOTAL>
 __device__ __forceinline__ void fwalk(WalkCtx &cx, int node_begin, int &sink) {
   constexpr int EP = C::EP;
   Hot a;
@@ -435,25 +452,25 @@ __device__ __forceinline__ void fwalk(WalkCtx &cx, int node_begin, int &sink) {
     a.recs = reinterpret_cast<const NodeRec *>(uniform_ptr(ka.recs));
     a.ops = reinterpret_cast<const FeatOp *>(uniform_ptr(ka.ops));
     a.n_ops = __builtin_amdgcn_readfirstlane(ka.n_ops);
-    a.n_ops_padded = __builtin_amdgcn_readfirstlane(ka.n_ops_padded);
+    a.op_row_bytes = __builtin_amdgcn_readfirstlane(ka.n_ops_padded * 32);
   }
   double f[C::MAXLV][EP];
 #pragma unroll
   for (int k = 0; k < C::MAXLV; ++k)
 #pragma unroll
     for (int i = 0; i < EP; ++i) f[k][i] = 0.0;
-  int pc = node_begin;
-  Rec8 nd = load_rec8(a.recs, pc);
+  uint32_t rec_off = (uint32_t)node_begin * 64u;
+  int slot = 0;   // carry slots of the node: three per record of the group
+  Rec8 nd = load_rec8(a.recs, rec_off);
   while (nd.level() != kRecSentinelLevel) {
-    const int me = pc;
-    const int slot = kCarrySlots * (pc - node_begin);
-    ++pc;
+    const uint32_t me = rec_off;
+    rec_off += 64u;
     const int ne = nd.emit_count();
-    const int64_t k0 = nd.w[7];
+    const uint32_t op_off = (uint32_t)nd.w[7] * a.op_row_bytes;
     // the lines of the next record and of this node's ops, on their way to the scalar cache
-    const int t_rec = touch(a.recs + pc);
-    int t_ops = 0;
-    if (ne > 0) t_ops = touch(a.ops + k0 * a.n_ops_padded);
+    // (a node without output rows names row 0: a harmless touch)
+    const int t_rec = touch(a.recs, rec_off);
+    const int t_ops = touch(a.ops, op_off);
     feat_reserve<C>(cx, ne * a.n_ops);
     cx.slot = slot;
     const int nf = nd.fac_count(), flags = nd.flags(), lv = nd.level();
@@ -467,55 +484,52 @@ __device__ __forceinline__ void fwalk(WalkCtx &cx, int node_begin, int &sink) {
     } else {
       frame_mul<C, C::MAXLV - 1>(cx, rd_bit, nd.w[2], f, s);
       if (nf > 1) {
-        mul_row<C>(cx, nd.w[3], s);
-        if (nf > 2) mul_row<C>(cx, nd.w[4], s);
-        if (nf > 3) mul_row<C>(cx, nd.w[5], s);
+        mul_rowp<C>(cx, nd.w[3], s);
+        if (nf > 2) mul_rowp<C>(cx, nd.w[4], s);
+        if (nf > 3) mul_rowp<C>(cx, nd.w[5], s);
       }
     }
     const int w1 = nd.w[1];
-    const bool kids = (flags & F_CHILDREN) != 0;
     if (flags & F_NEED1) {
       double c[EP], x[EP];
       fscan<C>(cx, s, c, x, slot);
-      Op1 pre;
-      if (ne > 0) pre = load_op1(a, k0, 0);   // (a scalar-cache hit: its line was touched above)
       // Reals: children start from the exclusive shift; Arctic / Bayesian: from the inclusive
       // maximum (taken before the emitted values are rescaled)
-      if (kids && !(flags & F_NEED2)) {
+      if ((flags & (F_CHILDREN | F_NEED2)) == F_CHILDREN) {
         if constexpr (C::SEMI == 0) frame_put<C, C::MAXLV - 1>(lv_bit, f, x);
         else frame_put<C, C::MAXLV - 1>(lv_bit, f, c);
       }
-      if (ne > 0) {
-        // total weighting: the sieves see c * exp(-g alpha_k) (Arctic: c - g alpha_k)
-        const int emit_mul = ((w1 >> 24) & 0xff) - 1;
-        if (C::WEIGHTED && emit_mul >= 0)
-          mul_row<C>(cx, C::SEMI != 1 ? emit_mul : fac_arctic(emit_mul, -1), c);
-        if constexpr (C::TOTALINC) {
-          if (emit_mul >= 0) {
+      if (flags & F_EMIT) {
+        if constexpr (C::WEIGHTED && TOTAL) {
+          // total weighting: the sieves see c * exp(-g alpha_k) (Arctic: c - g alpha_k)
+          const int emit_mul = ((w1 >> 24) & 0xff) - 1;
+          mul_rowp<C>(cx, C::SEMI != 1 ? emit_mul : fac_arctic(emit_mul, -1), c);
+          if constexpr (C::TOTALINC) {
             double xs[EP];
             previous_weighted<C>(cx, emit_mul, x, xs);
-            fops_all<C>(cx, a, ne, k0, me, pre, c, xs, s, false);
+            fops_all<C, false>(cx, a, ne, op_off, me, c, xs, s);
           } else {
-            fops_all<C>(cx, a, ne, k0, me, pre, c, x, s, true);
+            fops_all<C, false>(cx, a, ne, op_off, me, c, x, s);
           }
         } else {
-          fops_all<C>(cx, a, ne, k0, me, pre, c, x, s, !(C::WEIGHTED && emit_mul >= 0));
+          fops_all<C, true>(cx, a, ne, op_off, me, c, x, s);
         }
       }
     }
     sink += t_rec + t_ops;
-    nd = load_rec8(a.recs, pc);   // (a scalar-cache hit; in flight over the second scan)
-    if constexpr (C::WEIGHTED) {
+    nd = load_rec8(a.recs, rec_off);   // (a scalar-cache hit; in flight over the second scan)
+    if constexpr (C::WEIGHTED && !TOTAL) {
       if (flags & F_NEED2) {
         // non-total weighting: the children continue from the scan of s * exp(+g alpha_k)
         const int z_mul = ((w1 >> 16) & 0xff) - 1;
         double c2[EP], x2[EP];
-        mul_row<C>(cx, C::SEMI != 1 ? z_mul : fac_arctic(z_mul, 1), s);
+        mul_rowp<C>(cx, C::SEMI != 1 ? z_mul : fac_arctic(z_mul, 1), s);
         fscan<C>(cx, s, c2, x2, slot + 1);
         if constexpr (C::SEMI == 0) frame_put<C, C::MAXLV - 1>(lv_bit, f, x2);
         else frame_put<C, C::MAXLV - 1>(lv_bit, f, c2);
       }
     }
+    slot += kCarrySlots;
   }
 }
 
@@ -597,7 +611,7 @@ __device__ __forceinline__ void stage_chunk(const WalkCtx &cx, const IssArgs &a,
 
 // LDS of the fused kernel: rows [R][CHUNK] | totals window [2][8] | tails [2][4] | carries
 // [carry_slots] (MULTI) | feature window (values, populations, columns)
-template <class C>
+template <class C, bool TOTAL>
 __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(4)))
 void iss_fused_kernel(const IssArgs a) {
   static_assert(C::MODE == 1 && C::TEAM == 4 && C::P == 1 && C::MULTI != 2, "fused configuration");
@@ -660,7 +674,7 @@ void iss_fused_kernel(const IssArgs a) {
     stage_chunk<C>(cx, a, n, t0, lds);
     __syncthreads();
     cx.fused_used = 0;  // same slots in every chunk
-    fwalk<C>(cx, node_begin, sink);
+    fwalk<C, TOTAL>(cx, node_begin, sink);
     // a unit whose features fit the window keeps them there over its time chunks; else every
     // chunk leaves its share (added onto the earlier chunks' in global memory)
     if (!a.feat_fits || chunk + 1 == a.nchunks) feat_flush<C>(cx, !a.feat_fits && chunk > 0);

@@ -23,6 +23,7 @@ constexpr int32_t F_CHILDREN = 2;  // the exclusive prefix of this node is consu
 // scan over s * exp(+g alpha) for the children
 constexpr int32_t F_NEED1 = 8;
 constexpr int32_t F_NEED2 = 16;
+constexpr int32_t F_EMIT = 32;     // the node has output rows
 // factor code: LDS row in the low 7 bits.  Reals: bit 7 = divide instead of multiply
 // (one code per occurrence of a letter).  Arctic: bits 8-15 = signed multiplier el of
 // the ADDED term el * row (one code per dimension of the extended letter).
@@ -142,6 +143,7 @@ struct IssArgs {
   int32_t cw_Lmax;
   int32_t lds_pad;          // experiments: extra dynamic LDS bytes per workgroup (fewer resident ones)
   int32_t total_inc;        // 1: totally weighted plan whose fused sieves difference (WalkCfg::TOTALINC)
+  int32_t total_weighting;  // 1: the plan's weighting is total (the fused walk is compiled per mode)
   int32_t nt_input;         // 1: stage the rows of X with non-temporal loads (interpreter, one group)
   int32_t static_prog;      // != 0: the records equal pre-compiled static program #n (walk_static_inst.hip)
   uint32_t k_stride_bytes32; // out_k_stride * 8 when that fits 32 bits (and is > 0), else 0
