@@ -1130,19 +1130,22 @@ int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
             }
             int idx = sv.cuts[j + 1] - 1;
             if (idx < 0) idx += (int)pl->T;  // numpy's wrap of index -1 (segment.py:213-218)
-            row.push_back(fr::FeatOp{FR_SIEVE_END, k * pl->per_sum + sv.col + j, idx, 0, 0.0, 0.0});
+            row.push_back(fr::FeatOp{FR_SIEVE_END | (1 << 20), k * pl->per_sum + sv.col + j, idx, 0, 0.0, 0.0});
           }
           continue;
         }
         const double *q = h_quant + (size_t)k * pl->q_stride + sv.q_off;
         for (int j = 0; j < C; ++j)
           for (int b = 0; b + 1 < sv.Q1; ++b) {
-            // what the epilogue may skip (walk_fused.h, OPF_*): the range test of a band over
-            // the whole series, the comparison with an infinite threshold
+            // the common shapes get a short path in the fused walk (walk_fused.h, OPF_SHAPE_*):
+            // a counting band over the whole series, of the values or their first differences,
+            // with or without an upper threshold
             int32_t flags = sv.series_cuts ? (1 << 16) : 0;
-            if (!sv.series_cuts && sv.cuts[j] <= 0 && sv.cuts[j + 1] >= pl->T) flags |= 1 << 17;
-            if (q[b + 1] == std::numeric_limits<double>::infinity()) flags |= 1 << 18;
-            if (q[b] == -std::numeric_limits<double>::infinity()) flags |= 1 << 19;
+            if (sv.kind == FR_SIEVE_NPI && !sv.series_cuts && sv.cuts[j] <= 0 &&
+                sv.cuts[j + 1] >= pl->T && (sv.inc == 0 || sv.inc == 1)) {
+              const bool no_hi = q[b + 1] == std::numeric_limits<double>::infinity();
+              flags |= ((no_hi ? 2 : 4) | sv.inc) << 20;
+            }
             row.push_back(fr::FeatOp{sv.kind | ((sv.inc & 0xff) << 8) | flags,
                                      k * pl->per_sum + sv.col + j * (sv.Q1 - 1) + b, sv.cuts[j],
                                      sv.cuts[j + 1], q[b], q[b + 1]});
@@ -1155,7 +1158,8 @@ int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
           if ((row[i].kind_inc & 0xff) != FR_SIEVE_NPI) continue;
           for (size_t m = 0; m < row.size(); ++m) {
             if ((row[m].kind_inc & 0xff) != FR_SIEVE_MPI || used[m]) continue;
-            if ((row[m].kind_inc >> 8) == (row[i].kind_inc >> 8) && row[m].lo == row[i].lo &&
+            // (same differencing order and kind of cuts; the shape bits above are the walk's)
+            if ((((row[m].kind_inc ^ row[i].kind_inc) >> 8) & 0x1ff) == 0 && row[m].lo == row[i].lo &&
                 row[m].hi == row[i].hi && std::memcmp(&row[m].qlo, &row[i].qlo, 8) == 0 &&
                 std::memcmp(&row[m].qhi, &row[i].qhi, 8) == 0) {
               drop[i] = used[m] = 1;

@@ -28,9 +28,11 @@ namespace fr {
 
 // feature-op flags (FeatOp::kind_inc), resolved by the host (capi.cpp, fr_pipeline_set_quantiles)
 constexpr int32_t OPF_SERIES_CUTS = 1 << 16;
-constexpr int32_t OPF_FULL_RANGE = 1 << 17;   // lo <= 0 and hi >= T: every element of the series
-constexpr int32_t OPF_NO_HI = 1 << 18;        // qhi = +inf
-constexpr int32_t OPF_NO_LO = 1 << 19;        // qlo = -inf
+// bits 20-22: the op's SHAPE when it is one of the common ones (0: none of them)
+constexpr int OPF_SHAPE_SHIFT = 20;
+constexpr int OPF_SHAPE_END = 1;     // END at a fixed index (lo)
+constexpr int OPF_SHAPE_BAND1 = 2;   // NPI over the whole series, qlo < v (qhi = +inf); | 1: of the first differences
+constexpr int OPF_SHAPE_BAND2 = 4;   // NPI over the whole series, qlo < v <= qhi;       | 1: of the first differences
 
 // Table reads of the node loop: base pointer + unsigned 32-bit BYTE offset (one scalar load with
 // a register offset; a 64-bit index costs five scalar instructions of address arithmetic).
@@ -219,33 +221,17 @@ __device__ __forceinline__ double pick_uniform(int eu, const double (&c)[E]) {
   }
 }
 
-// Band count (and sum) of the differenced values d of one op; the three shapes the host flags
-// are separate straight-line loops.
+// END at a position the host resolved (no per-series cut): the value at series index `pick`
 template <class C>
-__device__ __forceinline__ void band_count(const WalkCtx &cx, int flags, int lo, int hi, double qlo,
-                                           double qhi, const double (&d)[C::EP], bool want_sum,
-                                           int &cnt, double &sum) {
+__device__ __forceinline__ void end_pick(WalkCtx &cx, int pick, int slot, const double (&c)[C::EP]) {
   constexpr int E = C::E;
-  const int t_first = (int)cx.t0 + cx.wave * C::SPAN + cx.lane * E;
-  cnt = 0;
-  sum = 0.0;
-  const bool whole = (flags & OPF_FULL_RANGE) && cx.full_chunk;
-  if (whole && (flags & OPF_NO_HI) && !want_sum) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) cnt += __popcll(__ballot(qlo < d[e]));
-  } else if (whole && !want_sum) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) cnt += __popcll(__ballot(qlo < d[e] && d[e] <= qhi));
-  } else {
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const int t = t_first + e;
-      const double v = d[e];
-      const bool in = t >= lo && t < hi && qlo < v && v <= qhi;
-      cnt += __popcll(__ballot(in));
-      if (want_sum) sum += in ? v : 0.0;
-    }
-  }
+  const unsigned rel = (unsigned)(pick - (int)cx.t0);
+  if (rel >= (unsigned)C::CHUNK) return;           // another time chunk's element
+  if ((int)(rel / C::SPAN) != cx.wave) return;     // another wave's
+  // the position is uniform: uniform selects of the register, ONE lane stores
+  const unsigned q = rel % C::SPAN;
+  const double v = pick_uniform<E, 0>((int)(q % E), c);
+  lds_store_lane((int)(q / E), lds_offset(cx.fl_val + slot), v);
 }
 
 template <class C>
@@ -253,11 +239,46 @@ __device__ __forceinline__ void fop(WalkCtx &cx, const int32_t *w, int slot, con
                                     const double (&x)[C::EP], const double (&s)[C::EP],
                                     bool seq_steps, FusedScratch<C::EP> &sc) {
   constexpr int E = C::E;
-  const int kind = w[0] & 0xff, inc = (int)(int8_t)((w[0] >> 8) & 0xff), col = w[1];   // inc: signed
+  // (the flush needs the column of every slot, also of one no lane adds to)
+  if (cx.wave == 0) lds_store_lane0_i32(lds_offset(cx.fl_col + slot), w[1]);
+  // The shapes the host flags (OPF_SHAPE_*: END at a fixed index; a counting band over the whole
+  // series, of the values or of their first differences, with or without an upper threshold)
+  // are short straight-line paths; everything else takes the general one below.
+  const int shape = (w[0] >> OPF_SHAPE_SHIFT) & 7;
+  if (shape == OPF_SHAPE_END) {
+    end_pick<C>(cx, w[2], slot, c);
+    return;
+  }
+  if (shape != 0 && cx.full_chunk) {
+    const double qlo = bits_to_double(w[4], w[5]);
+    double d[E];
+    if (shape & 1) {   // first differences
+#pragma unroll
+      for (int i = 0; i < E; ++i) {
+        double step = c[i] - x[i];
+        if (C::SEMI == 0 && seq_steps) step = (x[i] + s[i]) - x[i];
+        d[i] = step;
+      }
+      // element 0 of the series: increments are zero-padded there (fruits/cache.py:8-13)
+      d[0] = (cx.first_chunk && cx.wave == 0 && cx.lane == 0) ? 0.0 : d[0];
+    } else {
+#pragma unroll
+      for (int i = 0; i < E; ++i) d[i] = c[i];
+    }
+    int cnt = 0;
+    if (shape >= OPF_SHAPE_BAND2) {
+      const double qhi = bits_to_double(w[6], w[7]);
+#pragma unroll
+      for (int e = 0; e < E; ++e) cnt += __popcll(__ballot(qlo < d[e] && d[e] <= qhi));
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) cnt += __popcll(__ballot(qlo < d[e]));
+    }
+    lds_add_lane0(lds_offset(cx.fl_val + slot), (double)cnt);
+    return;
+  }
+  const int kind = w[0] & 0xff, inc = (int)(int8_t)((w[0] >> 8) & 0xff);   // inc: signed
   const bool series_cuts = (w[0] & OPF_SERIES_CUTS) != 0;
-  // (the flush needs the column of every slot, also of one no lane adds to; every wave
-  // writes the same word - cheaper than asking which wave is first)
-  lds_store_lane0_i32(lds_offset(cx.fl_col + slot), col);
   if (kind == FR_SIEVE_END_K) {
     int pick = w[2];                    // index of the value to pick
     if (series_cuts) {                  // X[:, cut - 1], index -1 wrapping like numpy
@@ -265,17 +286,7 @@ __device__ __forceinline__ void fop(WalkCtx &cx, const int32_t *w, int slot, con
       pick = as_const(ca->series_cuts + cx.series * ca->cut_slots)[w[2]] - 1;
       if (pick < 0) pick += (int)ca->T;
     }
-    const int rel = pick - (int)cx.t0;
-    if (rel >= 0 && rel < C::CHUNK) {
-      const int wv = rel / C::SPAN;
-      if (cx.wave == wv) {
-        // the position is uniform: uniform selects of the register, ONE lane stores
-        const int q = rel - wv * C::SPAN;
-        const int owner = q / E, eu = q - owner * E;
-        const double v = pick_uniform<E, 0>(eu, c);
-        lds_store_lane(owner, lds_offset(cx.fl_val + slot), v);
-      }
-    }
+    end_pick<C>(cx, pick, slot, c);
     return;
   }
   int lo = w[2], hi = w[3];
@@ -333,16 +344,25 @@ __device__ __forceinline__ void fop(WalkCtx &cx, const int32_t *w, int slot, con
       }
     }
   }
-  int cnt;
-  double sum;
   const bool mpi = kind == FR_SIEVE_MPI_K;
-  band_count<C>(cx, w[0], lo, hi, qlo, qhi, d, mpi, cnt, sum);
-  if (mpi) sum = wave_inclusive_scan<0>(sum);  // lane 63 holds the wave total
+  const int t_first = (int)cx.t0 + cx.wave * C::SPAN + cx.lane * E;
+  int cnt = 0;
+  double sum = 0.0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int t = t_first + e;
+    const double v = d[e];
+    const bool in = t >= lo && t < hi && qlo < v && v <= qhi;
+    cnt += __popcll(__ballot(in));
+    if (mpi) sum += in ? v : 0.0;
+  }
   // one LDS add per wave (ds_add_f64, nothing returned)
-  if (mpi)
+  if (mpi) {
+    sum = wave_inclusive_scan<0>(sum);  // lane 63 holds the wave total
     lds_add2_lane63(lds_offset(cx.fl_val + slot), sum, lds_offset(cx.fl_cnt + slot), (double)cnt);
-  else
+  } else {
     lds_add_lane0(lds_offset(cx.fl_val + slot), (double)cnt);
+  }
 }
 
 // one feature op (32 bytes = one s_load_dwordx8)
