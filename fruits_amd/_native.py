@@ -614,6 +614,11 @@ def coswiss_combine(terms_d, begin_d, coeff_d, desc_d, trig_d, out, out_row_stri
     return out
 
 
+def release_scratch() -> None:
+    """Frees the grow-only device scratch of fr_select_ranks (kept between the calls of one fit)."""
+    check(lib().fr_release_scratch(), "fr_release_scratch")
+
+
 def nan_to_num(xd):
     """In place np.nan_to_num(x, nan=0.0) of a contiguous float64 device tensor."""
     if not xd.is_contiguous():

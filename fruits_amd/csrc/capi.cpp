@@ -31,7 +31,7 @@ struct Scratch {
   size_t bytes = 0;
 };
 constexpr int kScratchDevices = 64;
-std::mutex g_scratch_mu;
+std::mutex g_scratch_mu[kScratchDevices];   // one per device: fits on different devices do not queue
 Scratch g_scratch[kScratchDevices];
 
 int fail(int code, const std::string &msg) {
@@ -338,7 +338,14 @@ void ensure_jit(fr::Plan &p) {
     }
     std::string code, err;
     fr::JitProgram prog;
-    if (!fr::jit_compile(sc, code, err) || !fr::jit_load(code, sc, prog, err)) {
+    bool from_cache = false;
+    bool ok = fr::jit_compile(sc, code, err, &from_cache) && fr::jit_load(code, sc, prog, err);
+    if (!ok && from_cache) {
+      // a cached code object the loader refuses (another ROCm, a damaged file): compile afresh
+      fr::jit_cache_drop(sc);
+      ok = fr::jit_compile(sc, code, err) && fr::jit_load(code, sc, prog, err);
+    }
+    if (!ok) {
       js.error = err;
       return;
     }
@@ -1521,7 +1528,7 @@ int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32
   const size_t need = align_up(o_cand + (size_t)n_dev * fr::kSelSmallCap * 8, 256);
   const int dev = current_device_id();
   if (dev < 0 || dev >= kScratchDevices) return fail(FR_E_ARG, "fr_select_ranks: device id");
-  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  std::lock_guard<std::mutex> lock(g_scratch_mu[dev]);
   Scratch &sc = g_scratch[dev];
   if (sc.bytes < need) {
     if (sc.ptr) (void)hipFree(sc.ptr);
@@ -1568,8 +1575,8 @@ int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32
 }
 
 int fr_release_scratch(void) {
-  std::lock_guard<std::mutex> lock(g_scratch_mu);
   for (int d = 0; d < kScratchDevices; ++d) {
+    std::lock_guard<std::mutex> lock(g_scratch_mu[d]);
     if (g_scratch[d].ptr) (void)hipFree(g_scratch[d].ptr);
     g_scratch[d] = Scratch{};
   }

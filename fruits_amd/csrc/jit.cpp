@@ -7,13 +7,18 @@
 // and compiled for gfx950 with the flags of the ahead-of-time units (-ffp-contract=off: results
 // stay bit-identical to the interpreter's).  hipRTC is loaded with dlopen: without it the plan
 // simply keeps running on the interpreter.  Compiled code objects are cached on disk
-// (FRUITS_HIP_JIT_CACHE, default ~/.cache/fruits_amd/jit) keyed by a hash of the source.
+// (FRUITS_HIP_JIT_CACHE, default ~/.cache/fruits_amd/jit): the file name hashes the source, the
+// compile options and the hipRTC version; the file carries a header (magic, format, sizes, a
+// hash of the payload) that is checked on every read; a cached object that fails to load is
+// deleted and compiled again; the directory is private (0700) and only files the user owns, in a
+// directory only the user can write, are trusted - a code object is executable input.
 #include "jit.h"
 
 #include <dlfcn.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -44,6 +49,7 @@ struct Rtc {
   int (*code_size)(void *, size_t *) = nullptr;
   int (*code)(void *, char *) = nullptr;
   int (*destroy)(void **) = nullptr;
+  int (*version)(int *, int *) = nullptr;
   bool ok = false;
 };
 
@@ -72,6 +78,7 @@ Rtc &rtc() {
     r.code_size = reinterpret_cast<decltype(r.code_size)>(sym("hiprtcGetCodeSize"));
     r.code = reinterpret_cast<decltype(r.code)>(sym("hiprtcGetCode"));
     r.destroy = reinterpret_cast<decltype(r.destroy)>(sym("hiprtcDestroyProgram"));
+    r.version = reinterpret_cast<decltype(r.version)>(sym("hiprtcVersion"));
     r.ok = r.create && r.add_name && r.compile && r.log_size && r.log && r.lowered &&
            r.code_size && r.code && r.destroy;
   });
@@ -99,9 +106,83 @@ std::string cache_dir() {
   return base + "/fruits_amd/jit";
 }
 
-void make_dirs(const std::string &path) {
+// Creates the directory chain privately; true when `path` then is a directory the user owns and
+// nobody else can write to.
+bool private_dir(const std::string &path) {
   for (size_t i = 1; i <= path.size(); ++i)
-    if (i == path.size() || path[i] == '/') (void)mkdir(path.substr(0, i).c_str(), 0755);
+    if (i == path.size() || path[i] == '/') (void)mkdir(path.substr(0, i).c_str(), 0700);
+  struct stat st;
+  if (stat(path.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+  return st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+
+const char *kCompileOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+constexpr int kNumCompileOptions = 4;
+
+// what a cached object depends on besides the source text
+std::string toolchain_tag() {
+  std::string t;
+  for (const char *o : kCompileOptions) t += std::string(o) + ";";
+  Rtc &r = rtc();
+  int major = 0, minor = 0;
+  if (r.ok && r.version && r.version(&major, &minor) == 0)
+    t += "hiprtc " + std::to_string(major) + "." + std::to_string(minor);
+  else
+    t += "hiprtc ?";
+  return t;
+}
+
+// Disk format: header, then the payload jit_load takes (code object, lowered kernel name, the
+// name's length).
+struct CacheHeader {
+  char magic[8];            // "FRJITCO\1"
+  uint32_t format;          // 1
+  uint32_t reserved;
+  uint64_t payload_bytes;
+  uint64_t payload_hash;    // FNV-1a of the payload
+};
+const char kCacheMagic[8] = {'F', 'R', 'J', 'I', 'T', 'C', 'O', 1};
+
+bool read_cached(const std::string &file, std::string &payload) {
+  struct stat st;
+  if (stat(file.c_str(), &st) != 0 || !S_ISREG(st.st_mode) || st.st_uid != geteuid()) return false;
+  std::ifstream f(file, std::ios::binary);
+  if (!f) return false;
+  std::stringstream ss;
+  ss << f.rdbuf();
+  const std::string all = ss.str();
+  CacheHeader h;
+  if (all.size() < sizeof h) return false;
+  std::memcpy(&h, all.data(), sizeof h);
+  if (std::memcmp(h.magic, kCacheMagic, 8) != 0 || h.format != 1 ||
+      h.payload_bytes != all.size() - sizeof h || h.payload_bytes < 8)
+    return false;
+  payload = all.substr(sizeof h);
+  return fnv1a(payload) == h.payload_hash;
+}
+
+void write_cached(const std::string &dir, const std::string &file, const std::string &payload) {
+  if (!private_dir(dir)) return;
+  CacheHeader h{};
+  std::memcpy(h.magic, kCacheMagic, 8);
+  h.format = 1;
+  h.payload_bytes = payload.size();
+  h.payload_hash = fnv1a(payload);
+  const std::string tmp = file + ".tmp" + std::to_string((long long)getpid());
+  std::ofstream f(tmp, std::ios::binary);
+  if (!f) return;
+  f.write(reinterpret_cast<const char *>(&h), sizeof h);
+  f.write(payload.data(), (std::streamsize)payload.size());
+  f.close();
+  if (!f || rename(tmp.c_str(), file.c_str()) != 0) (void)remove(tmp.c_str());
+}
+
+std::string cache_file(const std::string &src, std::string &dir) {
+  dir = cache_dir();
+  if (dir.empty()) return std::string();
+  char key[32];
+  snprintf(key, sizeof key, "%016llx", fnv1a(src + "\n//" + toolchain_tag()));
+  return dir + "/" + key + ".gfx950.co";
 }
 
 }  // namespace
@@ -131,24 +212,28 @@ std::string jit_source(const StaticSchedule &sc) {
   return o.str();
 }
 
-bool jit_compile(const StaticSchedule &sc, std::string &code, std::string &err) {
+void jit_cache_drop(const StaticSchedule &sc) {
+  if (!sc.ok) return;
+  std::string dir;
+  const std::string file = cache_file(jit_source(sc), dir);
+  if (!file.empty()) (void)remove(file.c_str());
+}
+
+bool jit_compile(const StaticSchedule &sc, std::string &code, std::string &err, bool *from_cache) {
+  if (from_cache) *from_cache = false;
   if (!sc.ok) {
     err = "the plan has no static schedule";
     return false;
   }
   const std::string src = jit_source(sc);
-  char key[32];
-  snprintf(key, sizeof key, "%016llx", fnv1a(src));
-  const std::string dir = cache_dir();
-  const std::string file = dir.empty() ? std::string() : dir + "/" + key + ".gfx950.co";
+  std::string dir;
+  const std::string file = cache_file(src, dir);
   if (!file.empty()) {
-    std::ifstream f(file, std::ios::binary);
-    if (f) {
-      std::stringstream ss;
-      ss << f.rdbuf();
-      code = ss.str();
-      if (!code.empty()) return true;
+    if (read_cached(file, code)) {
+      if (from_cache) *from_cache = true;
+      return true;
     }
+    code.clear();
   }
   Rtc &r = rtc();
   if (!r.ok) {
@@ -161,10 +246,9 @@ bool jit_compile(const StaticSchedule &sc, std::string &code, std::string &err) 
     return false;
   }
   bool ok = false;
-  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
   if (r.add_name(prog, kKernelExpr) != 0) {
     err = "hiprtcAddNameExpression failed";
-  } else if (r.compile(prog, 4, opts) != 0) {
+  } else if (r.compile(prog, kNumCompileOptions, kCompileOptions) != 0) {
     size_t n = 0;
     r.log_size(prog, &n);
     std::string log(n, '\0');
@@ -188,16 +272,7 @@ bool jit_compile(const StaticSchedule &sc, std::string &code, std::string &err) 
     }
   }
   r.destroy(&prog);
-  if (ok && !file.empty()) {
-    make_dirs(dir);
-    const std::string tmp = file + ".tmp" + std::to_string((long long)getpid());
-    std::ofstream f(tmp, std::ios::binary);
-    if (f) {
-      f.write(code.data(), (std::streamsize)code.size());
-      f.close();
-      if (rename(tmp.c_str(), file.c_str()) != 0) (void)remove(tmp.c_str());
-    }
-  }
+  if (ok && !file.empty()) write_cached(dir, file, code);
   return ok;
 }
 
@@ -247,7 +322,17 @@ hipError_t jit_launch(const JitProgram &p, const IssArgs &a, hipStream_t st) {
   const int64_t units = a.N * p.groups;
   if (units <= 0) return hipSuccess;
   if (units > 0x7fffffffLL || a.G != p.groups) return hipErrorInvalidValue;
-  int64_t resident = (int64_t)p.per_cu * device_cu_count();
+  // (the resident count of the grid as launched: with the launch's own LDS pad)
+  int per_cu = p.per_cu;
+  if (a.lds_pad != 0 && a.persistent) {
+    int nb = 0;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, p.fn, kWalkThreads,
+                                                           p.lds_bytes + (size_t)a.lds_pad) == hipSuccess && nb >= 1)
+      per_cu = nb;
+    else
+      (void)hipGetLastError();
+  }
+  int64_t resident = (int64_t)per_cu * device_cu_count();
   resident -= resident % 8;
   if (resident < 8) resident = 8;
   const int64_t blocks = (units < resident || !a.persistent) ? units : resident;

@@ -23,7 +23,11 @@ struct JitProgram {
 std::string jit_source(const StaticSchedule &sc);
 // Compiles `sc` for gfx950 (code object in `code`); false + `err` when hipRTC is missing or
 // the compilation fails.  Needs no GPU.
-bool jit_compile(const StaticSchedule &sc, std::string &code, std::string &err);
+// `from_cache`: set when the code object came from the disk cache (a caller whose load of it
+// fails drops the file - jit_cache_drop - and compiles again).
+bool jit_compile(const StaticSchedule &sc, std::string &code, std::string &err,
+                 bool *from_cache = nullptr);
+void jit_cache_drop(const StaticSchedule &sc);
 // Loads a compiled program on the current device.
 bool jit_load(const std::string &code, const StaticSchedule &sc, JitProgram &out, std::string &err);
 void jit_unload(JitProgram &p);

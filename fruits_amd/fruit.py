@@ -90,6 +90,9 @@ class Fruit:
         cache_ = SharedSeedCache(X) if cache is None else cache
         for slc in self._slices:
             slc.fit(X, cache=cache_)
+        # (the selection scratch of the device-side fit lives outside torch's allocator: hand it
+        # back - a transform needs none of it)
+        nat.release_scratch()
         self._fitted = True
 
     def transform(self, X: np.ndarray,
@@ -188,91 +191,74 @@ class Fruit:
         return self.get_slice(index)
 
 
+# The three stages of a slice, in pipeline order: (name of the stage's list, what may be added to
+# it, the suffix of its add_ / get_ / clear_ verbs; fruits/fruit.py:280-429 is the contract - the
+# verbs, what they accept and raise).  Everything a slice derives from its configuration (the
+# fitted sieve copies, fused pipelines) is dropped whenever a stage changes.
+_STAGES = (
+    ("preparateurs", Preparateur, "preparateur", "preparateurs"),
+    ("iss", ISS, "iss", "iss"),
+    ("sieves", FeatureSieve, "sieve", "sieves"),
+)
+
+
 class FruitSlice:
     """One slice: preparateurs -> (chained) ISS -> sieves."""
 
     def __init__(self) -> None:
-        self._preparateurs: list[Preparateur] = []
-        self._iss: list[ISS] = []
-        self._sieves: list[FeatureSieve] = []
+        self._stage: dict[str, list[Seed]] = {name: [] for name, *_ in _STAGES}
+        self.fit_sample_size: Union[float, int] = 1
+        self._invalidate()
+
+    def _invalidate(self) -> None:
         # one list of fitted sieve copies per iterated sum
         self._sieves_extended: list[list[FeatureSieve]] = []
+        self._fused_cache: dict = {}
         self._fitted: bool = False
-        self.fit_sample_size: Union[float, int] = 1
+
+    # the stage lists under the names the rest of the slice reads them by
+    _preparateurs = property(lambda self: self._stage["preparateurs"])
+    _iss = property(lambda self: self._stage["iss"])
+    _sieves = property(lambda self: self._stage["sieves"])
 
     # ---- configuration ------------------------------------------------------
-    def add_preparateur(self, preparateur: Preparateur) -> None:
-        if not isinstance(preparateur, Preparateur):
+    def _put(self, stage: str, accepts: type, seed: Seed) -> None:
+        if not isinstance(seed, accepts):
             raise TypeError
-        self._preparateurs.append(preparateur)
-        self._fitted = False
+        self._stage[stage].append(seed)
+        self._invalidate()
 
-    def get_preparateurs(self) -> list[Preparateur]:
-        return self._preparateurs
-
-    def clear_preparateurs(self) -> None:
-        self._preparateurs = []
-        self._fitted = False
-
-    def add_iss(self, iss: ISS) -> None:
-        if not isinstance(iss, ISS):
-            raise TypeError
-        self._iss.append(iss)
-        self._fitted = False
-
-    def get_iss(self) -> list[ISS]:
-        return self._iss
-
-    def clear_iss(self) -> None:
-        self._iss = []
-        self._sieves_extended = []
-        self._fitted = False
-
-    def add_sieve(self, sieve: FeatureSieve) -> None:
-        if not isinstance(sieve, FeatureSieve):
-            raise TypeError
-        self._sieves.append(sieve)
-        self._fitted = False
-
-    def get_sieves(self) -> list[FeatureSieve]:
-        return self._sieves
-
-    def clear_sieves(self) -> None:
-        self._sieves = []
-        self._sieves_extended = []
-        self._fitted = False
+    def _wipe(self, stage: str) -> None:
+        self._stage[stage] = []
+        self._invalidate()
 
     def add(self, *objects: Union[Seed, Callable[[], Seed]]) -> None:
+        """Appends seeds (instances, or classes to be instantiated without arguments) to the
+        stage each belongs to."""
         for obj in objects:
-            if inspect.isclass(obj):
-                obj = obj()
-            if isinstance(obj, Preparateur):
-                self.add_preparateur(obj)
-            elif isinstance(obj, ISS):
-                self.add_iss(obj)
-            elif isinstance(obj, FeatureSieve):
-                self.add_sieve(obj)
+            seed = obj() if inspect.isclass(obj) else obj
+            for stage, accepts, _, _ in _STAGES:
+                if isinstance(seed, accepts):
+                    self._put(stage, accepts, seed)
+                    break
             else:
-                raise TypeError(f"Cannot add variable of type {type(obj)}")
+                raise TypeError(f"Cannot add variable of type {type(seed)}")
 
     def clear(self) -> None:
-        self.clear_preparateurs()
-        self.clear_iss()
-        self.clear_sieves()
-        self.iss_mode = "single"
+        for stage, *_ in _STAGES:
+            self._wipe(stage)
         self.fit_sample_size = 1
-
-    def nfeatures(self) -> int:
-        return sum(s.nfeatures() for s in self._sieves) * self.niteratedsums()
 
     def niteratedsums(self) -> int:
         return int(np.prod([iss.n_iterated_sums() for iss in self._iss]))
 
+    def nfeatures(self) -> int:
+        return self.niteratedsums() * sum(sieve.nfeatures() for sieve in self._sieves)
+
     def _compile(self) -> None:
-        if not self._iss:
-            raise RuntimeError("No ISS given")
-        if not self._sieves:
-            raise RuntimeError("No feature sieves given")
+        for stage, what in (("iss", "ISS"), ("sieves", "feature sieves")):
+            if not self._stage[stage]:
+                raise RuntimeError(f"No {what} given")
 
     def _select_fit_sample(self, X: np.ndarray) -> np.ndarray:
         # same draws from numpy's global generator as the reference
@@ -387,8 +373,6 @@ class FruitSlice:
         the fused set; cached until the next fit.  ``indices``: only these words
         (a rank's share of a word-sharded slice, fruits_amd.parallel); the pipeline
         then produces the feature columns of their iterated sums, in that order."""
-        if not hasattr(self, "_fused_cache"):
-            self._fused_cache = {}
         key = T if indices is None else (T, tuple(indices))
         if key in self._fused_cache:
             return self._fused_cache[key]
@@ -422,13 +406,13 @@ class FruitSlice:
             for sv in acting:
                 inc = 0 if type(sv) is END else sv._inc
                 if sv._has_float_cuts():
-                    key = (tuple(sv._cut), sv._coquantile_norm)
-                    if key not in cut_columns:
-                        cut_columns[key] = (n_slots, sv)
+                    cuts_key = (tuple(sv._cut), sv._coquantile_norm)
+                    if cuts_key not in cut_columns:
+                        cut_columns[cuts_key] = (n_slots, sv)
                         n_slots += len(sv._cut) + 1
-                    first = cut_columns[key][0]
+                    slot0 = cut_columns[cuts_key][0]
                     specs.append((sv._kind | nat.FR_SIEVE_SERIES_CUTS, inc,
-                                  np.arange(first, first + len(sv._cut) + 1), len(sv._q)))
+                                  np.arange(slot0, slot0 + len(sv._cut) + 1), len(sv._q)))
                 else:
                     specs.append((sv._kind, inc, sv._int_cut_row(T), len(sv._q)))
             try:
@@ -449,7 +433,7 @@ class FruitSlice:
                         quant[k, off:off + len(sv._q)] = sv._quantiles
                         off += len(sv._q)
                 pipe.set_quantiles(quant)
-                pipe._cut_columns = [(first, sv) for first, sv in cut_columns.values()]
+                pipe._cut_columns = [(slot0, sv) for slot0, sv in cut_columns.values()]
                 pipe._cut_slots = n_slots
                 entry = pipe
         self._fused_cache[key] = entry
@@ -492,10 +476,19 @@ class FruitSlice:
             std, eps = (2 if p._div_std else 1), float(p._eps)
         if preps or (lag == 0 and std == 0):
             return None
-        for iss in self._iss:            # a weighting computed from the PREPARED input needs it
+        # The lookup of a weighting is computed from what the ISS is handed
+        # (fruits/iss/weighting.py:65-66) - the PREPARED input, which a fused preparation never
+        # writes.  Safe are only weightings that do not look at the data (Indices, Plateaus) and
+        # path lengths of the cache's RAW input; a Custom function, or any user subclass, gets
+        # the materialised preparation.
+        from .iss.weighting import _PathLength, _SeriesIndependent
+        for iss in self._iss:
             w = getattr(iss, "weighting", None)
-            if w is not None and getattr(w, "_on_prepared", False):
-                return None
+            if w is None or isinstance(w, _SeriesIndependent):
+                continue
+            if isinstance(w, _PathLength) and not w._on_prepared:
+                continue
+            return None
         return lag, as_new, std, eps
 
     def _attach(self, cache) -> None:
@@ -673,3 +666,24 @@ class FruitSlice:
                 return text + sieve.label(findex)
             findex -= sieve.nfeatures()
         raise RuntimeError("Feature index out of range")
+
+
+def _stage_verbs(stage: str, accepts: type, one: str, many: str) -> None:
+    """add_<one> / get_<many> / clear_<many> of one stage of a slice."""
+    def add(self, seed) -> None:
+        self._put(stage, accepts, seed)
+
+    def get(self) -> list:
+        return self._stage[stage]
+
+    def clear(self) -> None:
+        self._wipe(stage)
+
+    for verb, fn in ((f"add_{one}", add), (f"get_{many}", get), (f"clear_{many}", clear)):
+        fn.__name__ = fn.__qualname__ = verb
+        setattr(FruitSlice, verb, fn)
+
+
+for _row in _STAGES:
+    _stage_verbs(*_row)
+

@@ -174,12 +174,12 @@ class CosWISS(ISS):
         before a run of the plan itself or of a fused pipeline built on it."""
         if self._dropout is None or self._ffn_size is not None:
             return
-        if T != self._dropout_T:
-            raise IndexError(f"the dropout indices were drawn for series of length "
-                             f"{self._dropout_T}, the input has {T}")
-        if getattr(plan, "_dropout_set", None) is not self._dropout_indices:
+        # The reference zeroes tmp[dropout[k]] (fruits/iss/cos.py:84) whatever the length of the
+        # series: indices drawn on the fit's length work on any input they fit into, and only one
+        # beyond the input's end is an IndexError (raised while the mask for T is built).
+        if getattr(plan, "_dropout_set", None) != (id(self._dropout_indices), T):
             nat.coswiss_set_dropout(plan, self._dropout_indices[list(idx)], T)
-            plan._dropout_set = self._dropout_indices
+            plan._dropout_set = (id(self._dropout_indices), T)
 
     def _n_terms(self, w: int) -> int:
         p = len(self.words[w]) + 1 if self._total_weighting else len(self.words[w])

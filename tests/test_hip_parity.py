@@ -882,8 +882,15 @@ def test_coswiss_dropout_fused_and_long(fr, monkeypatch, T):
     np.testing.assert_allclose(fused[:, 1::2], ref[:, :, -1].T, rtol=RTOL, atol=1e-9)
     np.testing.assert_allclose(plain[:, 1::2], ref[:, :, -1].T, rtol=RTOL, atol=1e-9)
     rowwise_close(fitted.transform(X), ref)
+    # indices drawn on the fit's length apply to any series they fit into
+    # (tmp[dropout[k]] = 0, fruits/iss/cos.py:84); one beyond the input's end is an IndexError
+    longer = np.concatenate([X, X[:, :, :7]], axis=2)
+    rowwise_close(fitted.transform(longer),
+                  orc.coswiss_transform(longer, words, [0.25, 0.5], 2, True,
+                                        dropout_indices=fitted._dropout_indices))
+    assert fitted._dropout_indices.max() >= T // 2
     with pytest.raises(IndexError):
-        fitted.transform(X[:, :, :T - 1].copy())
+        fitted.transform(X[:, :, :T // 2].copy())
 
 
 def test_coswiss_unsupported(fr):
@@ -1177,6 +1184,59 @@ def test_fused_preparation(fr, monkeypatch, chain, T):
     np.testing.assert_allclose(got, plain, rtol=1e-12, atol=1e-300)
     ref, expo = oracle_features(spec, X, X, np_seed=1)
     compare_features(got, ref, labels, expo, what=f"fused preparation {chain} T={T}")
+
+
+@pytest.mark.parametrize("prep", ["INC", "STD"])
+def test_custom_weighting_sees_the_prepared_input(fr, monkeypatch, prep):
+    """A Custom weighting (or any user subclass) builds its lookup from what the ISS is handed -
+    the PREPARED input (fruits/iss/weighting.py:65-66): behind INC / STD such a slice must not
+    take the fused preparation (which never writes the prepared tensor).  Fused launch vs the
+    materialised preparation vs the unfused path, all the same features."""
+    T = 600
+    rng = np.random.default_rng(77)
+    X = rng.standard_normal((9, 2, T)).cumsum(axis=2) / 5.0
+
+    def build():
+        fruit = fr.Fruit("custom")
+        fruit.add(fr.preparation.INC if prep == "INC" else fr.preparation.STD)
+        h = lambda Z: np.cumsum(np.abs(Z[:, 0, :]), axis=1) / (1.0 + np.abs(Z[:, 0, :]).sum(axis=1, keepdims=True))
+        fruit.add(fr.ISS(fr.words.of_weight(2, dim=2), mode=fr.ISSMode.EXTENDED,
+                         weighting=fr.iss.weighting.Custom(h)))
+        fruit.add(fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END)
+        fruit.get_slice().fit_sample_size = 1.0
+        np.random.seed(3)
+        fruit.fit(X)
+        return fruit
+    fruit = build()
+    got = fruit.transform(X)
+    assert fruit.get_slice()._fusable_preparation(T) is None
+    assert fruit.get_slice()._fused(T).raw_dims == 0
+    monkeypatch.setenv("FRUITS_AMD_FUSED_PREP", "0")
+    np.testing.assert_array_equal(got, build().transform(X))
+    monkeypatch.setenv("FRUITS_AMD_FUSED", "0")
+    plain = build().transform(X)
+    labels = [fruit.label(i) for i in range(fruit.nfeatures())]
+    compare_features(got, plain, labels, what=f"custom weighting behind {prep}")
+
+
+def test_fused_pipeline_is_cached_per_length(fr):
+    """FruitSlice._fused keeps ONE pipeline per series length until the next fit - also for a
+    slice with float (coquantile) cuts, whose cut columns must not replace the cache key."""
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((8, 1, 520)).cumsum(axis=2)
+    fruit = fr.Fruit("cache")
+    fruit.add(fr.preparation.INC, fr.ISS(fr.words.of_weight(2, dim=1), mode=fr.ISSMode.EXTENDED))
+    fruit.add(fr.sieving.NPI(cut=[0.3, -1], q=(0.5, 1.0)), fr.sieving.END(cut=[0.5, -1]))
+    fruit.get_slice().fit_sample_size = 1.0
+    np.random.seed(0)
+    fruit.fit(X)
+    slc = fruit.get_slice()
+    first = slc._fused(520)
+    assert first is not None and slc._fused(520) is first
+    fruit.transform(X)
+    assert slc._fused(520) is first
+    fruit.fit(X)
+    assert slc._fused(520) is not first
 
 
 @pytest.mark.parametrize("name", ["cfg3_small", "reduced_slice1_small", "readme", "readme_fullfit"])

@@ -516,6 +516,39 @@ def test_jit_compiles_static_programs(tmp_path, monkeypatch):
     assert fr.ISS(big, mode=fr.ISSMode.EXTENDED)._plan(0, len(big)).jit(1, compile_only=True)[0] == 0
 
 
+def test_jit_cache_is_validated(tmp_path, monkeypatch):
+    """The disk cache of compiled programs: a damaged or foreign file is not trusted (header with
+    sizes and a hash of the payload) but compiled again and replaced; a cache directory that
+    cannot be created or is open to others is simply not used."""
+    words = [fr.words.SimpleWord(s) for s in ["[1][2]", "[12][1]", "[2]", "[1][1][2]"]]
+    plan = fr.ISS(words, mode=fr.ISSMode.EXTENDED)._plan(0, len(words))
+    cache = tmp_path / "jit"
+    monkeypatch.setenv("FRUITS_HIP_JIT_CACHE", str(cache))
+    try:
+        size, _ = plan.jit(1, compile_only=True)
+    except ValueError as e:
+        if "not available" in str(e):
+            pytest.skip("hipRTC is not installed")
+        raise
+    (name,) = os.listdir(cache)
+    good = (cache / name).read_bytes()
+    assert good[:7] == b"FRJITCO" and len(good) > size
+    assert (os.stat(cache).st_mode & 0o077) == 0                # private directory
+    for damaged in (good[:len(good) // 2], good[:-1] + bytes([good[-1] ^ 1]), b"", b"x" * 4096):
+        (cache / name).write_bytes(damaged)
+        assert plan.jit(1, compile_only=True)[0] == size        # rejected, compiled again
+        assert (cache / name).read_bytes() == good              # and replaced
+    # a directory that cannot exist, and one others may write to: compile without a cache
+    monkeypatch.setenv("FRUITS_HIP_JIT_CACHE", "/dev/null/jit")
+    assert plan.jit(1, compile_only=True)[0] == size
+    shared = tmp_path / "shared"
+    shared.mkdir()
+    os.chmod(shared, 0o777)
+    monkeypatch.setenv("FRUITS_HIP_JIT_CACHE", str(shared))
+    assert plan.jit(1, compile_only=True)[0] == size
+    assert os.listdir(shared) == []
+
+
 def test_jit_without_hiprtc_falls_back(tmp_path):
     """No hipRTC: fr_plan_jit says so (FR_E_LIMIT) and nothing else changes - the plan keeps
     its interpreter program (checked in a fresh process: the library handle is cached)."""
