@@ -132,13 +132,17 @@ def _device_batch(torch, shape, seed):
 
 
 class _Pipeline:
-    """INC -> ISS(words, EXTENDED, weighting) -> sieves on a device-resident batch, fitted on
-    the first `n_fit` series: the fused launch (all words, or a rank's share of them)."""
+    """INC -> ISS(words, EXTENDED, weighting) -> sieves on a device-resident RAW batch, fitted on
+    the first `n_fit` series: ONE fused launch (all words, or a rank's share of them) that forms
+    the increments while it stages the raw rows - what FruitSlice.transform runs."""
 
-    def __init__(self, torch, fr, nat, shape, words, weighting, sieves, n_fit, seed=0):
+    def __init__(self, torch, fr, nat, shape, words, weighting, sieves, n_fit, seed=0, Xd=None,
+                 fit_on_root=None):
+        """``fit_on_root`` = (rank, world): the fruit is fitted on rank 0 only and its fitted
+        state broadcast (fruits_amd.parallel.fit_on_root) instead of fitted on every rank."""
         self.torch, self.fr, self.nat = torch, fr, nat
         self.N, self.D, self.T = shape
-        self.Xd = _device_batch(torch, shape, seed)
+        self.Xd = _device_batch(torch, shape, seed) if Xd is None else Xd
         fruit = fr.Fruit("bench")
         fruit.add(fr.preparation.INC)
         self.iss = fr.ISS(words, mode=fr.ISSMode.EXTENDED, weighting=weighting)
@@ -147,28 +151,38 @@ class _Pipeline:
         self.slc = fruit.get_slice()
         self.slc.fit_sample_size = 1.0
         np.random.seed(0)
-        fruit.fit(self.Xd[:n_fit].cpu().numpy())
+        if fit_on_root is None:
+            fruit.fit(self.Xd[:n_fit].cpu().numpy())
+        else:
+            from fruits_amd import parallel as par
+            rank, world = fit_on_root
+            par.fit_on_root(fruit, self.Xd[:n_fit].cpu().numpy() if rank == 0 else None, rank, world)
+            self.slc = fruit.get_slice()
+            self.iss = self.slc.get_iss()[0]
         self.fruit = fruit
         self.cache = fr.cache.SharedSeedCache(None)
         self.cache.adopt_device_input(self.Xd)
-        self.Pd = self.slc._prepare_device(self.Xd, self.cache)
         self.slc._attach(self.cache)
-        self.lk = self.iss.lookup_device(self.Pd)
+        self.chain = self.slc._fusable_preparation(self.T)
+        assert self.chain is not None, "the bench pipelines fuse their preparation"
+        # (Indices do not look at the data, L1 measures the cache's raw input)
+        self.lk = self.iss.lookup_device(self.Xd)
         self.strings = [str(w) for w in self.iss.words]
         self.depths = [self.iss._depth(i) for i in range(len(self.strings))]
         self.per_sum = sum(s.nfeatures() for s in self.slc.get_sieves())
 
     def launch(self, indices=None):
-        """(fn, feats, pipe): fn enqueues the fused launch of the given words."""
+        """(fn, feats, pipe): fn enqueues the fused launch of the given words on the raw batch."""
         torch, nat = self.torch, self.nat
         pipe = self.slc._fused(self.T, indices=indices)
         assert pipe is not None, "the bench pipelines are inside the fused set"
+        assert pipe.set_preparation(self.D, *self.chain), "INC is formed while the rows are staged"
         feats = torch.empty((self.N, pipe.n_features), dtype=torch.float64, device="cuda")
         rows = 0 if self.lk is None else int(self.lk.shape[0])
         wb = int(nat.lib().fr_pipeline_workspace_bytes(pipe._h, self.N, rows))
         work = torch.empty(max(wb, 1), dtype=torch.uint8, device="cuda")
         pipe.prepare(self.N)
-        return (lambda: pipe.run(self.Pd, self.lk, feats=feats, work=work)), feats, pipe
+        return (lambda: pipe.run(self.Xd, self.lk, feats=feats, work=work)), feats, pipe
 
     def figures(self, pipe, t_us):
         N, T = self.N, self.T
@@ -179,15 +193,87 @@ class _Pipeline:
             "elements_per_s": N * K * T / (t_us * 1e-6),
             "algorithmic_bytes": 8.0 * N * T * d_used + lookup_b + 8.0 * N * pipe.n_features,
             "equivalent_materialised_GBs": (8.0 * N * T * (d_used + K) + lookup_b) / (t_us * 1e-6) / 1e9,
-            "note": "no (K,N,T) tensor is written; the GB/s figure is what a materialising run "
-                    "of the same work would have needed, not achieved bandwidth",
+            "note": "the raw batch goes in, INC is formed in the staging; no (K,N,T) tensor is "
+                    "written; the GB/s figure is what a materialising run of the same work would "
+                    "have needed, not achieved bandwidth",
         }
 
 
-def _config4(torch, fr, nat):
+def _config4(torch, fr, nat, Xd=None, fit_on_root=None):
     return _Pipeline(torch, fr, nat, (8192, 3, 1024), fr.words.of_weight(6, dim=2),
                      fr.iss.weighting.Indices(), [fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END],
-                     n_fit=128)
+                     n_fit=128, Xd=Xd, fit_on_root=fit_on_root)
+
+
+def _broadcast_batch(torch, dist, shape, rank, backend):
+    """The batch generated ONCE, on rank 0, and broadcast device to device (RCCL; a gloo
+    rehearsal stages it through the host) - instead of every rank generating / uploading it."""
+    t0 = time.perf_counter()
+    Xd = (_device_batch(torch, shape, 0) if rank == 0
+          else torch.empty(shape, dtype=torch.float64, device="cuda"))
+    if backend == "nccl":
+        dist.broadcast(Xd, src=0)
+    else:
+        host = Xd.cpu()
+        dist.broadcast(host, src=0)
+        Xd.copy_(host)
+    torch.cuda.synchronize()
+    return Xd, (time.perf_counter() - t0) * 1e3
+
+
+def sweep(torch, fr, nat, dev, copy_GBs, budget_s=25.0):
+    """The materialising walk of of_weight(2,3) EXTENDED (K = 18) over N x T, once with the
+    pre-compiled static program and once through the record interpreter (FRUITS_HIP_STATIC=0),
+    and of_weight(4,2) EXTENDED (K = 115, no static program) at the headline shape; every cell
+    with its fraction of the 8 TB/s spec and of the copy rate measured on this box.  Cells are
+    dropped when the time budget is spent (largest first kept: the order below)."""
+    t_start = time.perf_counter()
+    cells = []
+    w2 = fr.words.of_weight(2, dim=N_DIMS)
+
+    def cell(words, N, T, static):
+        plan = fr.ISS(words, mode=fr.ISSMode.EXTENDED)._plan(0, len(words))
+        K = plan.rows
+        if 8.0 * N * T * (plan.dims_used + K) > 40e9:
+            return None
+        prev = os.environ.get("FRUITS_HIP_STATIC")
+        os.environ["FRUITS_HIP_STATIC"] = "1" if static else "0"
+        try:
+            Xs = _device_batch(torch, (N, N_DIMS, T), 1)
+            buf = torch.empty((K, N, T), dtype=torch.float64, device=dev)
+            if static:
+                plan.prepare(N, T)
+            t = _event_time_us(torch, lambda: plan.run(Xs, None, out=buf), reps=10)
+        finally:
+            if prev is None:
+                os.environ.pop("FRUITS_HIP_STATIC", None)
+            else:
+                os.environ["FRUITS_HIP_STATIC"] = prev
+        b_alg = 8.0 * N * T * (plan.dims_used + K)
+        gbs = b_alg / (t * 1e-6) / 1e9
+        del Xs, buf
+        return {"words": f"of_weight({len(words)} words)", "K": K, "N": N, "T": T,
+                "path": "static program" if static else "interpreter", "kernel_us": t,
+                "GBs": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS, "frac_of_on_box_copy": gbs / copy_GBs}
+    order = [(w2, 2048, 1024), (w2, 8192, 1024), (w2, 512, 1024), (w2, 1024, 1024), (w2, 3072, 1024),
+             (w2, 4096, 1024), (w2, 16384, 1024), (w2, 2048, 4096), (w2, 8192, 256), (w2, 2048, 256),
+             (w2, 512, 4096), (w2, 8192, 4096), (w2, 512, 256), (w2, 16384, 256)]
+    for words, N, T in order:
+        for static in (True, False):
+            if time.perf_counter() - t_start > budget_s:
+                break
+            c = cell(words, N, T, static)
+            if c is not None:
+                cells.append(c)
+        torch.cuda.empty_cache()
+    if time.perf_counter() - t_start <= budget_s + 5.0:
+        c = cell(fr.words.of_weight(4, dim=2), N_SERIES, N_STEPS_T, True)
+        if c is not None:
+            c["path"] = "run-time compiled static program if the scheduler accepts the plan, else interpreter"
+            cells.append(c)
+    return {"cells": cells, "on_box_copy_GBs": copy_GBs,
+            "note": "static programs cover T in (512, 1024]; other lengths run the interpreter "
+                    "(or the wave-per-series kernels for T <= 384) on both lines"}
 
 
 def extras(torch, fr, nat, dev, quick=False):
@@ -224,40 +310,26 @@ def extras(torch, fr, nat, dev, quick=False):
                             "bytes": nbytes,
                             "note": "torch fill_ / copy_ of a buffer of the (K,N,T) tensor's size"}
     del big, big2
-    # (b) config 3 shape: INC -> ISS(of_weight(4,2) EXTENDED, Indices) -> NPI(q=(.5,1)), END, fused
-    fruit = fr.Fruit("cfg3")
-    fruit.add(fr.preparation.INC)
-    iss = fr.ISS(fr.words.of_weight(4, dim=2), mode=fr.ISSMode.EXTENDED,
-                 weighting=fr.iss.weighting.Indices())
-    fruit.add(iss)
-    fruit.add(fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END)
-    fruit.get_slice().fit_sample_size = 1.0
-    np.random.seed(0)
-    fruit.fit(X[:128])
-    slc = fruit.get_slice()
-    cache = fr.cache.SharedSeedCache(X)
-    cache.adopt_device_input(Xd)
-    Pd = slc._prepare_device(Xd, cache)
-    slc._attach(cache)
-    pipe = slc._fused(N_STEPS_T)
-    lk = iss.lookup_device(Pd)
-    feats = torch.empty((N_SERIES, pipe.n_features), dtype=torch.float64, device=dev)
-    t = _event_time_us(torch, lambda: pipe.run(Pd, lk, feats=feats))
-    K = pipe.plan.rows
-    fruit.transform(X)   # first call builds plans / uploads tables
+    # (b) config 3 shape: INC -> ISS(of_weight(4,2) EXTENDED, Indices) -> NPI(q=(.5,1)), END: one
+    # fused launch on the raw batch
+    p3 = _Pipeline(torch, fr, nat, (N_SERIES, N_DIMS, N_STEPS_T), fr.words.of_weight(4, dim=2),
+                   fr.iss.weighting.Indices(), [fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END],
+                   n_fit=128, Xd=Xd)
+    fn, _, pipe3 = p3.launch()
+    t = _event_time_us(torch, fn)
+    p3.fruit.transform(X)   # first call builds plans / uploads tables
     t0 = time.perf_counter()
-    fruit.transform(X)
+    p3.fruit.transform(X)
     e2e = time.perf_counter() - t0
-    out["config3_fused_pipeline"] = {
-        "launch_us": t, "K": K, "features": pipe.n_features,
-        "elements_per_s": N_SERIES * K * N_STEPS_T / (t * 1e-6),
-        "algorithmic_bytes": 8.0 * N_SERIES * N_STEPS_T * 2 + 8.0 * N_SERIES * pipe.n_features,
-        "equivalent_materialised_GBs": 8.0 * N_SERIES * N_STEPS_T * (2 + K) / (t * 1e-6) / 1e9,
-        "fruit_transform_end_to_end_ms": e2e * 1e3,
-        "note": "no (K,N,T) tensor is written; the GB/s figure is what a materialising run "
-                "of the same work would have needed, not achieved bandwidth",
-    }
-    del Xd, Pd, feats
+    out["config3_fused_pipeline"] = dict(
+        p3.figures(pipe3, t), fruit_transform_end_to_end_ms=e2e * 1e3,
+        workload="BASELINE configs[2] shape: of_weight(4,2) EXTENDED + Indices, (2048,3,1024), "
+                 "INC -> ISS -> NPI(q=(0.5,1)), END, one fused launch")
+    del p3, fn, pipe3
+    # (b') the shape sweep: what the materialising walk reaches away from the headline shape
+    out["sweep"] = sweep(torch, fr, nat, dev, out["on_box_stream"]["copy_read_plus_write_GBs"],
+                         budget_s=4.0 if quick else 25.0)
+    del Xd
     if quick:
         return out
     # (c) config 4 on ONE GPU: fruit_general's of_weight(6,2) + Indices, (8192,3,1024),
@@ -266,8 +338,8 @@ def extras(torch, fr, nat, dev, quick=False):
     fn, _, pipe4 = p4.launch()
     out["config4_single_gpu"] = dict(
         p4.figures(pipe4, _event_time_us(torch, fn, reps=5)),
-        workload="BASELINE configs[3] on one GPU: of_weight(6,2) EXTENDED + Indices, "
-                 "(8192,3,1024), INC -> ISS -> NPI(q=(0.5,1)), END, one fused launch")
+        workload="BASELINE configs[3] on one GPU: of_weight(6,2) EXTENDED + Indices, raw "
+                 "(8192,3,1024) in, INC -> ISS -> NPI(q=(0.5,1)), END, one fused launch")
     del p4, fn, pipe4
     torch.cuda.empty_cache()
     # (d) config 5 on ONE GPU: fruit_twi slice 1, of_weight(9,1) + L1, (8192,6,4096)
@@ -289,7 +361,10 @@ def word_sharded_config4(torch, fr, nat, dist, rank, world, backend):
     """BASELINE configs[3]: the word list of fruit_general's first slice sharded over the
     ranks, features all-gathered (fruits_amd.parallel).  Every rank holds the same batch."""
     from fruits_amd import parallel as par
-    p = _config4(torch, fr, nat)
+    Xd, bcast_ms = _broadcast_batch(torch, dist, (8192, 3, 1024), rank, backend)
+    t0 = time.perf_counter()
+    p = _config4(torch, fr, nat, Xd=Xd, fit_on_root=(rank, world))
+    fit_ms = (time.perf_counter() - t0) * 1e3
     N, T = p.N, p.T
     parts = par.shard_words(p.strings, p.depths, world)
     maps = par.column_map(parts, p.depths, p.per_sum)
@@ -329,6 +404,7 @@ def word_sharded_config4(torch, fr, nat, dist, rank, world, backend):
             "features": pipe.n_features, "nodes": pipe.plan.nodes}
     everyone = [None] * world
     dist.all_gather_object(everyone, mine)
+    series_leg = series_sharded_config4(torch, dist, rank, world, backend, p)
     if rank != 0:
         return None
     # (4) rank 0: the unsharded transform of the same batch, every column compared
@@ -363,6 +439,65 @@ def word_sharded_config4(torch, fr, nat, dist, rank, world, backend):
         "equals_unsharded_transform": bool(cols_ok == n_features),
         "columns_checked": n_features, "columns_bit_identical": cols_ok,
         "max_abs_diff": float(diff.max().item()),
+        "batch": f"generated on rank 0, broadcast to the ranks ({bcast_ms:.1f} ms incl. generation)",
+        "fit": f"on rank 0 only, fitted state broadcast (pipeline set-up {fit_ms:.1f} ms on rank 0)",
+        "series_sharded_config4": None if series_leg is None else dict(
+            series_leg, single_rank_unsharded_launch_ms=t_one,
+            equals_unsharded_transform=bool((series_leg.pop("_full") == feats1).all().item())),
+    }
+
+
+def series_sharded_config4(torch, dist, rank, world, backend, p):
+    """The same workload with the SERIES sharded instead: every rank runs the whole word list
+    (one fused launch) on its N / world rows of the batch - no collective on the data path."""
+    from fruits_amd import parallel as par
+    nat = p.nat
+    rows = par.shard_series(p.N, rank, world)
+    Xr = p.Xd[rows].contiguous()
+    n_r = int(Xr.shape[0])
+    pipe = p.slc._fused(p.T)
+    assert pipe.set_preparation(p.D, *p.chain) and p.lk.shape[0] == 1
+    feats = torch.empty((n_r, pipe.n_features), dtype=torch.float64, device="cuda")
+    wb = int(nat.lib().fr_pipeline_workspace_bytes(pipe._h, n_r, 1))
+    work = torch.empty(max(wb, 1), dtype=torch.uint8, device="cuda")
+    pipe.prepare(n_r)
+    fn = lambda: pipe.run(Xr, p.lk, feats=feats, work=work)
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        dist.barrier()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b))
+    everyone = [None] * world
+    dist.all_gather_object(everyone, {"rank": rank, "rows": n_r, "launch_ms": float(np.median(ts))})
+    # for the check only (not part of the path): the row blocks assembled on rank 0
+    tallest = max(e["rows"] for e in everyone)
+    padded = torch.zeros((tallest, pipe.n_features), dtype=torch.float64, device="cuda")
+    padded[:n_r] = feats
+    if backend == "nccl":
+        flat = torch.empty((world * tallest, pipe.n_features), dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(flat, padded)
+    else:
+        flat_h = torch.empty((world * tallest, pipe.n_features), dtype=torch.float64)
+        dist.all_gather_into_tensor(flat_h, padded.cpu())
+        flat = flat_h.cuda()
+    if rank != 0:
+        return None
+    blocks = flat.view(world, tallest, pipe.n_features)
+    full = torch.cat([blocks[r, :everyone[r]["rows"]] for r in range(world)], dim=0)
+    launches = [e["launch_ms"] for e in everyone]
+    return {
+        "workload": "BASELINE configs[3] with the series sharded: every rank the whole word list "
+                    "(K = 1351) on N / world rows, one fused launch, no data-path collective",
+        "rows_per_rank": [e["rows"] for e in everyone], "rank_launch_ms": launches,
+        "slowest_launch_ms": max(launches), "balance": float(np.mean(launches) / max(launches)),
+        "elements_per_s": p.N * pipe.plan.rows * p.T / (max(launches) * 1e-3),
+        "_full": full,
     }
 
 

@@ -123,6 +123,24 @@ class Fruit:
         self.fit(X)
         return self.transform(X, callbacks=callbacks)
 
+    # ---- the fitted state, to be handed to other processes (fruits_amd.parallel) ----
+    def fit_state(self) -> bytes:
+        """Everything ``fit`` derived from the data, pickled: the fitted seeds of every slice."""
+        if not self._fitted:
+            raise RuntimeError("Missing call of self.fit")
+        import pickle
+        return pickle.dumps([slc._fit_state() for slc in self._slices])
+
+    def load_fit_state(self, state: bytes) -> None:
+        """Makes this fruit (same configuration) the fitted fruit ``state`` was taken from."""
+        import pickle
+        states = pickle.loads(state)
+        if len(states) != len(self._slices):
+            raise ValueError("the state belongs to a fruit with another number of slices")
+        for slc, st in zip(self._slices, states):
+            slc._load_fit_state(st)
+        self._fitted = True
+
     # ---- introspection ------------------------------------------------------
     def summary(self) -> str:
         bar = 80 * "="
@@ -248,6 +266,19 @@ class FruitSlice:
         for stage, *_ in _STAGES:
             self._wipe(stage)
         self.fit_sample_size = 1
+
+    def _fit_state(self) -> dict:
+        return {"stage": self._stage, "extended": self._sieves_extended,
+                "fit_sample_size": self.fit_sample_size}
+
+    def _load_fit_state(self, state: dict) -> None:
+        if [len(v) for v in state["stage"].values()] != [len(v) for v in self._stage.values()]:
+            raise ValueError("the state belongs to a slice of another configuration")
+        self._stage = state["stage"]
+        self.fit_sample_size = state["fit_sample_size"]
+        self._invalidate()
+        self._sieves_extended = state["extended"]
+        self._fitted = True
 
     def niteratedsums(self) -> int:
         return int(np.prod([iss.n_iterated_sums() for iss in self._iss]))

@@ -47,7 +47,10 @@ class ISS(Seed):
         self.semiring = semiring if semiring is not None else Reals()
         self._cache_plan = CachePlan(self.words if mode == ISSMode.EXTENDED else [])
         self.weighting = weighting
-        self._plans: dict = {}
+        self._fresh_transients()
+
+    def _fresh_transients(self) -> None:
+        self._plans: dict = {}      # device programs by (words, mode, weighting)
 
     @property
     def requires_fitting(self) -> bool:

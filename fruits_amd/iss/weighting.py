@@ -40,6 +40,9 @@ class Weighting(ABC):
     def __init__(self, total: bool = False) -> None:
         self.total = total
 
+    def __getstate__(self):     # (the cache belongs to the running process: seed.py, _TRANSIENT)
+        return {k: v for k, v in self.__dict__.items() if k != "_cache"}
+
     @abstractmethod
     def get_lookup(self, X: np.ndarray) -> np.ndarray:
         ...

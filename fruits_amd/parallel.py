@@ -173,15 +173,25 @@ def _device_block(slc, iss, X, cache, indices, depths, per_sum):
     from . import _native as nat
     t = nat.torch()
     Xd = cache.input_device(X) if cache._input is X else nat.to_device(X)
-    Pd = slc._prepare_device(Xd, cache)
-    slc._attach(cache)
     rr = row_ranges(depths)
     n_rows = sum(depths[i] for i in indices)
-    feats = t.zeros((X.shape[0], n_rows * per_sum), dtype=t.float64, device=Pd.device)
     if not indices:
-        return feats
+        return t.zeros((X.shape[0], 0), dtype=t.float64, device=Xd.device)
+    # the rank's share in ONE launch on the RAW batch where the slice's preparation fuses into
+    # the staging (INC / NEW(INC) / STD): as in FruitSlice.transform_device
+    T = int(Xd.shape[2])
+    chain = slc._fusable_preparation(T)
+    fused = slc._fused(T, indices=indices) if chain is not None else None
+    if fused is not None and fused.set_preparation(int(Xd.shape[1]), *chain):
+        slc._attach(cache)
+        slc._arm_series_cuts(fused, int(Xd.shape[0]), T, cache)
+        return fused.run(Xd, iss.lookup_device(Xd))
+    Pd = slc._prepare_device(Xd, cache)
+    slc._attach(cache)
+    feats = t.zeros((X.shape[0], n_rows * per_sum), dtype=t.float64, device=Pd.device)
     fused = slc._fused(int(Pd.shape[2]), indices=indices)
     if fused is not None:      # the rank's share in ONE launch, no (K_r, N, T) tensor
+        fused.set_preparation(int(Pd.shape[1]))     # (prepared input: nothing to fuse)
         slc._arm_series_cuts(fused, int(Pd.shape[0]), int(Pd.shape[2]), cache)
         return fused.run(Pd, iss.lookup_device(Pd))
     block = iss.transform_device(Pd, indices=indices)
@@ -213,3 +223,59 @@ def transform_sharded(fruit, X: np.ndarray, rank: Optional[int] = None,
     cache = SharedSeedCache(X)
     blocks = [slice_transform_sharded(slc, X, cache, rank, world, group) for slc in fruit._slices]
     return np.nan_to_num(np.concatenate(blocks, axis=1), copy=False, nan=0.0)
+
+
+# ----------------------------------------------------------------------- fit once, series axis
+def fit_on_root(fruit, X, rank: Optional[int] = None, world: Optional[int] = None, group=None,
+                root: int = 0) -> None:
+    """``Fruit.fit`` on ONE rank, the fitted state (thresholds of every sieve copy, statistics of
+    the preparateurs, random state of a CosWISS) broadcast to the others - instead of every rank
+    repeating the same fit on the same data.  ``X`` is only looked at on ``root``."""
+    import torch.distributed as dist
+
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    box = [None]
+    if rank == root:
+        fruit.fit(X)
+        box[0] = fruit.fit_state()
+    if world > 1:
+        dist.broadcast_object_list(box, src=root, group=group)
+    if rank != root:
+        fruit.load_fit_state(box[0])
+
+
+def transform_series_sharded(fruit, X: np.ndarray, rank: Optional[int] = None,
+                             world: Optional[int] = None, group=None, gather: bool = True):
+    """``Fruit.transform`` with the SERIES sharded over the ranks: every rank transforms its own
+    contiguous block of rows with the whole word list - no collective on the data path.
+    ``gather``: the blocks are then all-gathered (padded to the largest block) so that every
+    rank returns the full ``(N, nfeatures)``; else a rank returns its own rows."""
+    import torch
+    import torch.distributed as dist
+
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    mine = shard_series(X.shape[0], rank, world)
+    local = fruit.transform(np.ascontiguousarray(X[mine]))
+    if not gather or world == 1:
+        return local
+    rows = [shard_series(X.shape[0], r, world) for r in range(world)]
+    tallest = max(sl.stop - sl.start for sl in rows)
+    padded = torch.zeros((tallest, local.shape[1]), dtype=torch.float64)
+    padded[:local.shape[0]] = torch.from_numpy(local)
+    flat = torch.empty((world * tallest, local.shape[1]), dtype=torch.float64)
+    if dist.get_backend(group) == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device())
+        flat_d = flat.to(dev)
+        dist.all_gather_into_tensor(flat_d, padded.to(dev), group=group)
+        flat = flat_d.cpu()
+    else:
+        dist.all_gather_into_tensor(flat, padded, group=group)
+    blocks = flat.view(world, tallest, local.shape[1]).numpy()
+    return np.concatenate([blocks[r, :rows[r].stop - rows[r].start] for r in range(world)], axis=0)
+

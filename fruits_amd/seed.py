@@ -20,6 +20,18 @@ from .cache import SharedSeedCache
 
 class Seed(ABC):
     _cache: SharedSeedCache
+    # What a seed holds for the running process only - the cache it is attached to, device
+    # programs - and what therefore is no part of its pickled state (a fitted fruit is handed
+    # from the rank that fitted it to the others: fruits_amd.parallel.fit_on_root).
+    _TRANSIENT = ("_cache", "_plans")
+
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        if hasattr(self, "_fresh_transients"):
+            self._fresh_transients()
 
     @property
     def requires_fitting(self) -> bool:

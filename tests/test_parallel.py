@@ -99,3 +99,95 @@ def test_single_rank_gather_is_identity():
     local = torch.arange(4 * 54, dtype=torch.float64).reshape(4, 54)
     out = par.gather_features(local, maps, 54, 0, 1)
     torch.testing.assert_close(out, local)
+
+
+class _StandInFruit:
+    """Host stand-in with the interface the multi-rank helpers use (the real Fruit computes on
+    the GPU): `fit` takes a threshold from the data, `transform` is the oracle's block."""
+
+    def __init__(self, key):
+        self.ent = G.manifest["words"][key]
+        self.q = None
+        self.fits = 0
+
+    def fit(self, X):
+        self.fits += 1
+        self.q = float(np.median(X))
+
+    def fit_state(self):
+        import pickle
+        return pickle.dumps(self.q)
+
+    def load_fit_state(self, state):
+        import pickle
+        self.q = pickle.loads(state)
+
+    def transform(self, X):
+        idx = list(range(len(self.ent["words"])))
+        return _oracle_block(X, self.ent["words"], self.ent["plan"], idx, self.q).numpy()
+
+
+def _series_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X = np.random.default_rng(11).random((7, 3, 40))
+        fruit = _StandInFruit("2,3")
+        # only the root looks at the fit data
+        par.fit_on_root(fruit, X if rank == 0 else None)
+        assert fruit.fits == (1 if rank == 0 else 0)
+        full = par.transform_series_sharded(fruit, X)
+        own = par.transform_series_sharded(fruit, X, gather=False)
+        np.save(os.path.join(out_dir, f"full{rank}.npy"), full)
+        np.save(os.path.join(out_dir, f"own{rank}.npy"), own)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fit_on_root_and_series_sharded_transform(tmp_path):
+    """fit once, broadcast the fitted state; every rank transforms its rows (uneven blocks) and
+    the gathered matrix equals the unsharded transform on every rank."""
+    world = 2
+    mp.spawn(_series_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    X = np.random.default_rng(11).random((7, 3, 40))
+    fruit = _StandInFruit("2,3")
+    fruit.fit(X)
+    ref = fruit.transform(X)
+    for r in range(world):
+        np.testing.assert_array_equal(np.load(os.path.join(str(tmp_path), f"full{r}.npy")), ref)
+        np.testing.assert_array_equal(np.load(os.path.join(str(tmp_path), f"own{r}.npy")),
+                                      ref[par.shard_series(7, r, world)])
+
+
+def test_fit_state_round_trip():
+    """The fitted state of a fruit is picklable (no device handles, no cache) and makes an
+    equally configured fruit the fitted one."""
+    import fruits_amd as fr
+
+    def build():
+        fruit = fr.Fruit("state")
+        fruit.add(fr.preparation.STD(separately=False), fr.ISS(fr.words.of_weight(2, dim=2)))
+        fruit.add(fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END)
+        return fruit
+    a, b = build(), build()
+    slc = a.get_slice()
+    slc.get_preparateurs()[0]._mean, slc.get_preparateurs()[0]._std = 0.25, 1.5
+    slc.get_iss()[0]._plans["x"] = object()          # a device handle must not travel
+    rows = []
+    for k in range(slc.niteratedsums()):
+        copies = [sv.copy() for sv in slc.get_sieves()]
+        copies[0]._quantiles = np.array([0.1 * k, np.inf])
+        rows.append(copies)
+    slc._sieves_extended = rows
+    slc._fitted = a._fitted = True
+    with pytest.raises(RuntimeError):
+        b.fit_state()
+    b.load_fit_state(a.fit_state())
+    got = b.get_slice()
+    assert b._fitted and got._fitted and got.get_iss()[0]._plans == {}
+    assert got.get_preparateurs()[0]._std == 1.5
+    assert len(got._sieves_extended) == slc.niteratedsums()
+    np.testing.assert_array_equal(got._sieves_extended[3][0]._quantiles, [0.1 * 3, np.inf])
+    with pytest.raises(ValueError):
+        fr.Fruit("other").load_fit_state(a.fit_state())
