@@ -673,6 +673,9 @@ class SieveOracle:
 
     def fit(self, A):
         self.quantiles = fit_quantiles(self.q, pre_transform(A, self.inc))
+        # (test helper: the magnitude of the rows the thresholds were taken from - the scale a
+        # comparison of fitted thresholds has to use, since a quantile of differences can be tiny)
+        self.fit_scale = float(np.abs(A).max()) if A.size else 0.0
 
     def transform(self, A, X_raw=None):
         # a sieve used on its own builds its cache from its own (N, T) input
@@ -692,16 +695,28 @@ class SieveOracle:
         return fn(arr, cuts, self.quantiles)
 
 
-    def exposure(self, A, X_raw=None, rel=1e-10):
+    def exposure(self, A, X_raw=None, rel=1e-10, tight=False, means=None, robust_zeros=False):
         """Test helper (not part of the reference): for every feature the number of
-        elements of its cut segment that lie within ``rel * max|A[n]|`` of one of the
-        band's finite thresholds.  A band test ``q_lo < v <= q_hi`` can only come out
-        differently under a re-associated scan for such elements (an exact tie with a
-        fitted quantile that IS a data point, a whole plateau of a running maximum equal
-        to it, an increment the running sum absorbs next to the threshold 0), so a
-        count may differ from the reference's by at most this number - and by nothing
+        elements of its cut segment that lie so close to one of the band's finite thresholds
+        that a band test ``q_lo < v <= q_hi`` may come out differently under a re-associated
+        scan (an exact tie with a fitted quantile that IS a data point, a whole plateau of a
+        running maximum equal to it, an increment the running sum absorbs next to the threshold
+        0): a count may differ from the reference's by at most this number - and by nothing
         where it is 0.  (Element 0 of a series is left out: it is computed without any
-        addition - or zero-padded - on every path.)"""
+        addition - or zero-padded - on every path.)
+
+        Two widths.  ``tight=False`` (the end-to-end criterion, thresholds fitted by each side
+        on its own values): ``rel * max(|A[n]|, |arr[n]|)``, A the undifferenced row.
+        ``tight=True`` (the transform criterion, the SAME thresholds on both sides):
+        ``rel * max|arr[n]| + 8 ulp(max|A[n]|)`` with arr the ``inc``-times differenced row
+        the sieve looks at - the second term because an increment of a scan inherits the
+        rounding of the running sum it is taken from, however small the increment.
+
+        ``means`` (a dict, MPI only): filled with ``{(series, feature): candidate means}`` for
+        the exposed entries of at most 4 exposed elements - the band means after moving any
+        subset of the exposed elements across the threshold; a mean computed from values that
+        differ in the last bits must be one of them.  ``robust_zeros``: the rows are SUMS (see
+        the comment at its use)."""
         out = np.zeros((A.shape[0], self.nfeatures()), dtype=np.int64)
         if self.kind == "END":
             return out
@@ -709,7 +724,10 @@ class SieveOracle:
             self.quantiles = fit_quantiles(self.q)
         arr = pre_transform(A, self.inc)
         cuts = transformed_cuts(A.shape[0], A.shape[1], self.cut, X_raw, self.norm)
-        tol = rel * np.maximum(np.abs(A).max(axis=1), np.abs(arr).max(axis=1))
+        if tight:
+            tol = rel * np.abs(arr).max(axis=1) + 8 * np.finfo(float).eps * np.abs(A).max(axis=1)
+        else:
+            tol = rel * np.maximum(np.abs(A).max(axis=1), np.abs(arr).max(axis=1))
         Q = len(self.quantiles) - 1
         for i in range(A.shape[0]):
             for j in range(cuts.shape[1] - 1):
@@ -718,12 +736,33 @@ class SieveOracle:
                     near = np.zeros(seg.shape, dtype=bool)
                     for thr in (self.quantiles[k], self.quantiles[k + 1]):
                         if np.isfinite(thr):
-                            near |= np.abs(seg - thr) <= tol[i]
+                            close = np.abs(seg - thr) <= tol[i]
+                            if tight and robust_zeros and thr == 0.0 and self.inc == 1:
+                                # A first increment of a SUM that is exactly zero is a summand
+                                # the running sum absorbed: exactly zero on every path that forms
+                                # increments as the step of a sequential cumulative sum (the
+                                # fused walk does) - it cannot land on the other side of the
+                                # threshold 0.  (Not so for max-plus rows, whose inputs may differ
+                                # in the last bit, nor for higher differences.)
+                                close &= seg != 0.0
+                            near |= close
                     # t = 0 is exact on both sides (the first value of a scan is its first
                     # summand; increments are zero-padded there): never a disagreement
                     if cuts[i, j] == 0 and near.size:
                         near[0] = False
-                    out[i, j * Q + k] = int(near.sum())
+                    n_near = int(near.sum())
+                    out[i, j * Q + k] = n_near
+                    if means is not None and self.kind == "MPI" and 0 < n_near <= 4:
+                        inside = np.logical_and(self.quantiles[k] < seg, seg <= self.quantiles[k + 1])
+                        where = np.nonzero(near)[0]
+                        cands = []
+                        for bits in range(1 << n_near):
+                            m = inside.copy()
+                            for b, pos in enumerate(where):
+                                if bits >> b & 1:
+                                    m[pos] = not m[pos]
+                            cands.append(0.0 if not m.any() else float(np.mean(seg[m])))
+                        means[(i, j * Q + k)] = cands
         return out
 
 
@@ -842,22 +881,43 @@ def fruit_transform(spec, fitted, X):
     return np.nan_to_num(res, copy=False, nan=0.0)
 
 
-def fruit_transform_exposure(spec, fitted, X, rel=1e-10):
+def fruit_transform_exposure(spec, fitted, X, rel=1e-10, tight=False, means=None):
     """fruit_transform and, from the same iterated sums, the (N, F) near-threshold element
-    counts of every feature (SieveOracle.exposure, a test helper) in the same column order."""
+    counts of every feature (SieveOracle.exposure, a test helper) in the same column order.
+    ``means``: a dict filled with {(series, column): candidate band means} of the exposed MPI
+    entries (see SieveOracle.exposure)."""
     feats, expos = [], []
+    col0 = 0
     for sl, (sieves, ext) in zip(spec["slices"], fitted):
         P = _apply_preps(X, sl.get("preps", []))
+        sums = all(i.get("semiring", "Reals") == "Reals" and i.get("kind") != "CosWISS" for i in sl["iss"])
         cols, ecols = [], []
         for i, itsum in enumerate(_iterate_iss(P, sl["iss"], X)):
             for s in (ext[i] if ext else sieves):
                 cols.append(s.transform(itsum, X))
-                ecols.append(s.exposure(itsum, X, rel))
+                local = {} if means is not None else None
+                ecols.append(s.exposure(itsum, X, rel, tight, local, robust_zeros=sums))
+                if local:
+                    for (n, f), c in local.items():
+                        means[(n, col0 + f)] = c
+                col0 += cols[-1].shape[1]
         feats.append(np.concatenate(cols, axis=1))
         expos.append(np.concatenate(ecols, axis=1))
     res = np.nan_to_num(np.concatenate(feats, axis=1), copy=False, nan=0.0)
     return res, np.concatenate(expos, axis=1)
 
 
-def fruit_exposure(spec, fitted, X, rel=1e-10):
-    return fruit_transform_exposure(spec, fitted, X, rel)[1]
+def fruit_exposure(spec, fitted, X, rel=1e-10, tight=False, means=None):
+    return fruit_transform_exposure(spec, fitted, X, rel, tight, means)[1]
+
+
+def fitted_thresholds(fitted):
+    """The thresholds of a fitted fruit: per slice, per iterated sum, per sieve the sorted
+    quantile values (None for a sieve without any: END)."""
+    return [[[None if s.kind == "END" else (None if s.quantiles is None else np.array(s.quantiles))
+              for s in row] for row in ext] for _, ext in fitted]
+
+
+def fitted_scales(fitted):
+    """Same shape as fitted_thresholds: max |value| of the rows every sieve copy was fitted on."""
+    return [[[getattr(s, "fit_scale", 0.0) for s in row] for row in ext] for _, ext in fitted]

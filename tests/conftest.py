@@ -60,24 +60,58 @@ def golden():
 # features were compared, how many were exposed to a threshold tie, and how many differed;
 # printed at the end of the run (pytest -m gpu) so the observed mismatches are on record.
 PARITY_REPORT = []
+# The same for the STRICT comparisons (the oracle's thresholds transplanted into the GPU
+# pipeline, tight exposure) and for the fit comparisons (thresholds fitted here vs the oracle's).
+STRICT_REPORT = []
+FIT_REPORT = []
 
 
-def pytest_terminal_summary(terminalreporter):
-    if not PARITY_REPORT:
-        return
-    tr = terminalreporter
-    tr.write_sep("-", "feature parity report (counting sieves vs the oracle)")
+def _totals(tr, title, report):
+    tr.write_sep("-", title)
     tot = {"entries": 0, "exposed": 0, "differ": 0, "differ_unexposed": 0}
-    for r in PARITY_REPORT:
+    for r in report:
         for k in tot:
             tot[k] += r[k]
-    worst = sorted(PARITY_REPORT, key=lambda r: -r["differ"])[:12]
+    worst = sorted(report, key=lambda r: -r["differ"])[:12]
     for r in worst:
         if r["differ"] == 0:
             break
         tr.write_line(f"  {r['what'][:70]:70s} entries {r['entries']:8d} exposed {r['exposed']:7d} "
                       f"differ {r['differ']:5d} (max |d| {r['max_d']:.0f}, unexposed {r['differ_unexposed']})")
-    tr.write_line(f"  TOTAL over {len(PARITY_REPORT)} comparisons: count entries {tot['entries']}, "
-                  f"tie-exposed {tot['exposed']}, differing {tot['differ']} "
+    tr.write_line(f"  TOTAL over {len(report)} comparisons: count entries {tot['entries']}, "
+                  f"tie-exposed {tot['exposed']} ({100.0 * tot['exposed'] / max(tot['entries'], 1):.3f} %), "
+                  f"differing {tot['differ']} "
                   f"({100.0 * tot['differ'] / max(tot['entries'], 1):.4f} %), "
                   f"differing outside exposure {tot['differ_unexposed']}")
+    return tot
+
+
+def pytest_terminal_summary(terminalreporter):
+    tr = terminalreporter
+    if PARITY_REPORT:
+        _totals(tr, "feature parity report, end to end (fit AND transform on the GPU vs the oracle; "
+                    "exposure 1e-10 of the row)", PARITY_REPORT)
+    for cls, title in (("sum", "columns of sums (Reals, CosWISS)"),
+                       ("max-plus", "columns of max-plus slices (Arctic / Bayesian: plateaus)")):
+        part = [r for r in STRICT_REPORT if r.get("cls") == cls]
+        if not part:
+            continue
+        tot = _totals(tr, f"feature parity report, transform alone - {title}: the oracle's thresholds in the "
+                          "GPU pipeline; exposure 1e-13 of the differenced row + 8 ulp of the row", part)
+        means = sum(r.get("means_checked", 0) for r in part)
+        tr.write_line(f"  band means of exposed entries checked against the candidate means: {means}")
+        wide = [r for r in part if r.get("series", 0) >= 64]
+        if wide:
+            we, wx = sum(r["entries"] for r in wide), sum(r["exposed"] for r in wide)
+            tr.write_line(f"  on batches of >= 64 series: {we} entries, {wx} exposed ({100.0 * wx / max(we, 1):.3f} %)")
+        big = max((r["max_d"] for r in part), default=0)
+        tr.write_line(f"  SURVEY 7 bar: differing {100.0 * tot['differ'] / max(tot['entries'], 1):.4f} % "
+                      f"(bar 0.1 %), largest |d| {big:.0f} (bar 1)"
+                      + ("" if cls == "sum" else " - not asserted for this class"))
+    if FIT_REPORT:
+        tr.write_sep("-", "fit parity report (thresholds fitted on the GPU vs the oracle's)")
+        n = sum(r["thresholds"] for r in FIT_REPORT)
+        same = sum(r["identical"] for r in FIT_REPORT)
+        worst = max((r["max_rel"] for r in FIT_REPORT), default=0.0)
+        tr.write_line(f"  {n} finite thresholds over {len(FIT_REPORT)} fits: {same} bit-identical, largest "
+                      f"deviation {worst:.2e} of the magnitude of the fitted rows (bar 1e-13)")
