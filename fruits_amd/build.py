@@ -26,7 +26,7 @@ def units():
     """(object name, source, extra flags)"""
     out = [("kernels_misc", "kernels_misc.hip", []), ("plan", "plan.cpp", []),
            ("capi", "capi.cpp", []), ("jit", "jit.cpp", []),
-           ("walk_static_reg", "walk_static_inst.hip", ["-DSTATIC_REGISTRY"]), ("walk_team1", "walk_inst.hip", ["-DWALK_TEAM1"])]
+           ("walk_static_reg", "walk_static_inst.hip", ["-DSTATIC_REGISTRY"])]
     # The fused walk (mode 1): no a*b+c contraction - the reference rounds a letter's product
     # before the cumulative sum adds it (fruits/iss/semiring.py:143-149), and so do the static
     # programs below; and its uniform branches stay branches - structurised like divergent ones,

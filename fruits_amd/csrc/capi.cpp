@@ -55,6 +55,24 @@ int env_int(const char *name, int dflt) {
   return v && *v ? std::atoi(v) : dflt;
 }
 
+// Developer knobs live in ONE variable: FRUITS_HIP_DEBUG="name=value,name=value" with
+//   groups=G    groups of root sub-tries per series instead of the host's choice
+//   persist=P   1 / 0: persistent grid / one workgroup per unit for the materialising walk
+//   packed=0    cooperative kernels also for short series (the wave-per-series ones are default)
+//   stamps=M    the diagnostic timing build's mask (IssArgs::debug), dbg_bytes=B its stamp buffer
+// Nothing here changes a result; the product reads none of them in normal operation.
+int debug_knob(const char *name, int dflt) {
+  const char *v = std::getenv("FRUITS_HIP_DEBUG");
+  if (!v || !*v) return dflt;
+  const size_t n = std::strlen(name);
+  for (const char *p = v; *p;) {
+    if (std::strncmp(p, name, n) == 0 && p[n] == '=') return std::atoi(p + n + 1);
+    while (*p && *p != ',') ++p;
+    if (*p == ',') ++p;
+  }
+  return dflt;
+}
+
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -171,7 +189,7 @@ int choose_groups(const fr::Plan &p, int64_t N, int requested) {
   const int U = p.units();
   if (U <= 1) return 1;
   int G = requested;
-  if (G <= 0) G = env_int("FRUITS_HIP_GROUPS", 0);
+  if (G <= 0) G = debug_knob("groups", 0);
   if (G <= 0) {
     // aim for a few thousand workgroups (256 CUs x several resident each)
     const int64_t target = 2048;
@@ -199,7 +217,7 @@ LaunchShape launch_shape(const fr::Plan &p, int64_t N, int64_t T, int requested_
   s.fits = staged_rows_fit(p, T);
   // short series: four series per workgroup, one wave each (their rows side by side in LDS)
   const int64_t packed_chunk = T <= 128 ? 128 : (T <= 256 ? 256 : 384);
-  s.packed = env_int("FRUITS_HIP_PACKED", 1) != 0 &&
+  s.packed = debug_knob("packed", 1) != 0 &&
              fr::packed_supported(T, p.levels, p.semiring) &&
              (size_t)4 * p.rows_staged() * packed_chunk * 8 <= 64 * 1024;
   // (a packed workgroup holds four units: ask for four times the units)
@@ -218,8 +236,7 @@ int carry_slots_for(const fr::Plan &p, int G) {
 bool carries_fit_lds(const fr::Plan &p, int64_t T, int G) {
   // rows + carries must leave room for >= 4 workgroups per CU (160 KiB LDS)
   const size_t rows_bytes = (size_t)p.rows_staged() * fr::walk_chunk_elems(T) * 8;
-  return env_int("FRUITS_HIP_LDS_CARRY", 1) != 0 &&
-         rows_bytes + (size_t)carry_slots_for(p, G) * 8 <= 40 * 1024;
+  return rows_bytes + (size_t)carry_slots_for(p, G) * 8 <= 40 * 1024;
 }
 
 // LDS feature window of a fused cooperative launch (walk_device.h, feat_flush): as many slots
@@ -253,7 +270,7 @@ int feat_window_for(const fr::GroupedProgram &gp, size_t other_lds_bytes, int n_
 // Resident workgroups of the cooperative walk kernel instance that (plan, T, fused,
 // vec_ok) selects: a dry run of the launcher (nothing is enqueued).
 int64_t query_resident(const fr::Plan &p, int64_t N, int64_t T, bool fused, bool vec_ok) {
-  if (env_int("FRUITS_HIP_PERSIST", 1) == 0) return 0;
+  if (debug_knob("persist", 1) == 0) return 0;
   fr::IssArgs a{};
   int32_t resident = 0;
   double *const dummy = reinterpret_cast<double *>(uintptr_t(256));  // never dereferenced
@@ -316,6 +333,9 @@ struct JitState {
   std::string error;     // why the plan has none (not an error of the caller's)
 };
 
+// batches below this many series run a static program with all its groups (to fill the chip)
+constexpr int kStaticSplitBelow = 768;
+
 bool static_shape_ok(const fr::Plan &p, int64_t T) {
   return !p.cos && p.weighting == 0 && p.semiring == fr::kSemiReals && T > 512 && T <= 1024;
 }
@@ -364,7 +384,7 @@ int prepare_plan(fr::Plan &p, int64_t N, int64_t T, int32_t groups, bool fused, 
                                 std::to_string(p.rows_staged()) +
                                 " rows per time chunk, more than the LDS holds - split the word list");
   std::vector<int> Gs;
-  const bool auto_groups = !shape.packed && groups <= 0 && env_int("FRUITS_HIP_GROUPS", 0) <= 0;
+  const bool auto_groups = !shape.packed && groups <= 0 && debug_knob("groups", 0) <= 0;
   if (auto_groups) {
     // (the choice depends on the kernel instance - fused or not, 16-byte aligned or not -
     // which is only known when the pointers are: upload what either would ask for)
@@ -373,9 +393,6 @@ int prepare_plan(fr::Plan &p, int64_t N, int64_t T, int32_t groups, bool fused, 
   } else {
     Gs.push_back(shape.G);
   }
-  // the opt-in wave-per-row kernel (FRUITS_HIP_TEAM=1) always walks 4 groups
-  if (!fused && env_int("FRUITS_HIP_TEAM", 0) == 1 && groups <= 0 && p.units() >= 4)
-    Gs.push_back(4);
   for (int G : Gs) {
     int rc = ensure_device_program(p, fr::grouped(p, G), nullptr, who);
     if (rc != FR_OK) return rc;
@@ -725,7 +742,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
       a.cw_Lmax = c.Lmax;
     }
     a.cw_x_unit_stride = c.x_unit_stride;
-    a.packed = (T <= 384 && env_int("FRUITS_HIP_PACKED", 1) != 0) ? 1 : 0;
+    a.packed = (T <= 384 && debug_knob("packed", 1) != 0) ? 1 : 0;
     a.vec_ok = (T % 2 == 0) && aligned16(d_X) && aligned16(trig) &&
                (fu || (aligned16(d_out) && (out_k_stride % 2 == 0) && (out_n_stride % 2 == 0)));
     if (fu) {
@@ -746,7 +763,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     }
     // one short-lived workgroup per (series, word, frequency) unit: 0-2.5 % faster than a
     // persistent grid (exponent 2: 1515 -> 1478 us)
-    a.persistent = env_int("FRUITS_HIP_COS_PERSIST", 0);
+    a.persistent = 0;
     e = fr::launch_coswiss(a, c.exponent, st);
     if (e != hipSuccess) return hip_fail(e, "coswiss launch");
     return FR_OK;
@@ -763,13 +780,6 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   const bool vec_ok_pre = (T % 2 == 0) && aligned16(d_X) &&
                           (fu || (aligned16(d_out) && (out_k_stride % 2 == 0) &&
                                   (out_n_stride % 2 == 0)));
-  // one wave per row when the plan splits into 4 balanced groups (see WalkCfg::TEAM);
-  // opt-in: measured 71 us vs 67 us for the cooperative kernel on config 2 (a third
-  // of the scalar instructions, but only 2 waves/SIMD)
-  const int team_env = env_int("FRUITS_HIP_TEAM", 0);
-  const bool wave_rows = !fu && team_env == 1 && groups <= 0 && p.units() >= 4 &&
-                         p.semiring == fr::kSemiReals &&
-                         fr::wave_rows_supported(T, p.levels, vec_ok_pre);
   // the staged rows (input dimensions + exp tables) of one time chunk must fit the LDS
   LaunchShape shape = launch_shape(p, N, T, groups);
   if (!shape.fits)
@@ -779,9 +789,9 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
                                 " distinct alphas), more than the LDS holds - split the word list");
   // (a totally weighted plan with differencing sieves runs the cooperative kernels, which have
   // the instantiation for it, also on short series)
-  const bool packed = !wave_rows && shape.packed &&
+  const bool packed = shape.packed &&
                       !(fu && fu->total_inc && p.weighting == FR_W_TOTAL);
-  const bool auto_groups = !wave_rows && !packed && groups <= 0 && env_int("FRUITS_HIP_GROUPS", 0) <= 0;
+  const bool auto_groups = !packed && groups <= 0 && debug_knob("groups", 0) <= 0;
   const int64_t resident = auto_groups ? query_resident(p, N, T, fu != nullptr, vec_ok_pre) : 0;
   fr::GroupedProgram *gpp = nullptr;
   int static_lds_pad = 0;
@@ -794,8 +804,8 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     // Reals, the group count its schedule was generated for.  It reads no device tables, so
     // nothing is uploaded for it (and a run of it is capturable without fr_plan_prepare).
     int static_groups = 0;
-    const int asked = groups > 0 ? groups : env_int("FRUITS_HIP_GROUPS", 0);
-    if (!fu && !packed && !wave_rows && vec_ok_pre && static_shape_ok(p, T) && N > 0 &&
+    const int asked = groups > 0 ? groups : debug_knob("groups", 0);
+    if (!fu && !packed && vec_ok_pre && static_shape_ok(p, T) && N > 0 &&
         asked <= 3 && env_int("FRUITS_HIP_STATIC", 1) != 0) {
       if (p.static_prog[0] < 0) {
         const fr::GroupedProgram &g1 = fr::grouped(p, 1);
@@ -820,7 +830,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
       // finer units balance better (N = 8192: 273 vs 283 us).
       const int gmax = have(3) ? 3 : (have(2) ? 2 : 1);
       const double footprint = 8.0 * (double)N * (double)T * (double)(p.dims_used + p.K);
-      const bool cache_sized = N >= env_int("FRUITS_HIP_STATIC_SPLIT_BELOW", 768) &&
+      const bool cache_sized = N >= kStaticSplitBelow &&
                                footprint <= 2.0 * 256.0 * 1024.0 * 1024.0;
       static_groups = asked > 0 ? asked : (cache_sized ? 1 : gmax);
       // Batches that stream through HBM (beyond twice the cache): FOUR resident workgroups per
@@ -828,7 +838,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
       // (N = 4096 / 8192 / 16384: 134 -> 122, 263 -> 241, 525 -> 493 us); 16 KB of unused LDS
       // per workgroup is how a launch asks for that.  Cache-sized and small batches keep six
       // (N = 2048: 56.2 vs 58.6 us with four).
-      static_lds_pad = (!cache_sized && N >= env_int("FRUITS_HIP_STATIC_SPLIT_BELOW", 768)) ? 16384 : 0;
+      static_lds_pad = (!cache_sized && N >= kStaticSplitBelow) ? 16384 : 0;
       if (have(static_groups)) {
         static_prog = p.static_prog[static_groups] > 0 ? p.static_prog[static_groups] : -1;
         if (static_prog < 0) {
@@ -842,7 +852,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
       }
     }
     const int G = static_prog ? static_groups
-                              : (wave_rows ? 4 : (auto_groups ? choose_groups_walk(p, N, resident, fu != nullptr) : shape.G));
+                              : (auto_groups ? choose_groups_walk(p, N, resident, fu != nullptr) : shape.G);
     gpp = &fr::grouped(p, G);   // (map nodes are stable: the reference outlives the lock)
     if (!static_prog) {
       int rc = ensure_device_program(p, *gpp, st, who);
@@ -880,11 +890,11 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   }
   if (wl.carry_bytes) a.carry = reinterpret_cast<double *>(work + wl.aux_bytes);
   a.vec_ok = vec_ok_pre && (!a.aux || aligned16(a.aux));
-  a.debug = env_int("FRUITS_HIP_DEBUG", 0);
+  a.debug = debug_knob("stamps", 0);
   if (a.debug & 16) {
     // diagnostic build only: stamps go to the tail of the workspace if the caller
     // sized it with FRUITS_HIP_DBG_BYTES extra bytes
-    const int64_t extra = env_int("FRUITS_HIP_DBG_BYTES", 0);
+    const int64_t extra = debug_knob("dbg_bytes", 0);
     if (extra > 0 && d_work && work_bytes >= (int64_t)wl.total() + extra)
       a.dbg = reinterpret_cast<unsigned long long *>(work + align_up(wl.total(), 256));
   }
@@ -901,11 +911,10 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     // grid (16384 x 128: 86 -> 77 us, 32768 x 64: 120 -> 100 us), longer ones with (8192 x 256:
     // 71 vs 75 us)
     if (packed && !fu) by_shape = T > 192 ? 1 : 0;
-    a.persistent = env_int("FRUITS_HIP_PERSIST", by_shape);
+    a.persistent = debug_knob("persist", by_shape);
   }
-  a.wave_rows = wave_rows ? 1 : 0;
   a.packed = packed ? 1 : 0;
-  a.prefetch_next = env_int("FRUITS_HIP_PREFETCH", 24);  // longest unit (nodes) that prefetches; 0: off
+  a.prefetch_next = 24;  // longest unit (nodes) that touches its successor's rows
   a.semiring = p.semiring;
   a.letter_sum = p.letter_sum ? 1 : 0;
   a.k_stride_bytes32 = (out_k_stride > 0 && out_k_stride < (int64_t(1) << 29))
@@ -947,7 +956,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
         return fail(FR_E_LIMIT, w + ": letter-sum (argmax) plans have no fused walk");
     }
     if (fu->prep) {
-      if (packed || wave_rows)
+      if (packed)
         return fail(FR_E_LIMIT, w + ": the fused preparation needs the cooperative kernel");
       a.prep = fu->prep;
       a.stats = fu->stats;
@@ -955,19 +964,19 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     }
   }
   a.static_prog = static_prog > 0 ? static_prog : 0;
-  a.lds_pad = env_int("FRUITS_HIP_STATIC_LDS_PAD", static_lds_pad);
+  a.lds_pad = static_lds_pad;
   // The interpreter's share of the same finding, in the window where it was measured to pay:
   // one group per series and a batch just above the Infinity Cache (1 to 1.5 times its
   // 256 MiB - config 2: 70 -> 65 us; 264 MB: 43 -> 45 us, 440 MB: 88 -> 93 us, so not there).
   {
     const double footprint = 8.0 * (double)N * (double)T * (double)(p.dims_used + p.K);
     const double cache = 256.0 * 1024.0 * 1024.0;
-    a.nt_input = (!fu && !packed && !wave_rows && a.G == 1 && footprint > cache &&
-                  footprint <= 1.5 * cache && env_int("FRUITS_HIP_NT_INPUT", 1) != 0) ? 1 : 0;
+    a.nt_input = (!fu && !packed && a.G == 1 && footprint > cache &&
+                  footprint <= 1.5 * cache) ? 1 : 0;
   }
   // static programs of several groups run one short-lived workgroup per unit: the hardware
   // dispatcher balances them and keeps the write front compact
-  if (static_prog) a.persistent = env_int("FRUITS_HIP_STATIC_PERSIST", 0);
+  if (static_prog) a.persistent = 0;
   hipError_t e = jit_prog ? fr::jit_launch(*jit_prog, a, st) : fr::launch_iss_walk(a, p.levels, st);
   if (e != hipSuccess) return hip_fail(e, "iss_walk launch");
   return FR_OK;

@@ -11,7 +11,6 @@ namespace fr {
 
 
 int walk_chunk_elems(int64_t T);
-bool wave_rows_supported(int64_t T, int levels, bool vec_ok);
 bool packed_supported(int64_t T, int levels, int semiring);
 int static_program_for(const NodeRec *recs, int n, int groups, const int32_t *row_src, int rows);
 hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st);

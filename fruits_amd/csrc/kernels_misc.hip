@@ -802,26 +802,11 @@ hipError_t launch_select_ranks(void *jobs, int n_jobs, const void *groups, int n
 }
 
 // ---------------------------------------------------------------- launchers
-int walk_chunk_elems(int64_t T) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char *v = getenv("FRUITS_HIP_CHUNK");
-    forced = v && *v ? atoi(v) : 0;
-  }
-  if (forced == 512 || forced == 1024) return forced;
-  return T <= 512 ? 512 : 1024;
-}
-
-// wave-per-row variant (TEAM = 1): single chunk, aligned 16-byte accesses,
-// shallow tries (register frames of 2 * E * P VGPRs per level)
-bool wave_rows_supported(int64_t T, int levels, bool vec_ok) {
-  return vec_ok && T <= 1024 && levels <= 4;
-}
+int walk_chunk_elems(int64_t T) { return T <= 512 ? 512 : 1024; }
 
 #define DECL_INST(m, l) hipError_t walk_inst_m##m##_l##l(const IssArgs &, int, hipStream_t);
 DECL_INST(0, 2) DECL_INST(0, 4) DECL_INST(0, 6) DECL_INST(0, 8)
 DECL_INST(1, 2) DECL_INST(1, 4) DECL_INST(1, 6) DECL_INST(1, 8)
-hipError_t walk_inst_team1(const IssArgs &, int, int, hipStream_t);
 hipError_t walk_static_launch(const IssArgs &, hipStream_t);
 hipError_t walk_packed_inst_m0(const IssArgs &, int, hipStream_t);
 hipError_t walk_packed_inst_m1(const IssArgs &, int, hipStream_t);
@@ -839,11 +824,6 @@ hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st) {
   a.nchunks = (int32_t)((a.T + chunk - 1) / chunk);
   if (a.N * a.G <= 0) return hipSuccess;
   if (a.nchunks > 1 && a.carry == nullptr) return hipErrorInvalidValue;
-  if (a.wave_rows) {
-    if (a.G != 4 || a.feats || !wave_rows_supported(a.T, levels, a.vec_ok != 0))
-      return hipErrorInvalidValue;
-    return walk_inst_team1(a, levels, chunk, st);
-  }
   if (a.packed) {
     if (!packed_supported(a.T, levels, a.semiring)) return hipErrorInvalidValue;
     return a.feats ? walk_packed_inst_m1(a, levels, st) : walk_packed_inst_m0(a, levels, st);

@@ -27,7 +27,7 @@ static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
   hipError_t e = cache.facts(iss_walk_kernel<C>, kWalkThreads, lds,
                              a.persistent ? &per_cu : nullptr);
   if (e != hipSuccess) return e;
-  const int64_t units = TEAM == 1 ? a.N : a.N * a.G;
+  const int64_t units = a.N * a.G;
   if (units > 0x7fffffffLL) return hipErrorInvalidValue;  // unit indices are 32-bit in the kernel
   int64_t blocks = units;
   if (a.persistent) {

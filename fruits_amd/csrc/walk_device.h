@@ -1140,10 +1140,11 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
   // first round the resident workgroups write CONSECUTIVE series of every output plane.
   // (Round 2 tried contiguous spans of units per workgroup - even spans, one staging shared
   // by the groups of a series: 5-10 % slower at every batch size)
-  // TEAM = 1: a unit is a series, its G = TEAMS groups go to the 4 waves.
   int sink = 0;  // next-series prefetch (see below): one word per 128-byte line of the rows
   int pf_val = 0, pf_off = -1;
-  if constexpr (C::TEAM != 1 && C::MODE == 0) {
+  static_assert(C::TEAM == 4 && C::MODE == 0,
+                "the materialising interpreter (fused: walk_fused.h; short series: walk_packed.h)");
+  {
     const int lines = (int)((a.T * 8 + 127) >> 7);
     if (a.prefetch_next && a.nchunks == 1 && a.D * a.T < (1 << 30) && tid < a.R * lines) {
       const int r = tid / lines, line = tid - r * lines;
@@ -1151,14 +1152,11 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
       if (src >= 0) pf_off = src * (int)a.T + line * 16;
     }
   }
-  const int u_end = C::TEAM == 1 ? (int)a.N : (int)(a.N * a.G);  // (the host checks < 2^31)
+  const int u_end = (int)(a.N * a.G);  // (the host checks < 2^31)
   for (int u = blockIdx.x; u < u_end; u += gridDim.x) {
     int64_t n;
     int g0;
-    if constexpr (C::TEAM == 1) {
-      n = u;
-      g0 = cx.team;
-    } else if (a.xcd_map) {
+    if (a.xcd_map) {
       const int q = u >> 3, r = u & 7;
       n = (int64_t)(q / a.G) * 8 + r;
       g0 = q % a.G;
@@ -1179,12 +1177,6 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
       cx.first_chunk = chunk == 0;
       cx.full_chunk = t0 + C::CHUNK <= a.T;
       cx.out_base = a.out + n * a.out_n_stride + t0;
-      if constexpr (C::MODE == 1) {
-        cx.feat_row = a.feats + n * a.feat_stride;
-        cx.cnt_row = a.cnt + n * a.feat_stride;
-        cx.cut_row = a.series_cuts ? a.series_cuts + n * a.cut_slots : nullptr;
-        cx.series = n;
-      }
       if (!first_unit || chunk > 0) lds_barrier();  // all reads of the old rows are done
       // stage the referenced rows of this chunk: coalesced 16-byte units, the
       // loads of kStageRows rows in flight before the first LDS write
@@ -1198,58 +1190,19 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
         for (int rr = 0; rr < kStageRows; ++rr) {
           if (r0 + rr < a.R) {
             const int src = as_const(a.row_src)[r0 + rr];
-            bool prepared = false;
-            if constexpr (C::MODE == 1 && C::TEAM != 1) {
-              if (a.prep != nullptr && src >= 0) {
-                // fused preparation: the row is formed from the RAW input while it is staged -
-                // INC (x[t] - x[t - lag], zero-padded: fruits/cache.py:8-13), NEW(INC) (the
-                // prepared dimension names a raw dimension and a lag) and STD's apply step
-                // ((x - mean) / (std + eps), fruits/preparation/transform.py:141-147; the
-                // statistics come from row_stats_kernel)
-                prepared = true;
-                const int raw = as_const(a.prep)[4 * src], lag = as_const(a.prep)[4 * src + 1];
-                const bool standardise = as_const(a.prep)[4 * src + 2] != 0;
-                const double *gp = a.X + (n * a.D + raw) * a.T;
-                double mean = 0.0, den = 1.0;
-                if (standardise) {
-                  mean = as_const(a.stats)[(n * a.n_prep + src) * 2];
-                  den = as_const(a.stats)[(n * a.n_prep + src) * 2 + 1];
-                }
+            const double *gp =
+                src >= 0 ? a.X + (n * a.D + src) * a.T
+                         : a.aux + (int64_t)(-src - 1) * a.aux_tab_stride + n * a.aux_n_stride;
 #pragma unroll
-                for (int k = 0; k < U; ++k) {
-                  const int i = 2 * (k * kWalkThreads + tid);
-                  const int64_t t = t0 + i;
-                  double e0 = 0.0, e1 = 0.0;
-                  if (t < a.T) e0 = gp[t];
-                  if (t + 1 < a.T) e1 = gp[t + 1];
-                  if (lag > 0) {
-                    e0 = (t >= lag && t < a.T) ? e0 - gp[t - lag] : 0.0;
-                    e1 = (t + 1 >= lag && t + 1 < a.T) ? e1 - gp[t + 1 - lag] : 0.0;
-                  }
-                  if (standardise) {
-                    e0 = (e0 - mean) / den;
-                    e1 = (e1 - mean) / den;
-                  }
-                  // (elements beyond T stay what the unfused path stages there: zeros)
-                  v[rr][k] = vd2{t < a.T ? e0 : 0.0, t + 1 < a.T ? e1 : 0.0};
-                }
-              }
-            }
-            if (!prepared) {
-              const double *gp =
-                  src >= 0 ? a.X + (n * a.D + src) * a.T
-                           : a.aux + (int64_t)(-src - 1) * a.aux_tab_stride + n * a.aux_n_stride;
-#pragma unroll
-              for (int k = 0; k < U; ++k) {
-                const int i = 2 * (k * kWalkThreads + tid);
-                const int64_t t = t0 + i;
-                v[rr][k] = vd2{0.0, 0.0};
-                if (a.vec_ok) {
-                  if (cx.full_chunk || t < a.T) v[rr][k] = load_input<C::NT>(gp + t);
-                } else {
-                  if (t < a.T) v[rr][k].x = gp[t];
-                  if (t + 1 < a.T) v[rr][k].y = gp[t + 1];
-                }
+            for (int k = 0; k < U; ++k) {
+              const int i = 2 * (k * kWalkThreads + tid);
+              const int64_t t = t0 + i;
+              v[rr][k] = vd2{0.0, 0.0};
+              if (a.vec_ok) {
+                if (cx.full_chunk || t < a.T) v[rr][k] = load_input<C::NT>(gp + t);
+              } else {
+                if (t < a.T) v[rr][k].x = gp[t];
+                if (t + 1 < a.T) v[rr][k].y = gp[t + 1];
               }
             }
           }
@@ -1266,7 +1219,7 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
         }
       }
       __syncthreads();
-      if constexpr (C::TEAM != 1 && C::MODE == 0) {
+      {
         if (a.prefetch_next && a.nchunks == 1) {
           // Touch one word per 128-byte line of the rows of this workgroup's NEXT unit, so
           // that its staging - issued when the memory system is full of this kernel's

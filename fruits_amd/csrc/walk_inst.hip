@@ -5,20 +5,6 @@
 
 namespace fr {
 
-#ifdef WALK_TEAM1
-// wave-per-row variant: single chunk, aligned accesses, shallow tries
-template <int P>
-static hipError_t team1_p(const IssArgs &a, int levels, hipStream_t st) {
-  if (levels <= 2)
-    return a.aux ? launch_walk_cfg<2, P, 2, 0, true, true, 1>(a, st)
-                 : launch_walk_cfg<2, P, 2, 0, true, false, 1>(a, st);
-  return a.aux ? launch_walk_cfg<2, P, 4, 0, true, true, 1>(a, st)
-               : launch_walk_cfg<2, P, 4, 0, true, false, 1>(a, st);
-}
-hipError_t walk_inst_team1(const IssArgs &a, int levels, int chunk, hipStream_t st) {
-  return chunk == 512 ? team1_p<4>(a, levels, st) : team1_p<8>(a, levels, st);
-}
-#else
 #if WALK_MODE == 1
 // The fused walk (walk_fused.h): 4 consecutive elements per lane for 1024-element chunks, 2 for
 // 512-element ones; carries of a multi-chunk walk always live in LDS (the host sizes the groups
@@ -100,7 +86,6 @@ hipError_t WALK_CAT(walk_inst_m, WALK_MODE, _l, WALK_LV)(const IssArgs &a, int c
 #endif
   return chunk == 512 ? inst_p<1>(a, st) : inst_p<2>(a, st);
 }
-#endif
 #endif
 
 }  // namespace fr

@@ -113,7 +113,6 @@ struct IssArgs {
   int32_t semiring;         // kSemiReals / kSemiArctic
   int32_t prefetch_next;    // units of at most this many nodes touch the next unit's rows (0: off)
   int32_t packed;           // short series: wave-per-series kernel (walk_packed.h)
-  int32_t wave_rows;        // TEAM = 1 kernel: one wave per row, 4 groups per workgroup
   // fused sieve epilogue (MODE 1 kernels): features instead of the (K,N,T) tensor
   const FeatOp *ops;        // (K, n_ops_padded) feature ops per output row, 64-byte aligned rows
   double *feats;            // (N, feat_stride) features; every column is written, none is read first

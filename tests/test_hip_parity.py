@@ -213,10 +213,10 @@ def test_bayesian_fused_pipeline(fr):
 @pytest.mark.parametrize("T", [1, 2, 7, 64, 100, 128, 129, 255, 256, 257, 300, 383, 384, 385])
 def test_short_series_kernels(fr, monkeypatch, packed, T):
     """T <= 256 runs on the wave-per-series kernel (four series per workgroup) by default;
-    FRUITS_HIP_PACKED=0 keeps the cooperative kernel.  Both against the C oracle, with a
+    FRUITS_HIP_DEBUG=packed=0 keeps the cooperative kernel.  Both against the C oracle, with a
     series count that leaves waves without work, deep words (8 register levels), a
     per-series (L1) and a broadcast (Indices) lookup."""
-    monkeypatch.setenv("FRUITS_HIP_PACKED", packed)
+    monkeypatch.setenv("FRUITS_HIP_DEBUG", f"packed={packed}")
     rng = np.random.default_rng(T)
     X = rng.standard_normal((13, 2, T)) / 2
     words = G.manifest["words"]["4,2"]["words"][:40] + ["[1][2][1][2][1][2][1][2]", "[2][-1]"]
@@ -608,14 +608,14 @@ def test_coswiss_long_series(fr, T, total):
 
 
 def test_coswiss_short_series_cooperative(fr, monkeypatch):
-    # T <= 384 runs one wave per (series, word, frequency) unit; FRUITS_HIP_PACKED=0 keeps the
+    # T <= 384 runs one wave per (series, word, frequency) unit; FRUITS_HIP_DEBUG=packed=0 keeps the
     # cooperative kernel - both against the oracle
     X = np.random.default_rng(9).random((7, 2, 100)) + 0.25
     words, freqs = ["[1]", "[2][1]", "[1][2][2]"], [0.15, 0.5]
     ref = orc.coswiss_transform(X, words, freqs, 2, True)
     scale = np.abs(ref).max(axis=2, keepdims=True)
     for packed in ("1", "0"):
-        monkeypatch.setenv("FRUITS_HIP_PACKED", packed)
+        monkeypatch.setenv("FRUITS_HIP_DEBUG", f"packed={packed}")
         out = fr.CosWISS([fr.words.SimpleWord(s) for s in words], freqs, exponent=2,
                          total_weighting=True).fit_transform(X)
         assert np.all(np.abs(out - ref) <= RTOL * np.maximum(np.abs(ref), 1e-3 * scale))

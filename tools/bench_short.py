@@ -10,7 +10,7 @@ for N, T in ((8192, 256), (8192, 250), (16384, 128), (16384, 100), (32768, 64), 
     X = torch.randn((N, 3, T), dtype=torch.float64, device="cuda")
     out = torch.empty((K, N, T), dtype=torch.float64, device="cuda")
     t = graph_time(lambda: plan.run(X, None, out=out))
-    print(f"PACKED={os.environ.get('FRUITS_HIP_PACKED', '1')} N={N} T={T}: {t:.1f} us "
+    print(f"PACKED={os.environ.get('FRUITS_HIP_DEBUG', 'packed=1')} N={N} T={T}: {t:.1f} us "
           f"{8.0*N*T*(3+K)/t/1e6:.2f} TB/s", flush=True)
 # fused pipeline on short series
 X = np.random.default_rng(0).standard_normal((8192, 3, 128))
@@ -22,4 +22,4 @@ slc = fruit.get_slice(0); cache = fr.cache.SharedSeedCache(X)
 Pd = slc._prepare_device(cache.input_device(X), cache); pipe = slc._fused(128)
 feats = torch.empty((8192, pipe.n_features), dtype=torch.float64, device="cuda")
 t = graph_time(lambda: pipe.run(Pd, None, feats=feats))
-print(f"PACKED={os.environ.get('FRUITS_HIP_PACKED', '1')} fused of_weight(4,2) (8192,3,128): {t:.1f} us", flush=True)
+print(f"PACKED={os.environ.get('FRUITS_HIP_DEBUG', 'packed=1')} fused of_weight(4,2) (8192,3,128): {t:.1f} us", flush=True)

@@ -2,8 +2,8 @@
 import os, sys
 import numpy as np
 sys.path.insert(0, '.')
-os.environ["FRUITS_HIP_DEBUG"] = str(16 | int(os.environ.get("DBG_EXTRA", "0")))
-os.environ["FRUITS_HIP_DBG_BYTES"] = str(1 << 22)
+os.environ["FRUITS_HIP_DEBUG"] = (f"stamps={16 | int(os.environ.get('DBG_EXTRA', '0'))},dbg_bytes={1 << 22},"
+                                  f"persist={os.environ.get('DBG_PERSIST', '1')}")
 import torch
 import fruits_amd as fr
 from fruits_amd import _native as nat
@@ -21,7 +21,7 @@ torch.cuda.synchronize()
 work.zero_()
 plan.run(Xd, None, out=out, work=work); torch.cuda.synchronize()
 raw = work[:].cpu().numpy().view(np.uint64)
-nwaves = min(N, 1536) * 4 if os.environ.get("FRUITS_HIP_PERSIST", "1") != "0" else N * 4
+nwaves = min(N, 1536) * 4 if os.environ.get("DBG_PERSIST", "1") != "0" else N * 4
 st = raw[: nwaves * 12].reshape(nwaves, 12).astype(np.float64)
 names = ["interp", "factors", "scan-local", "lds+barrier", "prefix+final", "stores", "staging", "-"]
 tot = st[:, 8]
