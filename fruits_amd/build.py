@@ -35,7 +35,7 @@ def units():
     for mode in (0, 1):
         for lv in (2, 4, 6, 8):
             out.append((f"walk_m{mode}_l{lv}", "walk_inst.hip",
-                        [f"-DWALK_MODE={mode}", f"-DWALK_LV={lv}"] + (fused if mode else [])))
+                        [f"-DWALK_MODE={mode}", f"-DWALK_LV={lv}"] + (fused if mode else fused[1:])))
     for lv in (2, 4, 6, 8):
         out.append((f"walk_m1ti_l{lv}", "walk_inst.hip",
                     ["-DWALK_MODE=1", f"-DWALK_LV={lv}", "-DWALK_TI"] + fused))

@@ -631,9 +631,10 @@ __device__ __forceinline__ void stage_chunk(const WalkCtx &cx, const IssArgs &a,
 
 // LDS of the fused kernel: rows [R][CHUNK] | totals window [2][8] | tails [2][4] | carries
 // [carry_slots] (MULTI) | feature window (values, populations, columns)
+// (No waves-per-SIMD attribute: every instance fits 128 VGPRs - four waves - without one, and
+// with it the 8-level one-chunk instances spilled a few registers for nothing.)
 template <class C, bool TOTAL>
-__global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_waves_per_eu(4)))
-void iss_fused_kernel(const IssArgs a) {
+__global__ __launch_bounds__(kWalkThreads) void iss_fused_kernel(const IssArgs a) {
   static_assert(C::MODE == 1 && C::TEAM == 4 && C::P == 1 && C::MULTI != 2, "fused configuration");
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
@@ -681,10 +682,7 @@ void iss_fused_kernel(const IssArgs a) {
   const int node_begin = as_const(a.group_begin)[g0];
   int sink = 0;
   cx.pc_begin = node_begin;
-  cx.feat_row = a.feats + n * a.feat_stride;
-  cx.cnt_row = a.cnt + n * a.feat_stride;
-  cx.cut_row = a.series_cuts ? a.series_cuts + n * a.cut_slots : nullptr;
-  cx.series = n;
+  cx.series = n;   // (feature rows, cut rows: addressed from it where they are needed)
   for (int chunk = 0; chunk < a.nchunks; ++chunk) {
     const int64_t t0 = (int64_t)chunk * C::CHUNK;
     cx.t0 = t0;
@@ -699,7 +697,7 @@ void iss_fused_kernel(const IssArgs a) {
     // chunk leaves its share (added onto the earlier chunks' in global memory)
     if (!a.feat_fits || chunk + 1 == a.nchunks) feat_flush<C>(cx, !a.feat_fits && chunk > 0);
   }
-  if (sink == 0x7fffffff) cx.feat_row[0] = 0.0;   // (keeps the cache-touching loads alive)
+  if (sink == 0x7fffffff) a.feats[0] = 0.0;   // (keeps the cache-touching loads alive)
 }
 
 }  // namespace fr

@@ -6,7 +6,10 @@ flags = sys.argv[2:]
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
        "-Rpass-analysis=kernel-resource-usage", "-x", "hip", "-c", "fruits_amd/csrc/" + src,
        "-o", "/tmp/_ru.o"] + flags
-err = subprocess.run(cmd, capture_output=True, text=True).stderr
+run = subprocess.run(cmd, capture_output=True, text=True)
+err = run.stderr
+if run.returncode != 0:
+    sys.exit("compilation failed:\n" + "\n".join(l for l in err.splitlines() if "error" in l)[:4000])
 filt = shutil.which("c++filt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
 rows, cur = [], None
 for line in err.splitlines():
