@@ -319,9 +319,11 @@ int choose_groups_walk(const fr::Plan &p, int64_t N, int64_t resident, bool fuse
     return (int)std::max<int64_t>(1, std::min<int64_t>(G, U));
   }
   // fused launches run one short-lived workgroup per unit (run_walk): two groups per series
-  // balance a little better than whole series (configs 3 / 4 / 5: 529 -> 516 us, 22.0 -> 21.5 ms,
-  // 37.2 -> 36.3 ms; three groups: 514 us, 21.4 ms, 37.8 ms)
-  if (fused) return std::min(U, 2);
+  // balance a little better than whole series on LONG plans (config 4, 1351 nodes: 13.08 vs
+  // 13.32 ms); on shorter ones every extra unit is one more staging of the series' rows - the
+  // word shards of config 4 over 8 ranks (~170 nodes each): 1.86 ms with whole series, 2.40 ms
+  // with two groups (tools/bench_shards.py)
+  if (fused) return p.nodes.size() >= 400 ? std::min(U, 2) : 1;   // (config 5, 511 nodes: 24.9 vs 25.3 ms)
   if (N < 2 * resident || p.nodes.size() > 32) return 1;
   return std::min(U, 3);
 }

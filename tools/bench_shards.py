@@ -1,37 +1,47 @@
-"""Config 4 (fruit_general slice 1, of_weight(6,2) + Indices, (8192,3,1024)) word-sharded over
-1/2/4/8 ranks, every rank's fused launch timed on ONE GPU (loop-back): the 8-GPU time of the
-compute part is the slowest rank's; the all-gather volume per link follows from the block widths."""
+"""Config 4 (fruit_general slice 1, of_weight(6,2) + Indices, (8192,3,1024)) sharded over 1/2/4/8
+ranks, every rank's fused launch (raw batch in, INC in the staging) timed ALONE on ONE GPU
+(loop-back): word shards (every rank the whole batch and its share of the word list) and series
+shards (every rank the whole word list on N / world rows).  The multi-GPU time of the compute part
+is the slowest rank's; the all-gather volume per link follows from the block widths."""
 import sys, json, numpy as np, torch
-sys.path.insert(0, "."); sys.path.insert(0, "tools")
+sys.path.insert(0, ".")
 import fruits_amd as fr
-from fruits_amd import parallel as par
-from bench_pipeline import graph_time
-N, D, T = 8192, 3, 1024
-X = np.random.default_rng(0).standard_normal((N, D, T))
-fruit = fr.Fruit("general slice 1")
-fruit.add(fr.preparation.INC)
-iss = fr.ISS(fr.words.of_weight(6, 2), mode=fr.ISSMode.EXTENDED, weighting=fr.iss.weighting.Indices())
-fruit.add(iss)
-fruit.add(fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END)
-for s in fruit: s.fit_sample_size = 1.0
-np.random.seed(0); fruit.fit(X[:128])
-slc = fruit.get_slice(0); cache = fr.cache.SharedSeedCache(X)
-Pd = slc._prepare_device(cache.input_device(X), cache); slc._attach(cache)
-lk = iss.lookup_device(Pd)
-strings = [str(w) for w in iss.words]
-depths = [iss._depth(i) for i in range(len(strings))]
-per_sum = sum(s.nfeatures() for s in slc.get_sieves())
-for world in (1, 2, 4, 8):
-    parts = par.shard_words(strings, depths, world)
-    times, widths = [], []
+from fruits_amd import _native as nat, parallel as par
+import bench
+
+p = bench._config4(torch, fr, nat)
+N, T = p.N, p.T
+
+
+def timed(fn, reps=3):
+    return bench._event_time_us(torch, fn, reps=reps) / 1e3
+
+
+fn1, _, pipe1 = p.launch()
+t_one = timed(fn1)
+print(json.dumps({"unsharded_ms": round(t_one, 2), "K": pipe1.plan.rows, "nodes": pipe1.plan.nodes}), flush=True)
+for world in (2, 4, 8):
+    parts = par.shard_words(p.strings, p.depths, world)
+    times, widths, nodes = [], [], []
     for r in range(world):
-        pipe = slc._fused(T, indices=parts[r])
-        feats = torch.empty((N, pipe.n_features), dtype=torch.float64, device="cuda")
-        times.append(graph_time(lambda: pipe.run(Pd, lk, feats=feats), reps=3, rounds=3) / 1e3)
+        fn, _, pipe = p.launch(indices=parts[r])
+        times.append(timed(fn))
         widths.append(pipe.n_features)
-        del feats
+        nodes.append(pipe.plan.nodes)
+    series = []
+    for r in range(world):
+        rows = par.shard_series(N, r, world)
+        Xr = p.Xd[rows].contiguous()
+        pipe = p.slc._fused(T)
+        pipe.set_preparation(p.D, *p.chain)
+        feats = torch.empty((Xr.shape[0], pipe.n_features), dtype=torch.float64, device="cuda")
+        series.append(timed(lambda: pipe.run(Xr, p.lk, feats=feats)))
     gather_mb = max(widths) * N * 8 / 1e6
-    print(json.dumps({"world": world, "rank_ms": [round(t, 2) for t in times],
-                      "slowest_ms": round(max(times), 2), "balance": round(np.mean(times) / max(times), 3),
-                      "speedup_vs_1": None, "block_MB_per_rank": round(gather_mb, 1),
+    print(json.dumps({"world": world, "word_rank_ms": [round(t, 2) for t in times],
+                      "word_slowest_ms": round(max(times), 2),
+                      "word_slowest_over_ideal": round(max(times) / (t_one / world), 3),
+                      "nodes_per_rank": nodes, "nodes_over_ideal": round(max(nodes) / (pipe1.plan.nodes / world), 3),
+                      "series_slowest_ms": round(max(series), 2),
+                      "series_slowest_over_ideal": round(max(series) / (t_one / world), 3),
+                      "block_MB_per_rank": round(gather_mb, 1),
                       "allgather_ms_at_153GBs_per_link": round(gather_mb / 153e3 * 1e3, 3)}), flush=True)
