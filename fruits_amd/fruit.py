@@ -312,9 +312,13 @@ class FruitSlice:
                 cb.on_preparateur(nat.to_host(Xd))
         return Xd
 
-    def _iterate_iss_device(self, Xd, iss_index: int = 0) -> Generator:
+    def _iterate_iss_device(self, Xd, iss_index: int = 0, upto: Optional[int] = None) -> Generator:
         """Yields every iterated sum as an (N, T) device tensor, in the order of
-        fruits/fruit.py:440-454 (chained ISS feed each row to the next ISS)."""
+        fruits/fruit.py:440-454 (chained ISS feed each row to the next ISS).  ``upto``: stop in
+        front of that ISS of the chain and yield its (N, 1, T) INPUTS instead."""
+        if upto is not None and iss_index == upto:
+            yield Xd
+            return
         if iss_index == len(self._iss):
             yield Xd[:, 0, :]
             return
@@ -326,7 +330,8 @@ class FruitSlice:
                 if iss_index + 1 == len(self._iss):
                     yield block[k]
                 else:
-                    yield from self._iterate_iss_device(block[k].unsqueeze(1), iss_index + 1)
+                    yield from self._iterate_iss_device(block[k].unsqueeze(1).contiguous(),
+                                                        iss_index + 1, upto)
 
     # ---- device-side fit ------------------------------------------------------------
     def _fit_on_device(self, Sd, cache) -> bool:
@@ -380,16 +385,19 @@ class FruitSlice:
     def _fusable(self) -> bool:
         from .sieving.increment import MPI, NPI
         from .sieving.segment import END
-        if os.environ.get("FRUITS_AMD_FUSED", "1") == "0" or len(self._iss) != 1:
+        # (a chain of ISS: the LAST one fuses with the sieves, once per row of the chain in front
+        # of it - fruits/fruit.py:440-454 feeds every row of an ISS to the next one)
+        if os.environ.get("FRUITS_AMD_FUSED", "1") == "0" or not self._iss:
             return False
-        if getattr(self._iss[0], "_argmax", False):
+        last = self._iss[-1]
+        if getattr(last, "_argmax", False):
             return False     # (position rows are assembled from materialised maxima)
-        if type(self._iss[0]) is not ISS:
+        if type(last) is not ISS:
             from .iss.cos import CosWISS
             # the factorised CosWISS kernels fuse; the term-by-term path reduces first
-            if type(self._iss[0]) is not CosWISS or not self._iss[0]._native():
+            if type(last) is not CosWISS or not last._native():
                 return False
-            if self._iss[0]._ffn_size is not None:
+            if last._ffn_size is not None:
                 return False     # every (word, frequency) reads its own transformed input
         for sv in self._sieves:
             if type(sv) not in (NPI, MPI, END):
@@ -398,19 +406,23 @@ class FruitSlice:
                 return False     # (beyond 0..2: series of one time chunk; the pipeline says if not)
         return True
 
-    def _fused(self, T: int, indices=None):
+    def _fused(self, T: int, indices=None, chain_row: int = 0):
         """The fused pipeline for series length T (thresholds of the fitted sieve
         copies already resolved), or None when a sieve or the weighting is outside
         the fused set; cached until the next fit.  ``indices``: only these words
         (a rank's share of a word-sharded slice, fruits_amd.parallel); the pipeline
-        then produces the feature columns of their iterated sums, in that order."""
+        then produces the feature columns of their iterated sums, in that order.
+        ``chain_row`` (chained ISS): the pipeline of the LAST ISS for the ``chain_row``-th row of
+        the chain in front of it - the same program, that row's thresholds."""
         key = T if indices is None else (T, tuple(indices))
+        if chain_row:
+            key = (key, chain_row)
         if key in self._fused_cache:
             return self._fused_cache[key]
         entry = None
         if self._fusable():
             from .sieving.segment import END
-            iss = self._iss[0]
+            iss = self._iss[-1]
             iss._check_supported()
             if hasattr(iss, "_arm_plan"):     # CosWISS dropout: the plan carries the mask
                 iss._check_supported()
@@ -426,6 +438,8 @@ class FruitSlice:
                 first = np.concatenate([[0], np.cumsum(
                     [iss._depth(i) for i in range(len(iss.words))])]).astype(int)
                 rows = [r for i in indices for r in range(first[i], first[i + 1])]
+            if chain_row:
+                rows = [chain_row * iss.n_iterated_sums() + r for r in rows]
             # float ("coquantile") cuts differ from series to series: such a sieve names
             # columns of a per-series table instead of indices; sieves with the same cuts
             # share their columns (so NPI / MPI pairs still merge)
@@ -576,7 +590,7 @@ class FruitSlice:
             cache = SharedSeedCache(X)
         t = nat.torch()
         Xd = cache.input_device(X) if cache._input is X else nat.to_device(X)
-        if not callbacks:
+        if not callbacks and len(self._iss) == 1:
             # INC / NEW(INC) / STD formed while the fused launch stages the RAW rows: no
             # prepared tensor is written (one launch [+ the STD statistics pre-pass])
             T = int(Xd.shape[2])
@@ -595,6 +609,8 @@ class FruitSlice:
             cb.on_preparation_end(nat.to_host(Pd))
         self._attach(cache)
         fused = None if callbacks else self._fused(int(Pd.shape[2]))
+        if fused is not None and len(self._iss) > 1:
+            return self._transform_chain_fused(Pd, cache)
         if fused is not None:
             if fused.raw_dims > 0:       # (was configured for raw input by another call)
                 fused.set_preparation(int(Pd.shape[1]))
@@ -618,6 +634,24 @@ class FruitSlice:
             out = nat.to_host(feats)
             for cb in callbacks:
                 cb.on_sieving_end(out)
+        return feats
+
+    def _transform_chain_fused(self, Pd, cache):
+        """Chained ISS (fruits/fruit.py:440-454): the rows of the chain in front of the last ISS
+        are materialised one word batch at a time, and every one of them goes through ONE fused
+        launch of the last ISS + the sieves (that row's thresholds) - K_chain launches instead of
+        K_chain x K_last x |sieves|, and no (K_chain x K_last, N, T) tensor."""
+        t = nat.torch()
+        N, T = int(Pd.shape[0]), int(Pd.shape[2])
+        last = self._iss[-1]
+        width = last.n_iterated_sums() * sum(sv.nfeatures() for sv in self._sieves)
+        feats = t.empty((N, self.nfeatures()), dtype=t.float64, device=Pd.device)
+        for r, Xin in enumerate(self._iterate_iss_device(Pd, 0, upto=len(self._iss) - 1)):
+            pipe = self._fused(T, chain_row=r)
+            if pipe.raw_dims > 0:
+                pipe.set_preparation(1)
+            self._arm_series_cuts(pipe, N, T, cache)
+            feats[:, r * width:(r + 1) * width] = pipe.run(Xin, last.lookup_device(Xin))
         return feats
 
     def fit_transform(self, X: np.ndarray) -> np.ndarray:

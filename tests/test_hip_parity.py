@@ -1355,6 +1355,37 @@ def test_custom_weighting_sees_the_prepared_input(fr, monkeypatch, prep):
     compare_features(got, plain, labels, what=f"custom weighting behind {prep}")
 
 
+@pytest.mark.parametrize("T", [60, 600, 1100])
+@pytest.mark.parametrize("semiring", ["Reals", "Arctic"])
+def test_chained_iss_fuses_its_last_stage(fr, monkeypatch, T, semiring):
+    """A chain of ISS (fruits/fruit.py:440-454): the last ISS and the sieves run as one fused
+    launch per row of the chain in front of it - same features as the unfused path (a sieve launch
+    per iterated sum and sieve) and as the oracle; short, one-chunk and multi-chunk series."""
+    rng = np.random.default_rng(T)
+    X = rng.standard_normal((7, 2, T)).cumsum(axis=2) / 6.0
+    spec = {"slices": [{"preps": [{"kind": "INC"}],
+                        "iss": [{"words": ["[1]", "[12]", "[2][1]"], "mode": "EXTENDED", "semiring": semiring},
+                                {"words": ["[1]", "[1][1]", "[11]"], "mode": "SINGLE", "semiring": semiring,
+                                 "weighting": {"kind": "Indices", "scale": 2.0}}],
+                        "sieves": [{"kind": "NPI", "q": [0.4, 1.0]}, {"kind": "MPI", "inc": 0, "cut": [T // 3, -1]},
+                                   {"kind": "END"}],
+                        "fit_sample_size": 1.0}]}
+    fruit = build_fruit(fr, spec)
+    np.random.seed(2)
+    fruit.fit(X)
+    slc = fruit.get_slice()
+    assert slc._fused(T) is not None and slc._fused(T, chain_row=3) is not None
+    assert slc._fused(T, chain_row=3) is not slc._fused(T)
+    got = fruit.transform(X)
+    labels = [fruit.label(i) for i in range(fruit.nfeatures())]
+    ref, expo = oracle_features(spec, X, X, np_seed=2)
+    compare_features(got, ref, labels, expo, what=f"chained ISS {semiring} T={T}")
+    monkeypatch.setenv("FRUITS_AMD_FUSED", "0")
+    slc._fused_cache = {}
+    plain = fruit.transform(X)
+    compare_features(got, plain, labels, what=f"chained ISS {semiring} T={T} vs unfused")
+
+
 def test_fused_pipeline_is_cached_per_length(fr):
     """FruitSlice._fused keeps ONE pipeline per series length until the next fit - also for a
     slice with float (coquantile) cuts, whose cut columns must not replace the cache key."""
