@@ -463,8 +463,14 @@ class Pipeline:
 
     def prepare(self, N: int, groups: int = 0) -> None:
         """fr_pipeline_prepare: uploads the plan's tables for batches of N series so
-        that ``run`` only enqueues work (hipGraph capture)."""
+        that ``run`` only enqueues work (hipGraph capture), and compiles the pipeline's own
+        kernel - the fused walk with its sieves as compile-time constants (hipRTC, cached on disk;
+        FRUITS_HIP_JIT=0: not)."""
         check(lib().fr_pipeline_prepare(self._h, int(N), int(groups)), "fr_pipeline_prepare")
+
+    def jit_loaded(self) -> int:
+        """Run-time compiled kernels this pipeline holds."""
+        return int(lib().fr_pipeline_info(self._h, 3))
 
     def run(self, Xd, lookup_d, feats=None, groups: int = 0, work=None):
         t = torch()

@@ -117,7 +117,7 @@ def build_native(force: bool = False, verbose: bool = False, jobs: int = 0,
     return lib
 
 
-JIT_HEADERS = ["walk_types.h", "walk_scan.h", "walk_device.h"]
+JIT_HEADERS = ["walk_types.h", "walk_scan.h", "walk_device.h", "walk_fused.h"]
 
 
 def write_jit_sources() -> str:

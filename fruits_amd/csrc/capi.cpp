@@ -673,6 +673,44 @@ int32_t fr_plan_jit(fr_plan_t *plan, int32_t groups, int32_t compile_only, char 
 
 }  // extern "C"
 
+struct PipeSieve {
+  int32_t kind, inc, Q1, col, q_off;
+  bool series_cuts = false;    // cuts are slots of the per-series table (coquantile cuts)
+  std::vector<int32_t> cuts;   // transformed, clamped to [0, T]
+};
+
+struct fr_pipeline {
+  fr_plan_t *plan = nullptr;
+  int64_t T = 0;
+  int32_t per_sum = 0, q_stride = 0, n_ops = 0, n_ops_padded = 0;
+  int32_t n_ops_eff = 0;           // ops per row after dropping NPI ops an MPI op covers
+  std::vector<int32_t> npi_pairs;  // (npi column, mpi column) inside one iterated sum's block
+  void *d_npi_pairs = nullptr;
+  std::vector<PipeSieve> sieves;
+  std::vector<int32_t> mpi_cols;   // columns inside one iterated sum's block
+  void *d_ops = nullptr;           // (K, n_ops_padded) FeatOp
+  void *d_mpi_cols = nullptr;
+  bool have_quantiles = false;
+  // per-series cut table (fr_pipeline_set_series_cuts): device (cuts_N, cut_slots) int32, owned
+  // by the caller; cut_slots_needed = 1 + the highest slot a sieve names
+  const int32_t *d_series_cuts = nullptr;
+  int64_t cuts_N = 0;
+  int32_t cut_slots = 0, cut_slots_needed = 0;
+  // fused preparation (fr_pipeline_set_preparation): 0 dims = none
+  int32_t prep_D = 0, prep_n = 0, prep_std = 0;
+  double prep_eps = 0.0;
+  void *d_prep = nullptr;          // (prep_n, 4) int32
+  // run-time compiled fused kernels (jit.cpp, walk_fused.h JitOps): the sieves' kind /
+  // differencing order / shape / cuts, the same for every output row, as immediates; compiled by
+  // fr_pipeline_prepare for the kernel instantiation the plan and T select, dropped when the
+  // thresholds (and with them the ops) are set again
+  fr::FusedOps jit_ops;
+  bool jit_uniform = false;        // every row's ops agree in what becomes an immediate
+  std::map<uint32_t, fr::JitProgram> jit;
+  std::map<uint32_t, std::string> jit_failed;
+};
+
+
 namespace {
 
 struct FusedArgs {          // non-null feats selects the fused sieve kernels
@@ -681,6 +719,7 @@ struct FusedArgs {          // non-null feats selects the fused sieve kernels
   int64_t feat_stride = 0;
   int32_t n_ops = 0, n_ops_padded = 0;
   bool has_mpi = false;     // cnt is a population table of its own
+  fr_pipeline *pl = nullptr;   // the pipeline (its run-time compiled kernels), if any
   const int32_t *series_cuts = nullptr;   // device (N, cut_slots) per-series boundaries
   int32_t cut_slots = 0;
   bool total_inc = false;   // a differencing sieve on a totally weighted plan
@@ -689,6 +728,34 @@ struct FusedArgs {          // non-null feats selects the fused sieve kernels
   const double *stats = nullptr;   // device (N, n_prep, 2) or nullptr (no STD)
   int32_t n_prep = 0;
 };
+
+// The instantiation of the fused walk a (plan, series length, sieves) selects - what
+// walk_inst.hip's dispatch picks at launch time, as a key for the run-time compiled variants.
+fr::FusedKey fused_key_for(const fr::Plan &p, int64_t T, bool total_inc) {
+  const int64_t chunk = fr::walk_chunk_elems(T);
+  fr::FusedKey k{};
+  k.E = chunk == 512 ? 2 : 4;
+  k.LV = p.levels <= 2 ? 2 : (p.levels <= 4 ? 4 : (p.levels <= 6 ? 6 : 8));
+  k.MULTI = T > chunk ? 1 : 0;
+  k.W = p.weighting != 0 ? 1 : 0;
+  k.SEMI = p.semiring;
+  k.TI = (k.W && total_inc && p.weighting == FR_W_TOTAL) ? 1 : 0;
+  k.TOTAL = (k.W && p.weighting == FR_W_TOTAL) ? 1 : 0;
+  return k;
+}
+
+// Compiles (hipRTC, disk cache) and loads the pipeline's fused kernel with its sieves as
+// immediates, once per instantiation; a failure leaves the pipeline on the generic kernel.
+void ensure_fused_jit(fr_pipeline &pl, const fr::FusedKey &key) {
+  const uint32_t id = key.packed();
+  if (!pl.jit_uniform || pl.jit.count(id) || pl.jit_failed.count(id)) return;
+  fr::JitProgram prog;
+  std::string err;
+  if (fr::jit_fused(pl.jit_ops, key, prog, err))
+    pl.jit[id] = prog;
+  else
+    pl.jit_failed[id] = err;
+}
 
 // Shared body of fr_iss_run and fr_pipeline_run: validates, lays out the
 // workspace, fills the exp tables and launches the trie walk.
@@ -979,41 +1046,26 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   // static programs of several groups run one short-lived workgroup per unit: the hardware
   // dispatcher balances them and keeps the write front compact
   if (static_prog) a.persistent = 0;
+  if (fu && fu->pl && !packed && !fu->pl->jit.empty()) {
+    // the pipeline's run-time compiled kernel for this instantiation (fr_pipeline_prepare)
+    const fr::FusedKey key = fused_key_for(p, T, fu->total_inc);
+    auto it = fu->pl->jit.find(key.packed());
+    if (it != fu->pl->jit.end() && it->second.device == fr::current_device()) {
+      const int64_t chunk = fr::walk_chunk_elems(T);
+      a.nchunks = (int32_t)((T + chunk - 1) / chunk);
+      const size_t lds = ((size_t)a.R * chunk + 16 + 8 + (a.nchunks > 1 ? a.carry_slots : 0)) * 8 +
+                         fr::feat_window_bytes(a.feat_window, a.has_mpi != 0);
+      hipError_t je = fr::jit_launch_fused(it->second, a, lds, st);
+      if (je != hipSuccess) return hip_fail(je, "fused walk (run-time compiled) launch");
+      return FR_OK;
+    }
+  }
   hipError_t e = jit_prog ? fr::jit_launch(*jit_prog, a, st) : fr::launch_iss_walk(a, p.levels, st);
   if (e != hipSuccess) return hip_fail(e, "iss_walk launch");
   return FR_OK;
 }
 
 }  // namespace
-
-struct PipeSieve {
-  int32_t kind, inc, Q1, col, q_off;
-  bool series_cuts = false;    // cuts are slots of the per-series table (coquantile cuts)
-  std::vector<int32_t> cuts;   // transformed, clamped to [0, T]
-};
-
-struct fr_pipeline {
-  fr_plan_t *plan = nullptr;
-  int64_t T = 0;
-  int32_t per_sum = 0, q_stride = 0, n_ops = 0, n_ops_padded = 0;
-  int32_t n_ops_eff = 0;           // ops per row after dropping NPI ops an MPI op covers
-  std::vector<int32_t> npi_pairs;  // (npi column, mpi column) inside one iterated sum's block
-  void *d_npi_pairs = nullptr;
-  std::vector<PipeSieve> sieves;
-  std::vector<int32_t> mpi_cols;   // columns inside one iterated sum's block
-  void *d_ops = nullptr;           // (K, n_ops_padded) FeatOp
-  void *d_mpi_cols = nullptr;
-  bool have_quantiles = false;
-  // per-series cut table (fr_pipeline_set_series_cuts): device (cuts_N, cut_slots) int32, owned
-  // by the caller; cut_slots_needed = 1 + the highest slot a sieve names
-  const int32_t *d_series_cuts = nullptr;
-  int64_t cuts_N = 0;
-  int32_t cut_slots = 0, cut_slots_needed = 0;
-  // fused preparation (fr_pipeline_set_preparation): 0 dims = none
-  int32_t prep_D = 0, prep_n = 0, prep_std = 0;
-  double prep_eps = 0.0;
-  void *d_prep = nullptr;          // (prep_n, 4) int32
-};
 
 extern "C" {
 
@@ -1107,6 +1159,7 @@ void fr_pipeline_destroy(fr_pipeline_t *pl) {
   if (pl->d_mpi_cols) (void)hipFree(pl->d_mpi_cols);
   if (pl->d_npi_pairs) (void)hipFree(pl->d_npi_pairs);
   if (pl->d_prep) (void)hipFree(pl->d_prep);
+  for (auto &kv : pl->jit) fr::jit_unload(kv.second);
   delete pl;
 }
 
@@ -1116,6 +1169,7 @@ int64_t fr_pipeline_info(const fr_pipeline_t *pl, int32_t what) {
     case 0: return pl->per_sum;
     case 1: return pl->q_stride;
     case 2: return (int64_t)pl->per_sum * pl->plan->p->K;
+    case 3: return (int64_t)pl->jit.size();      // run-time compiled kernels loaded
     default: return fail(FR_E_ARG, "fr_pipeline_info: unknown selector");
   }
 }
@@ -1211,6 +1265,28 @@ int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
       HIP_TRY(hipMemcpy(pl->d_npi_pairs, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
     }
   }
+  // What a run-time compiled kernel takes as immediates: per op kind | differencing order | shape
+  // and the cuts - the same for every output row (the shape only if every row's thresholds agree
+  // on it: an infinite threshold in one row alone keeps the generic band).
+  for (auto &kv : pl->jit) fr::jit_unload(kv.second);
+  pl->jit.clear();
+  pl->jit_failed.clear();
+  pl->jit_ops = fr::FusedOps{};
+  pl->jit_uniform = K > 0 && pl->n_ops_eff > 0 && pl->cut_slots_needed == 0;
+  for (int i = 0; i < pl->n_ops_eff && pl->jit_uniform; ++i) {
+    int32_t w0 = ops[i].kind_inc;
+    for (int k = 1; k < K; ++k) {
+      const fr::FeatOp &o = ops[(size_t)k * pl->n_ops_padded + i];
+      if (o.kind_inc != w0) {
+        if (((o.kind_inc ^ w0) & ~(7 << 20)) != 0) pl->jit_uniform = false;
+        w0 &= ~(7 << 20);
+      }
+      if (o.lo != ops[i].lo || o.hi != ops[i].hi) pl->jit_uniform = false;
+    }
+    pl->jit_ops.w0.push_back(w0);
+    pl->jit_ops.lo.push_back(ops[i].lo);
+    pl->jit_ops.hi.push_back(ops[i].hi);
+  }
   const size_t bytes = ops.size() * sizeof(fr::FeatOp);
   if (!pl->d_ops && bytes) HIP_TRY(hipMalloc(&pl->d_ops, bytes));
   if (bytes) HIP_TRY(hipMemcpy(pl->d_ops, ops.data(), bytes, hipMemcpyHostToDevice));
@@ -1272,7 +1348,24 @@ int fr_pipeline_prepare(fr_pipeline_t *pl, int64_t N, int32_t groups) {
     return fail(FR_E_ARG, "fr_pipeline_prepare: bad argument");
   if (!pl->have_quantiles)
     return fail(FR_E_ARG, "fr_pipeline_prepare: call fr_pipeline_set_quantiles first");
-  return prepare_plan(*pl->plan->p, N, pl->T, groups, true, "fr_pipeline_prepare");
+  fr::Plan &p = *pl->plan->p;
+  int rc = prepare_plan(p, N, pl->T, groups, true, "fr_pipeline_prepare");
+  if (rc != FR_OK) return rc;
+  // The pipeline's own kernel: the fused walk with the sieves as compile-time constants (hipRTC,
+  // ~2 s once per pipeline shape, cached on disk); a failure is not the caller's - the generic
+  // kernel runs the pipeline.  Not for the wave-per-series kernels (T <= 384) and CosWISS.
+  if (!p.cos && N > 0 && env_int("FRUITS_HIP_JIT", 1) != 0 && !p.letter_sum) {
+    bool total_inc = false;
+    for (const PipeSieve &sv : pl->sieves)
+      if (sv.kind != FR_SIEVE_END && sv.inc >= 1) total_inc = true;
+    const LaunchShape shape = launch_shape(p, N, pl->T, groups);
+    const bool packed = shape.packed && !(total_inc && p.weighting == FR_W_TOTAL);
+    if (!packed && shape.fits) {
+      std::lock_guard<std::mutex> lock(p.mu);
+      ensure_fused_jit(*pl, fused_key_for(p, pl->T, total_inc));
+    }
+  }
+  return FR_OK;
 }
 
 int fr_pipeline_set_series_cuts(fr_pipeline_t *pl, const int32_t *d_cuts, int64_t N, int32_t slots) {
@@ -1307,6 +1400,7 @@ int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, 
   hipStream_t st = (hipStream_t)stream;
   const size_t plan_ws = align_up(work_layout(p, N, T, p.weighting ? lookup_rows : 0).total(), 256);
   FusedArgs fu;
+  fu.pl = pl;
   fu.ops = static_cast<const fr::FeatOp *>(pl->d_ops);
   fu.feats = d_feats;
   fu.feat_stride = feat_stride;

@@ -212,22 +212,16 @@ std::string jit_source(const StaticSchedule &sc) {
   return o.str();
 }
 
-void jit_cache_drop(const StaticSchedule &sc) {
-  if (!sc.ok) return;
-  std::string dir;
-  const std::string file = cache_file(jit_source(sc), dir);
-  if (!file.empty()) (void)remove(file.c_str());
-}
-
-bool jit_compile(const StaticSchedule &sc, std::string &code, std::string &err, bool *from_cache) {
+// Compiles `src` for gfx950 and returns the payload jit_load takes (code object, lowered name of
+// `kernel_expr`, the name's length); served from the disk cache when it holds a valid object for
+// this source, toolchain and option set.
+static bool compile_source(const std::string &src, const char *kernel_expr, const char *const *opts,
+                           int n_opts, std::string &code, std::string &err, bool *from_cache) {
   if (from_cache) *from_cache = false;
-  if (!sc.ok) {
-    err = "the plan has no static schedule";
-    return false;
-  }
-  const std::string src = jit_source(sc);
+  std::string keyed = src + "\n//" + kernel_expr;
+  for (int i = 0; i < n_opts; ++i) keyed += std::string(" ") + opts[i];
   std::string dir;
-  const std::string file = cache_file(src, dir);
+  const std::string file = cache_file(keyed, dir);
   if (!file.empty()) {
     if (read_cached(file, code)) {
       if (from_cache) *from_cache = true;
@@ -246,9 +240,9 @@ bool jit_compile(const StaticSchedule &sc, std::string &code, std::string &err, 
     return false;
   }
   bool ok = false;
-  if (r.add_name(prog, kKernelExpr) != 0) {
+  if (r.add_name(prog, kernel_expr) != 0) {
     err = "hiprtcAddNameExpression failed";
-  } else if (r.compile(prog, kNumCompileOptions, kCompileOptions) != 0) {
+  } else if (r.compile(prog, n_opts, const_cast<const char **>(opts)) != 0) {
     size_t n = 0;
     r.log_size(prog, &n);
     std::string log(n, '\0');
@@ -257,7 +251,7 @@ bool jit_compile(const StaticSchedule &sc, std::string &code, std::string &err, 
   } else {
     const char *low = nullptr;
     size_t n = 0;
-    if (r.lowered(prog, kKernelExpr, &low) != 0 || !low || r.code_size(prog, &n) != 0 || n == 0) {
+    if (r.lowered(prog, kernel_expr, &low) != 0 || !low || r.code_size(prog, &n) != 0 || n == 0) {
       err = "hipRTC returned no code";
     } else {
       // the code object, then the lowered kernel name (the loader needs it)
@@ -276,7 +270,16 @@ bool jit_compile(const StaticSchedule &sc, std::string &code, std::string &err, 
   return ok;
 }
 
-bool jit_load(const std::string &code, const StaticSchedule &sc, JitProgram &out, std::string &err) {
+static void drop_cached(const std::string &src, const char *kernel_expr, const char *const *opts, int n_opts) {
+  std::string keyed = src + "\n//" + kernel_expr;
+  for (int i = 0; i < n_opts; ++i) keyed += std::string(" ") + opts[i];
+  std::string dir;
+  const std::string file = cache_file(keyed, dir);
+  if (!file.empty()) (void)remove(file.c_str());
+}
+
+// Loads a payload: module + function of the kernel it names.
+static bool load_payload(const std::string &code, hipModule_t &mod, hipFunction_t &fn, std::string &err) {
   if (code.size() < 8) {
     err = "empty code object";
     return false;
@@ -289,15 +292,109 @@ bool jit_load(const std::string &code, const StaticSchedule &sc, JitProgram &out
   }
   const std::string name = code.substr(code.size() - 4 - len, len);
   const std::string image = code.substr(0, code.size() - 4 - len);
-  hipModule_t mod = nullptr;
-  hipFunction_t fn = nullptr;
+  mod = nullptr;
+  fn = nullptr;
   if (hipModuleLoadData(&mod, image.data()) != hipSuccess ||
       hipModuleGetFunction(&fn, mod, name.c_str()) != hipSuccess) {
     (void)hipGetLastError();
     if (mod) (void)hipModuleUnload(mod);
+    mod = nullptr;
     err = "hipModuleLoadData failed for the compiled program";
     return false;
   }
+  return true;
+}
+
+void jit_cache_drop(const StaticSchedule &sc) {
+  if (!sc.ok) return;
+  drop_cached(jit_source(sc), kKernelExpr, kCompileOptions, kNumCompileOptions);
+}
+
+bool jit_compile(const StaticSchedule &sc, std::string &code, std::string &err, bool *from_cache) {
+  if (from_cache) *from_cache = false;
+  if (!sc.ok) {
+    err = "the plan has no static schedule";
+    return false;
+  }
+  return compile_source(jit_source(sc), kKernelExpr, kCompileOptions, kNumCompileOptions, code, err,
+                        from_cache);
+}
+
+// ---------------------------------------------------------------- fused walk, ops as constants
+// The fused walk of ONE pipeline (walk_fused.h): the kernel instantiation its plan and series
+// length select, over a JitOps struct that holds the sieves' kind / differencing order / shape /
+// cuts as immediates.  Same flags as the ahead-of-time fused units (fruits_amd/build.py).
+static const char *kFusedOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                                      "-mllvm", "-structurizecfg-skip-uniform-regions"};
+constexpr int kNumFusedOptions = 6;
+
+static std::string fused_kernel_expr(const FusedKey &k) {
+  std::ostringstream o;
+  o << "fr::iss_fused_kernel<fr::WalkCfg<" << k.E << ", 1, " << k.LV << ", " << k.MULTI << ", true, "
+    << (k.W ? "true" : "false") << ", 4, 1, " << k.SEMI << ", false, " << (k.TI ? "true" : "false")
+    << ">, " << (k.TOTAL ? "true" : "false") << ", fr::JitOps>";
+  return o.str();
+}
+
+std::string jit_fused_source(const FusedOps &ops) {
+  std::ostringstream o;
+  o << kJitDeviceSource << "\nnamespace fr {\nstruct JitOps {\n  static constexpr bool is_static = true;\n";
+  const size_t n = ops.w0.size();
+  o << "  static constexpr int n = " << n << ";\n";
+  auto list = [&](const char *name, const std::vector<int32_t> &v) {
+    o << "  static constexpr int32_t " << name << "[" << (n ? n : 1) << "] = {";
+    for (size_t i = 0; i < n; ++i) o << (i ? ", " : "") << v[i];
+    if (n == 0) o << 0;
+    o << "};\n";
+  };
+  list("w0", ops.w0);
+  list("lo", ops.lo);
+  list("hi", ops.hi);
+  o << "};\n}  // namespace fr\n";
+  return o.str();
+}
+
+bool jit_fused(const FusedOps &ops, const FusedKey &key, JitProgram &out, std::string &err) {
+  if (ops.w0.empty() || ops.w0.size() > 64) {
+    err = "no ops (or more than 64) per output row";
+    return false;
+  }
+  const std::string src = jit_fused_source(ops), expr = fused_kernel_expr(key);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    std::string code;
+    bool from_cache = false;
+    if (!compile_source(src, expr.c_str(), kFusedOptions, kNumFusedOptions, code, err, &from_cache))
+      return false;
+    hipModule_t mod;
+    hipFunction_t fn;
+    if (load_payload(code, mod, fn, err)) {
+      out = JitProgram{};
+      out.module = mod;
+      out.fn = fn;
+      out.device = current_device();
+      return true;
+    }
+    if (!from_cache) return false;
+    // a cached object the loader refuses (another ROCm, a damaged file): compile afresh, once
+    drop_cached(src, expr.c_str(), kFusedOptions, kNumFusedOptions);
+  }
+  return false;
+}
+
+hipError_t jit_launch_fused(const JitProgram &p, const IssArgs &a, size_t lds_bytes, hipStream_t st) {
+  const int64_t units = a.N * a.G;
+  if (units <= 0) return hipSuccess;
+  if (units > 0x7fffffffLL || lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+  IssArgs args = a;
+  void *params[] = {&args};
+  return hipModuleLaunchKernel(p.fn, (unsigned)units, 1, 1, kWalkThreads, 1, 1, (unsigned)lds_bytes, st,
+                               params, nullptr);
+}
+
+bool jit_load(const std::string &code, const StaticSchedule &sc, JitProgram &out, std::string &err) {
+  hipModule_t mod;
+  hipFunction_t fn;
+  if (!load_payload(code, mod, fn, err)) return false;
   out.module = mod;
   out.fn = fn;
   out.groups = sc.groups;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <vector>
 
 #include "plan.h"
 #include "walk_types.h"
@@ -31,6 +32,21 @@ void jit_cache_drop(const StaticSchedule &sc);
 // Loads a compiled program on the current device.
 bool jit_load(const std::string &code, const StaticSchedule &sc, JitProgram &out, std::string &err);
 void jit_unload(JitProgram &p);
+
+// The fused walk of one pipeline with its sieves as compile-time constants (walk_fused.h, JitOps).
+struct FusedOps {        // per op of an output row, the same for every row
+  std::vector<int32_t> w0, lo, hi;   // FeatOp::kind_inc (kind, differencing order, shape), cuts
+};
+struct FusedKey {        // the WalkCfg instantiation a (plan, series length, sieves) selects
+  int E, LV, MULTI, W, SEMI, TI, TOTAL;
+  uint32_t packed() const {
+    return (uint32_t)(E | LV << 4 | MULTI << 8 | W << 9 | SEMI << 10 | TI << 12 | TOTAL << 13);
+  }
+};
+std::string jit_fused_source(const FusedOps &ops);
+// Compiles (or takes from the disk cache) and loads on the current device; needs hipRTC.
+bool jit_fused(const FusedOps &ops, const FusedKey &key, JitProgram &out, std::string &err);
+hipError_t jit_launch_fused(const JitProgram &p, const IssArgs &a, size_t lds_bytes, hipStream_t st);
 hipError_t jit_launch(const JitProgram &p, const IssArgs &a, hipStream_t st);
 
 }  // namespace fr

@@ -64,7 +64,7 @@ __device__ __forceinline__ void lds_add2_lane63(int off0, double v0, int off1, d
                :: "v"(off0), "v"(v0), "v"(off1), "v"(v1) : "memory", "scc");
 }
 __device__ __forceinline__ int lds_offset(const void __attribute__((address_space(3))) *p) {
-  return (int)(unsigned)(uintptr_t)p;
+  return (int)(unsigned)(__UINTPTR_TYPE__)p;
 }
 
 // The kernel arguments as seen from code that rarely runs (flushes, reciprocal factors, further
@@ -384,19 +384,48 @@ __device__ __forceinline__ Op1 load_op1(const Hot &a, uint32_t op_off) {
   return o;
 }
 
+// What a kernel knows of the sieves at compile time.  DynOps: nothing - every op is decoded from
+// its 32-byte record (kind, differencing order, shape, cuts).  A run-time compiled kernel (jit.cpp,
+// fr_pipeline_prepare) is instantiated over a struct like
+//   struct JitOps { static constexpr bool is_static = true; static constexpr int n = 2;
+//                   static constexpr int32_t w0[n] = {...}, lo[n] = {...}, hi[n] = {...}; };
+// - the ops of EVERY output row of a pipeline are the same sieves, only the thresholds and the
+// column differ - so kind_inc / lo / hi are immediates: the op loop is unrolled and the decode of
+// fop folds away (an END at a fixed index of a one-chunk series becomes one predicated LDS store).
+struct DynOps {
+  static constexpr bool is_static = false;
+  static constexpr int n = 0;
+};
+
+template <class C, class OPS, bool SEQ, int I>
+__device__ __forceinline__ void fops_static(WalkCtx &cx, const Hot &a, uint32_t op_off, int slot,
+                                            const double (&c)[C::EP], const double (&x)[C::EP],
+                                            const double (&s)[C::EP], FusedScratch<C::EP> &sc) {
+  if constexpr (I < OPS::n) {
+    const Op1 o = load_op1(a, op_off + 32u * (uint32_t)I);   // (column and thresholds: the row's own)
+    const int32_t w[8] = {OPS::w0[I], o.w[1], OPS::lo[I], OPS::hi[I], o.w[4], o.w[5], o.w[6], o.w[7]};
+    fop<C>(cx, w, slot + I, c, x, s, SEQ, sc);
+    fops_static<C, OPS, SEQ, I + 1>(cx, a, op_off, slot, c, x, s, sc);
+  }
+}
+
 // The feature ops of every output row of a node: ONE code site for an op; an op is loaded where
 // it is evaluated (its line was touched at the start of the node: a scalar-cache hit).
-template <class C, bool SEQ>
+template <class C, bool SEQ, class OPS>
 __device__ __forceinline__ void fops_all(WalkCtx &cx, const Hot &a, int ne, uint32_t op_off,
                                          uint32_t rec_off, const double (&c)[C::EP],
                                          const double (&x)[C::EP], const double (&s)[C::EP]) {
-  const int n = a.n_ops;
+  const int n = OPS::is_static ? OPS::n : a.n_ops;
   FusedScratch<C::EP> sc;
   int slot = cx.fslot;   // window slot of (output row j, op i): fslot + j * n + i
   for (int j = 0;;) {
-    for (int i = 0; i < n; ++i) {
-      const Op1 o = load_op1(a, op_off + 32u * (uint32_t)i);
-      fop<C>(cx, o.w, slot + i, c, x, s, SEQ, sc);
+    if constexpr (OPS::is_static) {
+      fops_static<C, OPS, SEQ, 0>(cx, a, op_off, slot, c, x, s, sc);
+    } else {
+      for (int i = 0; i < n; ++i) {
+        const Op1 o = load_op1(a, op_off + 32u * (uint32_t)i);
+        fop<C>(cx, o.w, slot + i, c, x, s, SEQ, sc);
+      }
     }
     if (++j >= ne) break;
     slot += n;
@@ -461,7 +490,7 @@ __device__ __forceinline__ void frame_put(unsigned lv_bit, double (&f)[C::MAXLV]
 // Walks the records of one group (DFS order, sentinel at the end): per node the letters into
 // the prefix it continues (the frame of the level below; its own level's for an only child,
 // F_CHAIN), the scan, the feature ops, the hand-over to the children.
-template <class C, bool TOTAL>
+template <class C, bool TOTAL, class OPS>
 __device__ __forceinline__ void fwalk(WalkCtx &cx, int node_begin, int &sink) {
   constexpr int EP = C::EP;
   Hot a;
@@ -491,7 +520,7 @@ __device__ __forceinline__ void fwalk(WalkCtx &cx, int node_begin, int &sink) {
     // (a node without output rows names row 0: a harmless touch)
     const int t_rec = touch(a.recs, rec_off);
     const int t_ops = touch(a.ops, op_off);
-    feat_reserve<C>(cx, ne * a.n_ops);
+    feat_reserve<C>(cx, ne * (OPS::is_static ? OPS::n : a.n_ops));
     cx.slot = slot;
     const int nf = nd.fac_count(), flags = nd.flags(), lv = nd.level();
     const unsigned lv_bit = 1u << lv;
@@ -527,12 +556,12 @@ __device__ __forceinline__ void fwalk(WalkCtx &cx, int node_begin, int &sink) {
           if constexpr (C::TOTALINC) {
             double xs[EP];
             previous_weighted<C>(cx, emit_mul, x, xs);
-            fops_all<C, false>(cx, a, ne, op_off, me, c, xs, s);
+            fops_all<C, false, OPS>(cx, a, ne, op_off, me, c, xs, s);
           } else {
-            fops_all<C, false>(cx, a, ne, op_off, me, c, x, s);
+            fops_all<C, false, OPS>(cx, a, ne, op_off, me, c, x, s);
           }
         } else {
-          fops_all<C, true>(cx, a, ne, op_off, me, c, x, s);
+          fops_all<C, true, OPS>(cx, a, ne, op_off, me, c, x, s);
         }
       }
     }
@@ -633,7 +662,7 @@ __device__ __forceinline__ void stage_chunk(const WalkCtx &cx, const IssArgs &a,
 // [carry_slots] (MULTI) | feature window (values, populations, columns)
 // (No waves-per-SIMD attribute: every instance fits 128 VGPRs - four waves - without one, and
 // with it the 8-level one-chunk instances spilled a few registers for nothing.)
-template <class C, bool TOTAL>
+template <class C, bool TOTAL, class OPS = DynOps>
 __global__ __launch_bounds__(kWalkThreads) void iss_fused_kernel(const IssArgs a) {
   static_assert(C::MODE == 1 && C::TEAM == 4 && C::P == 1 && C::MULTI != 2, "fused configuration");
   extern __shared__ double lds[];
@@ -692,7 +721,7 @@ __global__ __launch_bounds__(kWalkThreads) void iss_fused_kernel(const IssArgs a
     stage_chunk<C>(cx, a, n, t0, lds);
     __syncthreads();
     cx.fused_used = 0;  // same slots in every chunk
-    fwalk<C, TOTAL>(cx, node_begin, sink);
+    fwalk<C, TOTAL, OPS>(cx, node_begin, sink);
     // a unit whose features fit the window keeps them there over its time chunks; else every
     // chunk leaves its share (added onto the earlier chunks' in global memory)
     if (!a.feat_fits || chunk + 1 == a.nchunks) feat_flush<C>(cx, !a.feat_fits && chunk > 0);

@@ -484,6 +484,19 @@ class FruitSlice:
         self._fused_cache[key] = entry
         return entry
 
+    @staticmethod
+    def _auto_prepare(pipe, N: int, T: int) -> None:
+        """A fused launch over a large batch prepares its pipeline once per batch size: the
+        pipeline's own kernel is compiled at run time (hipRTC, ~2 s, cached on disk) with the
+        sieves as immediates - worth it from ~64 MiB of iterated sums on, like ISS.transform's
+        static programs (FRUITS_AMD_AUTO_PREPARE=0: never)."""
+        if os.environ.get("FRUITS_AMD_AUTO_PREPARE", "1") == "0":
+            return
+        if getattr(pipe, "_prepared_for", None) == N or 8 * N * pipe.plan.rows * T < (64 << 20):
+            return
+        pipe.prepare(N)
+        pipe._prepared_for = N
+
     def _arm_series_cuts(self, pipe, N: int, T: int, cache) -> None:
         """Uploads the per-series boundaries of the float-cut sieves of a fused pipeline
         (SegmentSieve._get_transformed_cuts on this batch's cache) for a run on N series."""
@@ -603,6 +616,7 @@ class FruitSlice:
                 if fused.raw_dims > 0:
                     self._attach(cache)
                     self._arm_series_cuts(fused, int(Xd.shape[0]), T, cache)
+                    self._auto_prepare(fused, int(Xd.shape[0]), T)
                     return fused.run(Xd, self._iss[0].lookup_device(Xd))
         Pd = self._prepare_device(Xd, cache, callbacks)
         for cb in callbacks:
@@ -616,6 +630,7 @@ class FruitSlice:
                 fused.set_preparation(int(Pd.shape[1]))
                 fused._prep_chain = None
             self._arm_series_cuts(fused, int(Pd.shape[0]), int(Pd.shape[2]), cache)
+            self._auto_prepare(fused, int(Pd.shape[0]), int(Pd.shape[2]))
             return fused.run(Pd, self._iss[0].lookup_device(Pd))
         feats = t.zeros((X.shape[0], self.nfeatures()), dtype=t.float64, device=Pd.device)
         col = 0

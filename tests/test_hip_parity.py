@@ -1386,6 +1386,49 @@ def test_chained_iss_fuses_its_last_stage(fr, monkeypatch, T, semiring):
     compare_features(got, plain, labels, what=f"chained ISS {semiring} T={T} vs unfused")
 
 
+@pytest.mark.parametrize("which", ["counts", "bands_means", "arctic_total", "multi_chunk", "cuts"])
+def test_fused_kernel_compiled_for_its_pipeline(fr, which):
+    """fr_pipeline_prepare compiles the pipeline's own kernel (hipRTC): the fused walk with the
+    sieves' kind / differencing order / shape / cuts as immediates.  Same features as the generic
+    kernel that decodes every op from its record - bit for bit (band means: their wave sums are
+    added in LDS in arrival order)."""
+    T = {"multi_chunk": 1500}.get(which, 700)
+    rng = np.random.default_rng(len(which))
+    X = rng.standard_normal((40, 2, T)).cumsum(axis=2) / 5.0
+    fruit = fr.Fruit(which)
+    fruit.add(fr.preparation.INC)
+    if which == "arctic_total":
+        fruit.add(fr.ISS(fr.words.of_weight(3, dim=2), mode=fr.ISSMode.EXTENDED, semiring=fr.iss.semiring.Arctic(),
+                         weighting=fr.iss.weighting.Indices(total=True)))
+    else:
+        fruit.add(fr.ISS(fr.words.of_weight(3, dim=2), mode=fr.ISSMode.EXTENDED,
+                         weighting=fr.iss.weighting.Indices()))
+    if which == "counts":
+        fruit.add(fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.NPI, fr.sieving.END)
+    elif which == "cuts":
+        fruit.add(fr.sieving.NPI(cut=[T // 3, -1], q=(0.25, 0.5, 1.0)), fr.sieving.END(cut=[T // 2, -1]))
+    else:
+        fruit.add(fr.sieving.NPI(q=(0.3, 0.7, 1.0), inc=0), fr.sieving.MPI(q=(0.3, 0.7, 1.0), inc=0),
+                  fr.sieving.NPI(inc=2), fr.sieving.MPI(inc=1), fr.sieving.END)
+    fruit.get_slice().fit_sample_size = 1.0
+    np.random.seed(4)
+    fruit.fit(X)
+    slc = fruit.get_slice()
+    generic = fruit.transform(X)
+    pipe = slc._fused(T)
+    assert pipe.jit_loaded() == 0
+    pipe.prepare(X.shape[0])
+    if pipe.jit_loaded() == 0:
+        pytest.skip("hipRTC is not installed")
+    own = fruit.transform(X)
+    labels = [fruit.label(i) for i in range(fruit.nfeatures())]
+    exact = np.array(["MPI" not in lb for lb in labels])
+    np.testing.assert_array_equal(own[:, exact], generic[:, exact])
+    np.testing.assert_allclose(own, generic, rtol=1e-12, atol=1e-300)
+    fruit.fit(X)                                   # new thresholds: the compiled kernel is dropped
+    assert slc._fused(T).jit_loaded() == 0
+
+
 def test_fused_pipeline_is_cached_per_length(fr):
     """FruitSlice._fused keeps ONE pipeline per series length until the next fit - also for a
     slice with float (coquantile) cuts, whose cut columns must not replace the cache key."""
