@@ -125,7 +125,11 @@ int ensure_device_program(fr::Plan &p, fr::GroupedProgram &gp, hipStream_t st, c
   const size_t o_emit = off;        off = align_up(off + p.emit_rows.size() * 4, 64);
   const size_t o_rows = off;        off = align_up(off + p.row_src.size() * 4, 64);
   const size_t o_alpha = off;       off = align_up(off + p.alphas.size() * 4, 64);
+  const size_t o_srows = off;       off = align_up(off + gp.slot_rows.size() * 4, 64);
+  const size_t o_grb = off;         off = align_up(off + gp.group_row_begin.size() * 4, 64);
   std::vector<char> host(off + 64, 0);
+  std::memcpy(host.data() + o_srows, gp.slot_rows.data(), gp.slot_rows.size() * 4);
+  std::memcpy(host.data() + o_grb, gp.group_row_begin.data(), gp.group_row_begin.size() * 4);
   std::memcpy(host.data() + o_nodes, gp.recs.data(), n_recs * sizeof(fr::NodeRec));
   std::memcpy(host.data() + o_gb, gp.group_begin.data(), gp.group_begin.size() * 4);
   std::memcpy(host.data() + o_fac, p.factors.data(), p.factors.size() * 4);
@@ -147,6 +151,8 @@ int ensure_device_program(fr::Plan &p, fr::GroupedProgram &gp, hipStream_t st, c
   gp.d_emit_rows = reinterpret_cast<const int32_t *>(b + o_emit);
   gp.d_row_src = reinterpret_cast<const int32_t *>(b + o_rows);
   gp.d_alphas = reinterpret_cast<const float *>(b + o_alpha);
+  gp.d_slot_rows = reinterpret_cast<const int32_t *>(b + o_srows);
+  gp.d_group_row_begin = reinterpret_cast<const int32_t *>(b + o_grb);
   return FR_OK;
 }
 
@@ -259,10 +265,10 @@ int feat_window_for(const fr::GroupedProgram &gp, size_t other_lds_bytes, int n_
   const size_t budget = 38 * 1024;
   int W = 64;
   while (W < 1024 && W < largest_group &&
-         other_lds_bytes + fr::feat_window_bytes(2 * W, mpi) <= budget)
+         other_lds_bytes + fr::feat_window_bytes(2 * W, mpi, false) <= budget)
     W *= 2;
   if (W < widest) W = (widest + 1) / 2 * 2;
-  if (other_lds_bytes + fr::feat_window_bytes(W, mpi) > 160 * 1024) return 0;
+  if (other_lds_bytes + fr::feat_window_bytes(W, mpi, false) > 160 * 1024) return 0;
   fits = largest_group <= W;
   return W;
 }
@@ -941,6 +947,8 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   a.recs = gp.d_recs;
   a.factors = gp.d_factors;
   a.emit_rows = gp.d_emit_rows;
+  a.slot_rows = gp.d_slot_rows;
+  a.group_row_begin = gp.d_group_row_begin;
   a.group_begin = gp.d_group_begin;
   a.row_src = gp.d_row_src;
   a.G = gp.groups;
@@ -1054,7 +1062,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
       const int64_t chunk = fr::walk_chunk_elems(T);
       a.nchunks = (int32_t)((T + chunk - 1) / chunk);
       const size_t lds = ((size_t)a.R * chunk + 16 + 8 + (a.nchunks > 1 ? a.carry_slots : 0)) * 8 +
-                         fr::feat_window_bytes(a.feat_window, a.has_mpi != 0);
+                         fr::feat_window_bytes(a.feat_window, a.has_mpi != 0, false);
       hipError_t je = fr::jit_launch_fused(it->second, a, lds, st);
       if (je != hipSuccess) return hip_fail(je, "fused walk (run-time compiled) launch");
       return FR_OK;

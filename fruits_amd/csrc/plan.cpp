@@ -330,6 +330,7 @@ GroupedProgram &grouped(Plan &p, int G) {
   gp.group_begin.push_back(0);
   for (int g = 0; g < G; ++g) {
     std::sort(members[g].begin(), members[g].end());
+    gp.group_row_begin.push_back((int32_t)gp.slot_rows.size());
     for (int u : members[g])
       for (int i = p.unit_begin[u]; i < p.unit_begin[u + 1]; ++i) {
         const NodeDesc &nd = p.nodes[i];
@@ -357,6 +358,7 @@ GroupedProgram &grouped(Plan &p, int G) {
         r.w[12] = nd.fac_begin;
         r.w[13] = nd.emit_begin;
         gp.recs.push_back(r);
+        for (int j = 0; j < nd.emit_count; ++j) gp.slot_rows.push_back(p.emit_rows[nd.emit_begin + j]);
       }
     NodeRec end{};
     end.w[0] = kRecSentinelLevel;

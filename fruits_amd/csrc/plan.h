@@ -33,10 +33,14 @@ struct GroupedProgram {       // node order for one choice of G (groups per seri
   int groups = 0;
   std::vector<NodeRec> recs;          // per group: its units' nodes, then a sentinel
   std::vector<int32_t> group_begin;   // G+1 offsets into recs
+  // output rows in the order a group's walk emits them (the fused walk's feature window
+  // maps slot -> column through it when it leaves: walk_device.h, feat_flush) + G offsets
+  std::vector<int32_t> slot_rows, group_row_begin;
   // device copies
   void *d_blob = nullptr;
   const NodeRec *d_recs = nullptr;
   const int32_t *d_group_begin = nullptr;
+  const int32_t *d_slot_rows = nullptr, *d_group_row_begin = nullptr;
   const int32_t *d_factors = nullptr;
   const int32_t *d_emit_rows = nullptr;
   const int32_t *d_row_src = nullptr;

@@ -55,7 +55,7 @@ template <int E, int LV, int MULTI, bool W, int SEMI, bool TI, bool TOTAL>
 static hipError_t launch_fused_mode(const IssArgs &a, hipStream_t st) {
   using C = WalkCfg<E, 1, LV, MULTI, true, W, 4, 1, SEMI, false, TI>;
   const size_t lds = ((size_t)a.R * C::CHUNK + 16 + 8 + (MULTI == 1 ? a.carry_slots : 0)) * sizeof(double) +
-                     feat_window_bytes(a.feat_window, a.has_mpi != 0);
+                     feat_window_bytes(a.feat_window, a.has_mpi != 0, false);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static LaunchCache cache;  // per instantiation; per-device entries, thread-safe
   int per_cu = 1;

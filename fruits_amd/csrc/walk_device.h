@@ -99,6 +99,7 @@ struct WalkCtx {
   lds_i32 *fl_col;
   int fslot;            // first window slot of the node being processed
   int fused_used;       // slots of the window in use
+  int frow0;            // fused walk: position in IssArgs::slot_rows of the window's first output row
   int feat_window;      // slots of the window (a huge number when every group's features fit)
   const int32_t *cut_row;  // MODE 1: this series' row of IssArgs::series_cuts (or nullptr)
   int64_t series;          // MODE 1: index of the series being walked
@@ -637,7 +638,9 @@ __device__ __forceinline__ void fused_op(WalkCtx &cx, const int32_t *w, int slot
 // series' feature row with plain stores (`add`: onto what earlier time chunks of the unit left
 // there - the unit owns its columns, so a plain read-modify-write by the thread that wrote them),
 // and clears the window.  The next adds come behind the next node's scan barrier.
-template <class C>
+// TABLE (the fused walk): no columns in the window - a slot is (output row r of the unit's walk,
+// op i), its column the one the row's i-th op names (slot_rows, GroupedProgram).
+template <class C, bool TABLE = false>
 __device__ __forceinline__ void feat_flush(WalkCtx &cx, bool add) {
   lds_barrier();   // the adds of every wave are in
   // (the kernel arguments through a pointer the optimiser cannot look through: loaded here,
@@ -647,8 +650,16 @@ __device__ __forceinline__ void feat_flush(WalkCtx &cx, bool add) {
   const bool mpi = ap->has_mpi != 0;
   double *feat_row = ap->feats + cx.series * ap->feat_stride;
   double *cnt_row = ap->cnt + cx.series * ap->feat_stride;
+  const int n_ops = ap->n_ops;
   for (int sl = cx.tid; sl < cx.fused_used; sl += kWalkThreads) {
-    const int col = cx.fl_col[sl];
+    int col;
+    if constexpr (TABLE) {
+      const int r = sl / n_ops, i = sl - r * n_ops;
+      const int64_t k = as_const(ap->slot_rows)[cx.frow0 + r];
+      col = as_const(ap->ops)[k * ap->n_ops_padded + i].col;
+    } else {
+      col = cx.fl_col[sl];
+    }
     double v = cx.fl_val[sl];
     if (add) v = feat_row[col] + v;
     feat_row[col] = v;
@@ -660,13 +671,14 @@ __device__ __forceinline__ void feat_flush(WalkCtx &cx, bool add) {
       cx.fl_cnt[sl] = 0.0;
     }
   }
+  if constexpr (TABLE) cx.frow0 += cx.fused_used / n_ops;
   cx.fused_used = 0;
 }
 
 // Window slots of the next node (`need` = output rows x feature ops); a full window leaves first.
-template <class C>
+template <class C, bool TABLE = false>
 __device__ __forceinline__ void feat_reserve(WalkCtx &cx, int need) {
-  if (cx.fused_used + need > cx.feat_window) feat_flush<C>(cx, !cx.first_chunk);
+  if (cx.fused_used + need > cx.feat_window) feat_flush<C, TABLE>(cx, !cx.first_chunk);
   cx.fslot = cx.fused_used;
   cx.fused_used += need;
 }

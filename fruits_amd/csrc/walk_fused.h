@@ -239,8 +239,6 @@ __device__ __forceinline__ void fop(WalkCtx &cx, const int32_t *w, int slot, con
                                     const double (&x)[C::EP], const double (&s)[C::EP],
                                     bool seq_steps, FusedScratch<C::EP> &sc) {
   constexpr int E = C::E;
-  // (the flush needs the column of every slot, also of one no lane adds to)
-  if (cx.wave == 0) lds_store_lane0_i32(lds_offset(cx.fl_col + slot), w[1]);
   // The shapes the host flags (OPF_SHAPE_*: END at a fixed index; a counting band over the whole
   // series, of the values or of their first differences, with or without an upper threshold)
   // are short straight-line paths; everything else takes the general one below.
@@ -269,7 +267,7 @@ __device__ __forceinline__ void fop(WalkCtx &cx, const int32_t *w, int slot, con
     if (shape >= OPF_SHAPE_BAND2) {
       const double qhi = bits_to_double(w[6], w[7]);
 #pragma unroll
-      for (int e = 0; e < E; ++e) cnt += __popcll(__ballot(qlo < d[e] && d[e] <= qhi));
+      for (int e = 0; e < E; ++e) cnt += __popcll(__ballot(qlo < d[e]) & __ballot(d[e] <= qhi));
     } else {
 #pragma unroll
       for (int e = 0; e < E; ++e) cnt += __popcll(__ballot(qlo < d[e]));
@@ -352,9 +350,15 @@ __device__ __forceinline__ void fop(WalkCtx &cx, const int32_t *w, int slot, con
   for (int e = 0; e < E; ++e) {
     const int t = t_first + e;
     const double v = d[e];
-    const bool in = t >= lo && t < hi && qlo < v && v <= qhi;
-    cnt += __popcll(__ballot(in));
-    if (mpi) sum += in ? v : 0.0;
+    const bool in_t = t >= lo && t < hi;
+    if (mpi) {
+      const bool in = in_t && qlo < v && v <= qhi;
+      cnt += __popcll(__ballot(in));
+      sum += in ? v : 0.0;
+    } else {
+      // (the AND of the compare masks: as one predicate it goes through a vector register)
+      cnt += __popcll(__ballot(in_t) & __ballot(qlo < v) & __ballot(v <= qhi));
+    }
   }
   // one LDS add per wave (ds_add_f64, nothing returned)
   if (mpi) {
@@ -520,7 +524,7 @@ __device__ __forceinline__ void fwalk(WalkCtx &cx, int node_begin, int &sink) {
     // (a node without output rows names row 0: a harmless touch)
     const int t_rec = touch(a.recs, rec_off);
     const int t_ops = touch(a.ops, op_off);
-    feat_reserve<C>(cx, ne * (OPS::is_static ? OPS::n : a.n_ops));
+    feat_reserve<C, true>(cx, ne * (OPS::is_static ? OPS::n : a.n_ops));
     cx.slot = slot;
     const int nf = nd.fac_count(), flags = nd.flags(), lv = nd.level();
     const unsigned lv_bit = 1u << lv;
@@ -683,7 +687,7 @@ __global__ __launch_bounds__(kWalkThreads) void iss_fused_kernel(const IssArgs a
     double *fw = cx.carry + (C::MULTI == 1 ? a.carry_slots : 0);
     cx.fl_val = (lds_f64 *)fw;
     cx.fl_cnt = (lds_f64 *)(fw + a.feat_window);
-    cx.fl_col = (lds_i32 *)(fw + (a.has_mpi ? 2 : 1) * a.feat_window);
+    cx.fl_col = nullptr;   // (columns follow from the walk order: feat_flush<C, true>)
     for (int sl = tid; sl < a.feat_window; sl += kWalkThreads) {
       cx.fl_val[sl] = 0.0;
       if (a.has_mpi) cx.fl_cnt[sl] = 0.0;
@@ -721,10 +725,11 @@ __global__ __launch_bounds__(kWalkThreads) void iss_fused_kernel(const IssArgs a
     stage_chunk<C>(cx, a, n, t0, lds);
     __syncthreads();
     cx.fused_used = 0;  // same slots in every chunk
+    cx.frow0 = as_const(a.group_row_begin)[g0];
     fwalk<C, TOTAL, OPS>(cx, node_begin, sink);
     // a unit whose features fit the window keeps them there over its time chunks; else every
     // chunk leaves its share (added onto the earlier chunks' in global memory)
-    if (!a.feat_fits || chunk + 1 == a.nchunks) feat_flush<C>(cx, !a.feat_fits && chunk > 0);
+    if (!a.feat_fits || chunk + 1 == a.nchunks) feat_flush<C, true>(cx, !a.feat_fits && chunk > 0);
   }
   if (sink == 0x7fffffff) a.feats[0] = 0.0;   // (keeps the cache-touching loads alive)
 }

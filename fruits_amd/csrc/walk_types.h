@@ -66,9 +66,9 @@ constexpr int kStaticMaxNodes = 32;
 constexpr int kWalkThreads = 256;
 
 // LDS bytes of a feature window of `slots` slots (8-byte value, 8-byte population with MPI
-// sieves, 4-byte column; slots even)
-constexpr uint64_t feat_window_bytes(int slots, bool mpi) {
-  return (uint64_t)slots * (mpi ? 20u : 12u);
+// sieves, 4-byte column - not in the fused walk, whose columns follow from the walk order; slots even)
+constexpr uint64_t feat_window_bytes(int slots, bool mpi, bool cols = true) {
+  return (uint64_t)slots * ((mpi ? 16u : 8u) + (cols ? 4u : 0u));
 }
 
 constexpr int FR_SIEVE_NPI_K = 0;
@@ -94,6 +94,8 @@ struct IssArgs {
   const NodeRec *recs;       // 64-byte aligned
   const int32_t *factors;
   const int32_t *emit_rows;
+  const int32_t *slot_rows;        // fused walk: output rows in the order a group emits them,
+  const int32_t *group_row_begin;  // and where a group's rows start in it (GroupedProgram)
   const int32_t *group_begin;
   const int32_t *row_src;
   int64_t N, D, T;
