@@ -32,7 +32,7 @@ def units():
     # programs below; and its uniform branches stay branches - structurised like divergent ones,
     # every case of its level dispatch costs six scalar instructions and a speculative copy
     fused = ["-ffp-contract=off", "-mllvm", "-structurizecfg-skip-uniform-regions"]
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         for lv in (2, 4, 6, 8):
             out.append((f"walk_m{mode}_l{lv}", "walk_inst.hip",
                         [f"-DWALK_MODE={mode}", f"-DWALK_LV={lv}"] + (fused if mode else fused[1:])))

@@ -330,6 +330,10 @@ int choose_groups_walk(const fr::Plan &p, int64_t N, int64_t resident, bool fuse
   // word shards of config 4 over 8 ranks (~170 nodes each): 1.86 ms with whole series, 2.40 ms
   // with two groups (tools/bench_shards.py)
   if (fused) return p.nodes.size() >= 400 ? std::min(U, 2) : 1;   // (config 5, 511 nodes: 24.9 vs 25.3 ms)
+  // materialising launches of long plans run one short-lived workgroup per unit too (the lean
+  // walk, run_walk): two groups per series shorten the last round (of_weight(4,2), N = 2048:
+  // 390 -> 372 us; the same at N = 8192) for one more staging of the series' rows
+  if (!p.letter_sum && p.nodes.size() >= 64 && debug_knob("lean", 1) != 0) return std::min(U, 2);
   if (N < 2 * resident || p.nodes.size() > 32) return 1;
   return std::min(U, 3);
 }
@@ -1042,6 +1046,26 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   }
   a.static_prog = static_prog > 0 ? static_prog : 0;
   a.lds_pad = static_lds_pad;
+  // Materialising launches of the interpreter's plans run through the fused walk's node loop with
+  // a store epilogue (walk_fused.h, MODE 2: half the instructions per node) whenever that walk
+  // covers the plan: chunk carries in LDS, no letter sums (Arctic argmax).
+  const int64_t resident_round = resident > 0 ? resident : 1536;
+  if (!fu && !packed && !static_prog && !p.letter_sum && debug_knob("lean", 1) != 0 &&
+      (p.nodes.size() > 32 || N * (int64_t)gp.groups >= 2 * resident_round)) {
+    // (short plans on batches of less than two resident rounds keep the interpreter's persistent
+    // grid and its prefetch of the next unit's rows: of_weight(2,3) at N = 2048 66 vs 75 us)
+    int most = 0;
+    for (int g = 0; g < gp.groups; ++g) most = std::max(most, gp.group_begin[g + 1] - gp.group_begin[g]);
+    const int64_t chunk = fr::walk_chunk_elems(T);
+    const size_t lds = ((size_t)a.R * chunk + 24 + (T > chunk ? 3 * (size_t)most : 0)) * 8;
+    if (lds <= 40 * 1024 || T <= chunk) {
+      a.lean = 1;
+      a.carry_slots = 3 * most;
+      a.carry_in_lds = 1;
+      a.persistent = 0;
+      a.total_weighting = p.weighting == FR_W_TOTAL ? 1 : 0;
+    }
+  }
   // The interpreter's share of the same finding, in the window where it was measured to pay:
   // one group per series and a batch just above the Infinity Cache (1 to 1.5 times its
   // 256 MiB - config 2: 70 -> 65 us; 264 MB: 43 -> 45 us, 440 MB: 88 -> 93 us, so not there).

@@ -807,6 +807,7 @@ int walk_chunk_elems(int64_t T) { return T <= 512 ? 512 : 1024; }
 #define DECL_INST(m, l) hipError_t walk_inst_m##m##_l##l(const IssArgs &, int, hipStream_t);
 DECL_INST(0, 2) DECL_INST(0, 4) DECL_INST(0, 6) DECL_INST(0, 8)
 DECL_INST(1, 2) DECL_INST(1, 4) DECL_INST(1, 6) DECL_INST(1, 8)
+DECL_INST(2, 2) DECL_INST(2, 4) DECL_INST(2, 6) DECL_INST(2, 8)
 hipError_t walk_static_launch(const IssArgs &, hipStream_t);
 hipError_t walk_packed_inst_m0(const IssArgs &, int, hipStream_t);
 hipError_t walk_packed_inst_m1(const IssArgs &, int, hipStream_t);
@@ -835,6 +836,12 @@ hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st) {
     return walk_inst_m1_l8(a, chunk, st);
   }
   if (a.static_prog != 0) return walk_static_launch(a, st);
+  if (a.lean) {   // the fused walk's node loop with a store epilogue (walk_fused.h, MODE 2)
+    if (levels <= 2) return walk_inst_m2_l2(a, chunk, st);
+    if (levels <= 4) return walk_inst_m2_l4(a, chunk, st);
+    if (levels <= 6) return walk_inst_m2_l6(a, chunk, st);
+    return walk_inst_m2_l8(a, chunk, st);
+  }
   if (levels <= 2) return walk_inst_m0_l2(a, chunk, st);
   if (levels <= 4) return walk_inst_m0_l4(a, chunk, st);
   if (levels <= 6) return walk_inst_m0_l6(a, chunk, st);

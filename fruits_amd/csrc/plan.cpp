@@ -335,7 +335,9 @@ GroupedProgram &grouped(Plan &p, int G) {
       for (int i = p.unit_begin[u]; i < p.unit_begin[u + 1]; ++i) {
         const NodeDesc &nd = p.nodes[i];
         NodeRec r{};
-        bool slow = nd.fac_count > kRecInlineFactors || p.letter_sum;
+        // (a letter whose exponents cancel, [2-2], has no factor at all: the factor-table path
+        // multiplies by none, the inline one always by its first)
+        bool slow = nd.fac_count > kRecInlineFactors || nd.fac_count == 0 || p.letter_sum;
         for (int j = 0; j < nd.fac_count; ++j)
           if (p.multiplicative() && (p.factors[nd.fac_begin + j] & FAC_DIV)) slow = true;
         const bool kids = (nd.flags & F_CHILDREN) != 0;

@@ -152,6 +152,59 @@ __device__ __forceinline__ void mul_rowp(const WalkCtx &cx, int code, double (&s
   }
 }
 
+// The same scan for P pieces per wave (the materialising walk, MODE 2: lane l holds E = 2
+// consecutive elements of each of its wave's two pieces, so that every 16-byte store instruction
+// of a wave covers 1 KiB without holes): one DPP chain per piece, interleaved; the sums and their
+// order are block_scan's.
+template <class C>
+__device__ __forceinline__ void fscan_pieces(WalkCtx &cx, const double (&s)[C::EP], double (&c)[C::EP],
+                                             double (&x)[C::EP], int carry_slot) {
+  constexpr int E = C::E, P = C::P;
+  double l[C::EP], incl[P], excl[P];
+#pragma unroll
+  for (int h = 0; h < P; ++h) {
+    l[h * E] = s[h * E];
+#pragma unroll
+    for (int e = 1; e < E; ++e) l[h * E + e] = semi_add<C::SEMI>(l[h * E + e - 1], s[h * E + e]);
+    incl[h] = l[h * E + E - 1];
+  }
+  wave_inclusive_scan_multi<P, C::SEMI>(incl);
+#pragma unroll
+  for (int h = 0; h < P; ++h) excl[h] = wave_shift_right1<C::SEMI>(incl[h]);
+  // lane 63: the totals of the pieces in order = the wave's total
+  double total = incl[0];
+#pragma unroll
+  for (int h = 1; h < P; ++h) total = semi_add<C::SEMI>(total, incl[h]);
+  double carry_in = semi_zero<C::SEMI>();
+  if constexpr (C::MULTI != 0) {
+    if (!cx.first_chunk) carry_in = cx.carry[carry_slot];
+  }
+  lds_f64 *tw = (lds_f64 *)(cx.tot + cx.buf * 8);   // {Z, Z, Z, t0, t1, t2, t3, -}
+  lds_store_lane63(lds_offset(tw + 3 + cx.wave), total);
+  lds_barrier();
+  const double a0 = tw[cx.wave], a1 = tw[cx.wave + 1], a2 = tw[cx.wave + 2];
+  double base = semi_add<C::SEMI>(semi_add<C::SEMI>(a0, a1), a2);
+  cx.buf ^= 1;
+  if constexpr (C::MULTI != 0) {
+    if (cx.wave == 3)
+      lds_store_lane63(lds_offset((lds_f64 *)cx.carry + carry_slot),
+                       semi_add<C::SEMI>(carry_in, semi_add<C::SEMI>(base, total)));
+    base = semi_add<C::SEMI>(base, carry_in);
+  }
+#pragma unroll
+  for (int h = 0; h < P; ++h) {
+    const double off = semi_add<C::SEMI>(base, excl[h]);
+    x[h * E] = off;
+#pragma unroll
+    for (int e = 0; e + 1 < E; ++e) {
+      c[h * E + e] = semi_add<C::SEMI>(off, l[h * E + e]);
+      x[h * E + e + 1] = c[h * E + e];
+    }
+    c[h * E + E - 1] = semi_add<C::SEMI>(base, incl[h]);
+    if (h + 1 < P) base = semi_add<C::SEMI>(base, wave_last_lane(incl[h]));
+  }
+}
+
 // Inclusive scan of one chunk row over the workgroup (P = 1: lane l holds E consecutive
 // elements, wave w the span [w * 64 E, (w + 1) * 64 E)).  Same sums in the same order as
 // block_scan; the cross-wave step reads the totals window (see the file comment).
@@ -160,7 +213,11 @@ __device__ __forceinline__ void mul_rowp(const WalkCtx &cx, int code, double (&s
 template <class C, bool WINDOW = true>
 __device__ __forceinline__ void fscan(WalkCtx &cx, const double (&s)[C::EP], double (&c)[C::EP],
                                       double (&x)[C::EP], int carry_slot) {
-  static_assert(C::P == 1 && C::NW == 4, "fused kernels: one piece per wave, four waves");
+  static_assert(C::NW == 4, "four waves");
+  if constexpr (C::P != 1) {
+    fscan_pieces<C>(cx, s, c, x, carry_slot);
+    return;
+  }
   constexpr int E = C::E;
   double l[E];
   l[0] = s[0];
@@ -379,6 +436,11 @@ struct Hot {
   const FeatOp *ops;
   int n_ops;
   uint32_t op_row_bytes;   // bytes of one output row's ops (the host checks the table < 4 GiB)
+  // MODE 2 (the tensor is written): row 0 of this series' chunk, bytes between two output rows
+  // (0: beyond 32 bits - the general product), whole aligned chunk (no per-lane checks)
+  char *out;
+  uint32_t k_stride;
+  bool fast_store;
 };
 __device__ __forceinline__ Op1 load_op1(const Hot &a, uint32_t op_off) {
   cptr<int32_t> q = at_offset(a.ops, op_off);
@@ -436,6 +498,40 @@ __device__ __forceinline__ void fops_all(WalkCtx &cx, const Hot &a, int ne, uint
     const int k = j == 1 ? rec_field(a.recs, rec_off, 8)
                          : as_const(cold_args()->emit_rows)[rec_field(a.recs, rec_off, 13) + j];
     op_off = (uint32_t)k * a.op_row_bytes;
+  }
+}
+
+// MODE 2: the node's values into every output row it names (two inline in the record, further
+// ones - SINGLE-mode plans with repeated words - from the table).  A lane holds E consecutive
+// elements: 16-byte stores, base = the row's uniform address, offset = one 32-bit register.
+template <class C>
+__device__ __forceinline__ void emit_lean(const WalkCtx &cx, const Hot &a, int ne, int k,
+                                          uint32_t rec_off, const double (&c)[C::EP]) {
+  constexpr int E = C::E, P = C::P;
+  const uint32_t lane_bytes = (uint32_t)(cx.wave * C::SPAN + cx.lane * E) * 8u;
+  for (int j = 0;;) {
+    char *row = a.k_stride != 0
+                    ? a.out + (uint64_t)(uint32_t)k * (uint64_t)a.k_stride
+                    : a.out + (int64_t)k * cold_args()->out_k_stride * 8;
+    if (a.fast_store) {
+#pragma unroll
+      for (int h = 0; h < P; ++h)
+#pragma unroll
+        for (int e = 0; e < E; e += 2)
+          *reinterpret_cast<vd2 *>(row + lane_bytes + 8u * (h * C::PIECE + e)) = vd2{c[h * E + e], c[h * E + e + 1]};
+    } else {
+      const int64_t T = cold_args()->T;
+#pragma unroll
+      for (int h = 0; h < P; ++h)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const uint32_t at = lane_bytes + 8u * (h * C::PIECE + e);
+          if (cx.t0 + (at >> 3) < T) *reinterpret_cast<double *>(row + at) = c[h * E + e];
+        }
+    }
+    if (++j >= ne) break;
+    k = j == 1 ? rec_field(a.recs, rec_off, 8)
+               : as_const(cold_args()->emit_rows)[rec_field(a.recs, rec_off, 13) + j];
   }
 }
 
@@ -506,6 +602,11 @@ __device__ __forceinline__ void fwalk(WalkCtx &cx, int node_begin, int &sink) {
     a.ops = reinterpret_cast<const FeatOp *>(uniform_ptr(ka.ops));
     a.n_ops = __builtin_amdgcn_readfirstlane(ka.n_ops);
     a.op_row_bytes = __builtin_amdgcn_readfirstlane(ka.n_ops_padded * 32);
+    if constexpr (C::MODE == 2) {
+      a.out = static_cast<char *>(const_cast<void *>(uniform_ptr(cx.out_base)));
+      a.k_stride = __builtin_amdgcn_readfirstlane(ka.k_stride_bytes32);
+      a.fast_store = cx.full_chunk && ka.vec_ok != 0;
+    }
   }
   double f[C::MAXLV][EP];
 #pragma unroll
@@ -523,8 +624,11 @@ __device__ __forceinline__ void fwalk(WalkCtx &cx, int node_begin, int &sink) {
     // the lines of the next record and of this node's ops, on their way to the scalar cache
     // (a node without output rows names row 0: a harmless touch)
     const int t_rec = touch(a.recs, rec_off);
-    const int t_ops = touch(a.ops, op_off);
-    feat_reserve<C, true>(cx, ne * (OPS::is_static ? OPS::n : a.n_ops));
+    int t_ops = 0;
+    if constexpr (C::MODE == 1) {
+      t_ops = touch(a.ops, op_off);
+      feat_reserve<C, true>(cx, ne * (OPS::is_static ? OPS::n : a.n_ops));
+    }
     cx.slot = slot;
     const int nf = nd.fac_count(), flags = nd.flags(), lv = nd.level();
     const unsigned lv_bit = 1u << lv;
@@ -557,13 +661,17 @@ __device__ __forceinline__ void fwalk(WalkCtx &cx, int node_begin, int &sink) {
           // total weighting: the sieves see c * exp(-g alpha_k) (Arctic: c - g alpha_k)
           const int emit_mul = ((w1 >> 24) & 0xff) - 1;
           mul_rowp<C>(cx, C::SEMI != 1 ? emit_mul : fac_arctic(emit_mul, -1), c);
-          if constexpr (C::TOTALINC) {
+          if constexpr (C::MODE == 2) {
+            emit_lean<C>(cx, a, ne, nd.w[7], me, c);
+          } else if constexpr (C::TOTALINC) {
             double xs[EP];
             previous_weighted<C>(cx, emit_mul, x, xs);
             fops_all<C, false, OPS>(cx, a, ne, op_off, me, c, xs, s);
           } else {
             fops_all<C, false, OPS>(cx, a, ne, op_off, me, c, x, s);
           }
+        } else if constexpr (C::MODE == 2) {
+          emit_lean<C>(cx, a, ne, nd.w[7], me, c);
         } else {
           fops_all<C, true, OPS>(cx, a, ne, op_off, me, c, x, s);
         }
@@ -668,7 +776,8 @@ __device__ __forceinline__ void stage_chunk(const WalkCtx &cx, const IssArgs &a,
 // with it the 8-level one-chunk instances spilled a few registers for nothing.)
 template <class C, bool TOTAL, class OPS = DynOps>
 __global__ __launch_bounds__(kWalkThreads) void iss_fused_kernel(const IssArgs a) {
-  static_assert(C::MODE == 1 && C::TEAM == 4 && C::P == 1 && C::MULTI != 2, "fused configuration");
+  static_assert((C::MODE == 1 || C::MODE == 2) && C::TEAM == 4 && (C::P == 1 || C::MODE == 2) && C::MULTI != 2,
+                "fused (MODE 1) or lean materialising (MODE 2) configuration");
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
   WalkCtx cx;
@@ -683,7 +792,9 @@ __global__ __launch_bounds__(kWalkThreads) void iss_fused_kernel(const IssArgs a
   cx.team = 0;
   cx.buf = 0;
   cx.tail_buf = 0;
-  {
+  if constexpr (C::MODE == 2) {
+    if (tid < 6) cx.tot[(tid / 3) * 8 + tid % 3] = semi_zero<C::SEMI>();
+  } else {
     double *fw = cx.carry + (C::MULTI == 1 ? a.carry_slots : 0);
     cx.fl_val = (lds_f64 *)fw;
     cx.fl_cnt = (lds_f64 *)(fw + a.feat_window);
@@ -724,14 +835,19 @@ __global__ __launch_bounds__(kWalkThreads) void iss_fused_kernel(const IssArgs a
     if (chunk > 0) lds_barrier();  // all reads of the old rows are done
     stage_chunk<C>(cx, a, n, t0, lds);
     __syncthreads();
-    cx.fused_used = 0;  // same slots in every chunk
-    cx.frow0 = as_const(a.group_row_begin)[g0];
-    fwalk<C, TOTAL, OPS>(cx, node_begin, sink);
-    // a unit whose features fit the window keeps them there over its time chunks; else every
-    // chunk leaves its share (added onto the earlier chunks' in global memory)
-    if (!a.feat_fits || chunk + 1 == a.nchunks) feat_flush<C, true>(cx, !a.feat_fits && chunk > 0);
+    if constexpr (C::MODE == 2) {
+      cx.out_base = a.out + n * a.out_n_stride + t0;
+      fwalk<C, TOTAL, OPS>(cx, node_begin, sink);
+    } else {
+      cx.fused_used = 0;  // same slots in every chunk
+      cx.frow0 = as_const(a.group_row_begin)[g0];
+      fwalk<C, TOTAL, OPS>(cx, node_begin, sink);
+      // a unit whose features fit the window keeps them there over its time chunks; else every
+      // chunk leaves its share (added onto the earlier chunks' in global memory)
+      if (!a.feat_fits || chunk + 1 == a.nchunks) feat_flush<C, true>(cx, !a.feat_fits && chunk > 0);
+    }
   }
-  if (sink == 0x7fffffff) a.feats[0] = 0.0;   // (keeps the cache-touching loads alive)
+  if (sink == 0x7fffffff) (C::MODE == 2 ? a.out : a.feats)[0] = 0.0;   // (keeps the cache-touching loads alive)
 }
 
 }  // namespace fr

@@ -5,20 +5,20 @@
 
 namespace fr {
 
-#if WALK_MODE == 1
-// The fused walk (walk_fused.h): 4 consecutive elements per lane for 1024-element chunks, 2 for
-// 512-element ones; carries of a multi-chunk walk always live in LDS (the host sizes the groups
-// for that).
+#if WALK_MODE == 1 || WALK_MODE == 2
+// The fused walk (walk_fused.h; MODE 2: the same walk writing the tensor): 4 consecutive elements
+// per lane for 1024-element chunks, 2 for 512-element ones; carries of a multi-chunk walk always
+// live in LDS (the host sizes the groups for that).
 template <int E, int MULTI>
 static hipError_t inst_f(const IssArgs &a, hipStream_t st) {
   if (a.semiring == kSemiArctic)
-    return a.aux ? launch_fused_cfg<E, WALK_LV, MULTI, true, 1>(a, st)
-                 : launch_fused_cfg<E, WALK_LV, MULTI, false, 1>(a, st);
+    return a.aux ? launch_fused_cfg<E, WALK_LV, MULTI, true, 1, false, WALK_MODE>(a, st)
+                 : launch_fused_cfg<E, WALK_LV, MULTI, false, 1, false, WALK_MODE>(a, st);
   if (a.semiring == kSemiBayesian)
-    return a.aux ? launch_fused_cfg<E, WALK_LV, MULTI, true, 2>(a, st)
-                 : launch_fused_cfg<E, WALK_LV, MULTI, false, 2>(a, st);
-  return a.aux ? launch_fused_cfg<E, WALK_LV, MULTI, true, 0>(a, st)
-               : launch_fused_cfg<E, WALK_LV, MULTI, false, 0>(a, st);
+    return a.aux ? launch_fused_cfg<E, WALK_LV, MULTI, true, 2, false, WALK_MODE>(a, st)
+                 : launch_fused_cfg<E, WALK_LV, MULTI, false, 2, false, WALK_MODE>(a, st);
+  return a.aux ? launch_fused_cfg<E, WALK_LV, MULTI, true, 0, false, WALK_MODE>(a, st)
+               : launch_fused_cfg<E, WALK_LV, MULTI, false, 0, false, WALK_MODE>(a, st);
 }
 template <int P>
 static hipError_t inst_p(const IssArgs &a, hipStream_t st) {

@@ -146,6 +146,7 @@ struct IssArgs {
   int32_t total_inc;        // 1: totally weighted plan whose fused sieves difference (WalkCfg::TOTALINC)
   int32_t total_weighting;  // 1: the plan's weighting is total (the fused walk is compiled per mode)
   int32_t nt_input;         // 1: stage the rows of X with non-temporal loads (interpreter, one group)
+  int32_t lean;             // 1: materialising launch through the fused walk's node loop (walk_fused.h, MODE 2)
   int32_t static_prog;      // != 0: the records equal pre-compiled static program #n (walk_static_inst.hip)
   uint32_t k_stride_bytes32; // out_k_stride * 8 when that fits 32 bits (and is > 0), else 0
   int32_t *resident_out;    // HOST pointer; non-null: the launcher stores the number of resident

@@ -1322,6 +1322,31 @@ def test_fused_preparation(fr, monkeypatch, chain, T):
     strict_transform_parity(fruit, spec, X, X, labels, np_seed=1, what=f"fused preparation {chain} T={T}")
 
 
+@pytest.mark.parametrize("T", [385, 700, 1500])
+def test_letter_whose_exponents_cancel(fr, T):
+    """[2-2] multiplies by nothing (its node has no factor): the iterated sums against the C
+    oracle, and a fused fruit over the same words against the numpy oracle - the node loop of the
+    fused walk reads its first factor from the record, so such a node takes the factor-table path."""
+    rng = np.random.default_rng(T)
+    X = rng.random((9, 3, T)) * 0.9 + 0.3
+    words = ["[323][2-2][1]", "[2-2]", "[1][3-3][3-3][2]"]
+    iss = fr.ISS([fr.words.SimpleWord(s) for s in words], mode=fr.ISSMode.EXTENDED)
+    out = iss.fit_transform(X)
+    ref = corc.iss_transform(X, words, "EXTENDED", None, None, False, semiring="Reals")
+    rowwise_close(out, ref)
+    spec = {"slices": [{"preps": [], "iss": [{"words": words, "mode": "EXTENDED"}],
+                        "sieves": [{"kind": "NPI", "q": [0.5, 1.0]}, {"kind": "END"}],
+                        "fit_sample_size": 1.0}]}
+    fruit = build_fruit(fr, spec)
+    np.random.seed(2)
+    fruit.fit(X)
+    got = fruit.transform(X)
+    assert fruit.get_slice()._fused(T) is not None
+    labels = [fruit.label(i) for i in range(fruit.nfeatures())]
+    ref_f, expo = oracle_features(spec, X, X, np_seed=2)
+    compare_features(got, ref_f, labels, expo, what=f"cancelling letter T={T}")
+
+
 @pytest.mark.parametrize("prep", ["INC", "STD"])
 def test_custom_weighting_sees_the_prepared_input(fr, monkeypatch, prep):
     """A Custom weighting (or any user subclass) builds its lookup from what the ISS is handed -
