@@ -576,9 +576,13 @@ def pre_transform(Ad, inc: int):
     return out
 
 
-def select_ranks(block, job_row, job_inc, job_rank) -> np.ndarray:
+def select_ranks(block, job_row, job_inc, job_rank, stream=None) -> np.ndarray:
     """Order statistics of differenced (N, T) blocks of the (rows, N, T) device
-    tensor ``block`` (fr_select_ranks); exact."""
+    tensor ``block`` (fr_select_ranks); exact.  ``stream``: the HIP stream ``block`` was written
+    on, when the call comes from another thread than the one that wrote it (the current device
+    and stream are per thread)."""
+    if stream is not None:
+        torch().cuda.set_device(block.device)
     rows, N, T = block.shape
     jr = np.ascontiguousarray(job_row, dtype=np.int32)
     ji = np.ascontiguousarray(job_inc, dtype=np.int32)
@@ -590,7 +594,7 @@ def select_ranks(block, job_row, job_inc, job_rank) -> np.ndarray:
         dptr(block), C.c_int64(rows), C.c_int64(N), C.c_int64(T), C.c_int32(len(jr)),
         jr.ctypes.data_as(C.POINTER(C.c_int32)), ji.ctypes.data_as(C.POINTER(C.c_int32)),
         jk.ctypes.data_as(C.POINTER(C.c_int64)), out.ctypes.data_as(C.POINTER(C.c_double)),
-        stream_ptr())
+        stream_ptr() if stream is None else stream)
     check(rc, "fr_select_ranks")
     return out
 

@@ -1592,6 +1592,8 @@ int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32
     return fail(FR_E_ARG, "fr_select_ranks: bad argument");
   if (n_jobs == 0) return FR_OK;
   if (!d_A) return fail(FR_E_ARG, "fr_select_ranks: null device pointer");
+  if (T >= (int64_t(1) << 31))
+    return fail(FR_E_LIMIT, "fr_select_ranks: series of 2^31 elements or more (time indices are 32-bit)");
   struct HostJob {
     const double *base;
     unsigned long long prefix;
@@ -1650,6 +1652,22 @@ int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32
   }
   const int n_dev = (int)jobs.size();
   const int n_groups = (int)groups.size() / 2;
+  // The gather pass tracks the smallest key above the bucket of the first kSelTrackJobs jobs per
+  // group and differencing order that want a neighbour (pad bit 4); any further one costs a
+  // pass of its own (select_succ_kernel)
+  bool untracked = false;
+  for (int g = 0; g < n_groups; ++g) {
+    int pos = 0, last_inc = -1;   // position of a job among its group's jobs of one order
+    for (int j = groups[2 * g]; j < groups[2 * g] + groups[2 * g + 1]; ++j) {
+      pos = jobs[j].inc == last_inc ? pos + 1 : 0;
+      last_inc = jobs[j].inc;
+      if (!(jobs[j].pad & 1)) continue;
+      if (pos < fr::kSelTrackJobs) jobs[j].pad |= 16;
+      else untracked = true;
+    }
+  }
+  int max_inc = 0;
+  for (int j = 0; j < n_jobs; ++j) max_inc = std::max(max_inc, (int)job_inc[j]);
   std::vector<double> dev_out(n_dev);
   std::vector<unsigned long long> dev_succ(n_dev);
   hipStream_t st = (hipStream_t)stream;
@@ -1657,7 +1675,8 @@ int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32
   // fit calls this once per word batch and slice, and hipMalloc / hipFree synchronise
   const size_t o_jobs = 0;
   const size_t o_groups = align_up(o_jobs + jobs.size() * sizeof(HostJob), 256);
-  const size_t o_hist = align_up(o_groups + groups.size() * 4, 256);
+  const size_t o_groups2 = align_up(o_groups + groups.size() * 4, 256);   // (groups still in the passes)
+  const size_t o_hist = align_up(o_groups2 + groups.size() * 4, 256);
   const size_t o_out = align_up(o_hist + (size_t)n_dev * 256 * 4, 256);
   const size_t o_succ = align_up(o_out + (size_t)n_dev * 8, 256);
   const size_t o_cnt = align_up(o_succ + (size_t)n_dev * 8, 256);
@@ -1671,7 +1690,7 @@ int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32
     if (sc.ptr) (void)hipFree(sc.ptr);
     sc.ptr = nullptr;
     sc.bytes = 0;
-    const size_t want = std::max(need + need / 2, (size_t)1 << 20);
+    const size_t want = std::max(need + need / 2, (size_t)32 << 20);   // (one allocation per fit: the slices' needs differ)
     HIP_TRY(hipMalloc(&sc.ptr, want));
     sc.bytes = want;
   }
@@ -1684,7 +1703,8 @@ int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32
       (e = hipMemsetAsync(b + o_hist, 0, (size_t)n_dev * 256 * 4, st)) != hipSuccess ||
       (e = hipMemsetAsync(b + o_succ, 0xff, (size_t)n_dev * 8, st)) != hipSuccess ||
       (e = hipMemsetAsync(b + o_cnt, 0, ((size_t)n_dev + 1) * 4, st)) != hipSuccess ||
-      (e = fr::launch_select_ranks(b + o_jobs, n_dev, b + o_groups, n_groups, N, T,
+      (e = fr::launch_select_ranks(b + o_jobs, n_dev, b + o_groups, n_groups, groups.data(),
+                                   b + o_groups2, max_inc, untracked, N, T,
                                    reinterpret_cast<unsigned int *>(b + o_hist),
                                    reinterpret_cast<double *>(b + o_out),
                                    reinterpret_cast<unsigned long long *>(b + o_succ),

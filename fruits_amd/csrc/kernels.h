@@ -30,13 +30,15 @@ hipError_t launch_sieve(int kind, const double *A, int64_t N, int64_t T, int64_t
 // jobs sorted so that the jobs of one group (<= kSelGroupMax, same row block) are adjacent;
 // groups = int2 {first job, count}
 constexpr int kSelGroupMax = 8;
+constexpr int kSelTrackJobs = 2;     // jobs per group and differencing order whose successor the gather pass tracks
 constexpr int kSelSmallCap = 2048;   // candidates a job settles inside one workgroup (kernels_misc.hip)
 // job.pad bit 0: also return the next order statistic (succ[job] = its order key; all-ones
 // when there is none); succ must be preset to all-ones
-hipError_t launch_select_ranks(void *jobs, int n_jobs, const void *groups, int n_groups, int64_t N,
-                               int64_t T, unsigned int *hist, double *out,
-                               unsigned long long *succ, unsigned long long *cand,
-                               unsigned int *cand_count, hipStream_t st);
+hipError_t launch_select_ranks(void *jobs, int n_jobs, const void *groups, int n_groups,
+                               const int32_t *h_groups, void *groups_scratch, int max_inc,
+                               bool untracked, int64_t N, int64_t T, unsigned int *hist, double *out,
+                               unsigned long long *succ,
+                               unsigned long long *cand, unsigned int *cand_count, hipStream_t st);
 constexpr int kSelJobBytes = 32;
 hipError_t launch_pre_transform(const double *A, int64_t N, int64_t T, int64_t a_stride, int inc,
                                 double *out, hipStream_t st);

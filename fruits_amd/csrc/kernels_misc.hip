@@ -2,6 +2,7 @@
 // standalone sieves, STD) and the dispatcher over the walk-kernel instances.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <vector>
 
 #include "kernels.h"
 #include "walk_scan.h"
@@ -429,6 +430,7 @@ hipError_t launch_arctic_argmax(const double *V, int64_t rows, int64_t N, int64_
 // (sign, exponent, 12 mantissa bits); the few elements that share them (<= kSelSmall,
 // else the histogram passes simply go on) are gathered in ONE more pass over the data and
 // the remaining 40 bits are settled inside a workgroup: 4 passes over the data instead of 9.
+constexpr int kSelGroupJobs = 8;   // jobs of one group (they read the same (N, T) row block)
 struct SelJob {
   const double *base;        // (N, T) row block of one iterated sum
   unsigned long long prefix; // key bits fixed so far
@@ -446,27 +448,140 @@ __device__ __forceinline__ double key_to_double(unsigned long long k) {
   return __longlong_as_double((long long)u);
 }
 
+// The data passes of the selection (histogram, gather, successor) walk the differencing orders
+// 0 .. MI of an element in ONE unrolled loop: the triangle of differences advances a level (D_k:
+// k-th differences, zero-padded, see diff_at) and the jobs of that level - a group's jobs are
+// sorted by order - look at its value.  MI is the launch's largest order (0 / 1 / 2, or kMaxInc for
+// anything beyond).  Nothing is indexed by a run-time value: an array of the levels' keys picked
+// by a job's order ends up in LDS (the compiler's promotion of private arrays), which is what
+// the first version of these kernels spent its time on.
+template <int MI>
+__device__ __forceinline__ void element_load(const double *__restrict__ row, int t, double (&v)[MI + 1]) {
+  v[0] = row[t];
+#pragma unroll
+  for (int j = 1; j <= MI; ++j) v[j] = t - j >= 0 ? row[t - j] : 0.0;
+}
+// level LVL - 1 -> LVL: afterwards v[0] = D_LVL[t]
+template <int MI, int LVL>
+__device__ __forceinline__ void next_level(int t, double (&v)[MI + 1]) {
+#pragma unroll
+  for (int j = 0; j + LVL <= MI; ++j) v[j] = (t - j >= 1) ? v[j] - v[j + 1] : 0.0;
+}
+// The leading 32 bits of the order-preserving key: all that the first three digits and the bucket
+// tests of the gather pass look at (32-bit operations instead of 64-bit shifts and compares).
+__device__ __forceinline__ unsigned int order_key_hi(double v) {
+  const unsigned int h = (unsigned int)((unsigned long long)__double_as_longlong(v) >> 32);
+  return (h >> 31) ? ~h : (h | 0x80000000u);
+}
+
+// A group's jobs in LDS, once per workgroup and pass: the descriptors, and the jobs that take
+// part in this pass compacted by differencing order (level i: act[lvl[i]] .. act[lvl[i + 1])).
+constexpr int kSelTrack = kSelTrackJobs;   // (kernels.h: the host flags the jobs)
+struct SelGroup {
+  unsigned long long prefix[kSelGroupJobs];
+  int inc[kSelGroupJobs], pad[kSelGroupJobs];
+  int act[kSelGroupJobs];
+  unsigned int act_hi[kSelGroupJobs];   // leading dword of the job's prefix
+  int lvl[kMaxInc + 2];
+};
+// `take(j)`: does job j take part in this pass?  Returns the number of jobs that do.
+template <int MI, class F>
+__device__ __forceinline__ int load_group(SelGroup &g, const SelJob *__restrict__ jobs, int jb, int nj,
+                                          F take) {
+  if ((int)threadIdx.x < nj) {
+    g.prefix[threadIdx.x] = jobs[jb + threadIdx.x].prefix;
+    g.inc[threadIdx.x] = jobs[jb + threadIdx.x].inc;
+    g.pad[threadIdx.x] = jobs[jb + threadIdx.x].pad;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int n = 0;
+    for (int i = 0; i <= MI; ++i) {
+      g.lvl[i] = n;
+      for (int j = 0; j < nj; ++j)
+        if ((g.inc[j] == i || (i == MI && g.inc[j] > MI)) && take(j)) {
+          g.act[n] = j;
+          g.act_hi[n] = (unsigned int)(g.prefix[j] >> 32);
+          ++n;
+        }
+    }
+    g.lvl[MI + 1] = n;
+  }
+  __syncthreads();
+  return g.lvl[MI + 1];
+}
+
 // SelJob::pad: bit 0 the caller also wants the NEXT order statistic; bit 1 that one lies
 // outside what this job has seen (select_succ_kernel finds it); bit 2 the candidates that
 // share the job's leading 24 bits fit a workgroup (their number in pad >> 8): no further
-// histogram passes, select_gather_kernel + select_small_kernel finish the job
+// histogram passes, select_gather_kernel + select_small_kernel finish the job; bit 3 more
+// candidates than that (heavy ties); bit 4 (set by the host for the first kSelTrack jobs of a
+// group and differencing order that want the next statistic) the gather pass leaves the smallest
+// key above the job's bucket in succ[]
 constexpr int kSelSmall = kSelSmallCap;   // (the host sizes the candidate lists with it)
 constexpr int kSelSmallShift = 40;   // bits below this are settled among the gathered candidates
 
 // One block column per GROUP of jobs that read the same (N, T) row block (the ranks and
 // differencing orders one iterated sum is asked for): every element is loaded once per
 // pass for all of them.
-constexpr int kSelGroupJobs = 8;
+template <int MI, int LVL>
+__device__ __forceinline__ void hist_level(const SelGroup &g, unsigned int (*lh)[256], int t,
+                                           double (&v)[MI + 1], int shift) {
+  if constexpr (LVL <= MI) {
+    if constexpr (LVL > 0) next_level<MI, LVL>(t, v);
+    const int kb = __builtin_amdgcn_readfirstlane(g.lvl[LVL]), ke = __builtin_amdgcn_readfirstlane(g.lvl[LVL + 1]);
+    if (kb != ke) {
+      const unsigned int kh = order_key_hi(v[0]);
+      const unsigned long long key = order_key(v[0]);
+      for (int k = kb; k < ke; ++k) {
+        const int job = g.act[k];
+        bool match;
+        unsigned int bin;
+        if (shift >= 32) {   // (uniform) a digit of the leading dword
+          match = shift == 56 || (kh >> (shift - 24)) == (g.act_hi[k] >> (shift - 24));
+          bin = (kh >> (shift - 32)) & 255u;
+        } else {
+          match = (key >> (shift + 8)) == (g.prefix[job] >> (shift + 8));
+          bin = (unsigned int)(key >> shift) & 255u;
+        }
+        // The leading digits (sign, exponent, high mantissa bits) are shared by almost all
+        // elements: 64 lanes adding to ONE LDS counter serialise.  The lanes that hold the
+        // first matching lane's digit are counted together - all of them in the usual case -
+        // and in the first two digits the others add one by one (both signs of an increment);
+        // later digits are spread out: there the split costs more than it saves.
+        const unsigned long long m = __ballot(match);
+        if (m == 0) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        const unsigned int lead_bin = (unsigned int)__builtin_amdgcn_readlane((int)bin, leader);
+        const bool same = match && bin == lead_bin;
+        const unsigned long long ms = __ballot(same);
+        bool todo = match;
+        if (ms == m || shift >= 48) {
+          if ((int)(threadIdx.x & 63) == leader) atomicAdd(&lh[job][lead_bin], (unsigned int)__popcll(ms));
+          todo = match && !same;
+        }
+        if (todo) atomicAdd(&lh[job][bin], 1u);
+      }
+    }
+    hist_level<MI, LVL + 1>(g, lh, t, v, shift);
+  }
+}
+
+template <int MI>
 __global__ __launch_bounds__(256) void select_hist_kernel(const SelJob *__restrict__ jobs,
                                                            const int2 *__restrict__ groups,
                                                            int64_t N, int64_t T, int shift,
                                                            unsigned int *__restrict__ hist) {
   __shared__ unsigned int lh[kSelGroupJobs][256];
+  __shared__ SelGroup g;
   const int jb = groups[blockIdx.y].x, nj = groups[blockIdx.y].y;
-  // jobs that finish among their gathered candidates take no part in later passes
-  bool any = false;
-  for (int j = 0; j < nj; ++j) any = any || !(jobs[jb + j].pad & 4);
-  if (!any) return;
+  // jobs that finish among their gathered candidates take no part in later passes; first pass:
+  // no prefix yet - jobs of one differencing order see the same histogram, which is counted
+  // once and copied below
+  const int n_act = load_group<MI>(g, jobs, jb, nj, [&](int j) {
+    return !(g.pad[j] & 4) && !(shift == 56 && j > 0 && g.inc[j] == g.inc[j - 1]);
+  });
+  if (n_act == 0) return;
   for (int j = 0; j < nj; ++j) lh[j][threadIdx.x] = 0;
   __syncthreads();
   const double *base = jobs[jb].base;
@@ -478,43 +593,17 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const SelJob *__restri
   const int64_t t_len = (T + per_series - 1) / per_series;
   const int64_t t_lo = part * t_len, t_hi = (t_lo + t_len < T) ? t_lo + t_len : T;
   for (int64_t n = n_first; n < N; n += n_step)
-  for (int64_t t = t_lo + threadIdx.x; t < t_hi; t += blockDim.x) {
-    unsigned long long key = 0;
-    int key_inc = -1;
-    for (int j = 0; j < nj; ++j) {
-      if (jobs[jb + j].pad & 4) continue;
-      const int inc = jobs[jb + j].inc;
-      // first pass: no prefix yet - jobs of one differencing order see the same histogram,
-      // which is counted once and copied below
-      if (shift == 56 && j > 0 && inc == jobs[jb + j - 1].inc) continue;
-      if (inc != key_inc) {  // jobs are sorted by differencing order
-        key = order_key(diff_at(base + n * T, t, inc));
-        key_inc = inc;
-      }
-      const unsigned long long prefix = jobs[jb + j].prefix;
-      const bool match = shift == 56 || (key >> (shift + 8)) == (prefix >> (shift + 8));
-      const unsigned int bin = (unsigned int)(key >> shift) & 255u;
-      // The leading digits (sign, exponent, high mantissa bits) are shared by almost all
-      // elements: 64 lanes adding to ONE LDS counter serialise.  When every matching lane
-      // of the wave holds the same digit, one lane adds the population count instead.
-      const unsigned long long m = __ballot(match);
-      if (m == 0) continue;
-      const int leader = __ffsll((long long)m) - 1;
-      const unsigned int lead_bin = (unsigned int)__builtin_amdgcn_readlane((int)bin, leader);
-      if (__ballot(match && bin == lead_bin) == m) {
-        if ((int)(threadIdx.x & 63) == leader)
-          atomicAdd(&lh[j][lead_bin], (unsigned int)__popcll(m));
-      } else if (match) {
-        atomicAdd(&lh[j][bin], 1u);
-      }
+    for (int t = (int)t_lo + (int)threadIdx.x; t < (int)t_hi; t += (int)blockDim.x) {
+      double v[MI + 1];
+      element_load<MI>(base + n * T, t, v);
+      hist_level<MI, 0>(g, lh, t, v, shift);
     }
-  }
   __syncthreads();
   for (int j = 0; j < nj; ++j) {
-    if (jobs[jb + j].pad & 4) continue;
+    if (g.pad[j] & 4) continue;
     int src = j;   // first pass: the histogram of the first job of this differencing order
     if (shift == 56)
-      while (src > 0 && jobs[jb + src - 1].inc == jobs[jb + j].inc) --src;
+      while (src > 0 && g.inc[src - 1] == g.inc[j]) --src;
     if (lh[src][threadIdx.x]) atomicAdd(&hist[(jb + j) * 256 + threadIdx.x], lh[src][threadIdx.x]);
   }
 }
@@ -570,26 +659,112 @@ __global__ void select_pick_kernel(SelJob *__restrict__ jobs, int shift,
 
 // One pass over the data: the keys that share a small job's leading bits go to its
 // candidate list (cand[job][0 .. kSelSmall), filled through cnt[job]).
+//
+// The smallest key ABOVE a job's bucket is the next order statistic when the selected one is the
+// bucket's largest - the usual case for the median of increments, which lies near zero where the
+// 24-bit buckets of floating-point numbers hold an element or two.  It is found here, in the
+// pass that reads everything anyway (jobs flagged with pad bit 4; per thread a running minimum
+// in registers, `above`), instead of in a pass of its own (select_succ_kernel).
+struct GatherBig {   // up to two jobs of the group whose candidates may all be equal
+  int big0, big1;
+  unsigned long long ref0, ref1;   // the first candidate anybody saw
+  bool other0, other1;
+};
+template <int MI, int LVL>
+__device__ __forceinline__ void gather_level(const SelGroup &g, int jb, int t, double (&v)[MI + 1],
+                                             unsigned long long (&above)[MI + 1][kSelTrack],
+                                             GatherBig &gb, unsigned long long *__restrict__ cand,
+                                             unsigned int *__restrict__ cnt) {
+  if constexpr (LVL <= MI) {
+    if constexpr (LVL > 0) next_level<MI, LVL>(t, v);
+    const int kb = __builtin_amdgcn_readfirstlane(g.lvl[LVL]), ke = __builtin_amdgcn_readfirstlane(g.lvl[LVL + 1]);
+    if (kb != ke) {
+      // the bucket (leading 24 bits) of this element
+      const unsigned int bucket = order_key_hi(v[0]) >> (kSelSmallShift - 32);
+      const unsigned long long key = order_key(v[0]);
+#pragma unroll
+      for (int a = 0; a < kSelTrack; ++a) {   // (the level's first jobs: the host flags only those)
+        if (kb + a < ke && (g.pad[g.act[kb + a]] & 16)) {
+          const unsigned int pb = g.act_hi[kb + a] >> (kSelSmallShift - 32);
+          if (bucket > pb && key < above[LVL][a]) above[LVL][a] = key;
+        }
+      }
+      for (int k = kb; k < ke; ++k) {
+        const int j = g.act[k];
+        const bool hit = bucket == (g.act_hi[k] >> (kSelSmallShift - 32));
+        if (j == gb.big0 || j == gb.big1) {
+          unsigned long long &ref = j == gb.big0 ? gb.ref0 : gb.ref1;
+          // nobody has published a candidate yet: ONE lane of the wave tries (a compare-and-swap
+          // per thread on one address would serialise a hundred thousand of them) and tells
+          // the others what the reference is
+          const unsigned long long ask = __ballot(hit && ref == ~0ull);
+          if (ask != 0) {
+            const int leader = __ffsll((long long)ask) - 1;
+            unsigned long long got = 0;
+            if ((int)(threadIdx.x & 63) == leader) {
+              const unsigned long long old =
+                  atomicCAS(&cand[(int64_t)(jb + j) * kSelSmall], ~0ull, key);
+              got = old == ~0ull ? key : old;
+            }
+            const unsigned long long told = __shfl(got, leader);
+            if (ref == ~0ull) ref = told;
+          }
+          if (hit && key != ref) (j == gb.big0 ? gb.other0 : gb.other1) = true;
+        } else if (hit) {
+          const unsigned int slot = atomicAdd(&cnt[jb + j], 1u);
+          if (slot < (unsigned int)kSelSmall) cand[(int64_t)(jb + j) * kSelSmall + slot] = key;
+        }
+      }
+    }
+    gather_level<MI, LVL + 1>(g, jb, t, v, above, gb, cand, cnt);
+  }
+}
+template <int MI, int LVL>
+__device__ __forceinline__ void gather_publish(const SelGroup &g, int jb,
+                                               const unsigned long long (&above)[MI + 1][kSelTrack],
+                                               unsigned long long *__restrict__ succ) {
+  if constexpr (LVL <= MI) {
+    const int kb = g.lvl[LVL], ke = g.lvl[LVL + 1];
+#pragma unroll
+    for (int a = 0; a < kSelTrack; ++a) {
+      if (kb + a < ke && (g.pad[g.act[kb + a]] & 16)) {
+        unsigned long long b = above[LVL][a];
+        for (int o = 32; o > 0; o >>= 1) {
+          const unsigned long long w = __shfl_xor(b, o);
+          b = w < b ? w : b;
+        }
+        if ((threadIdx.x & 63) == 0 && b != ~0ull) atomicMin(&succ[jb + g.act[kb + a]], b);
+      }
+    }
+    gather_publish<MI, LVL + 1>(g, jb, above, succ);
+  }
+}
+
+template <int MI>
 __global__ __launch_bounds__(256) void select_gather_kernel(const SelJob *__restrict__ jobs,
                                                              const int2 *__restrict__ groups,
                                                              int64_t N, int64_t T,
                                                              unsigned long long *__restrict__ cand,
-                                                             unsigned int *__restrict__ cnt) {
+                                                             unsigned int *__restrict__ cnt,
+                                                             unsigned long long *__restrict__ succ) {
+  static_assert(kSelSmallShift >= 32, "the bucket test reads the leading dword of a key");
+  __shared__ SelGroup g;
   const int jb = groups[blockIdx.y].x, nj = groups[blockIdx.y].y;
-  bool any = false;
-  int big0 = -1, big1 = -1;   // up to two jobs of the group whose candidates may all be equal
+  if (load_group<MI>(g, jobs, jb, nj, [&](int j) { return (g.pad[j] & 12) != 0; }) == 0) return;
+  GatherBig gb{-1, -1, ~0ull, ~0ull, false, false};
   for (int j = 0; j < nj; ++j) {
-    any = any || (jobs[jb + j].pad & 12);
-    if (jobs[jb + j].pad & 8) {
-      if (big0 < 0) big0 = j;
-      else if (big1 < 0) big1 = j;
+    if (g.pad[j] & 8) {
+      if (gb.big0 < 0) gb.big0 = j;
+      else if (gb.big1 < 0) gb.big1 = j;
     }
   }
-  if (!any) return;
-  unsigned long long ref0 = ~0ull, ref1 = ~0ull;   // the first candidate anybody saw
-  bool other0 = false, other1 = false;
-  if (big0 >= 0) ref0 = cand[(int64_t)(jb + big0) * kSelSmall];
-  if (big1 >= 0) ref1 = cand[(int64_t)(jb + big1) * kSelSmall];
+  if (gb.big0 >= 0) gb.ref0 = cand[(int64_t)(jb + gb.big0) * kSelSmall];
+  if (gb.big1 >= 0) gb.ref1 = cand[(int64_t)(jb + gb.big1) * kSelSmall];
+  unsigned long long above[MI + 1][kSelTrack];
+#pragma unroll
+  for (int i = 0; i <= MI; ++i)
+#pragma unroll
+    for (int a = 0; a < kSelTrack; ++a) above[i][a] = ~0ull;
   const double *base = jobs[jb].base;
   const int64_t per_series = (N >= (int64_t)gridDim.x) ? 1 : ((int64_t)gridDim.x + N - 1) / N;
   const int64_t n_first = (int64_t)blockIdx.x / per_series, part = (int64_t)blockIdx.x % per_series;
@@ -597,50 +772,14 @@ __global__ __launch_bounds__(256) void select_gather_kernel(const SelJob *__rest
   const int64_t t_len = (T + per_series - 1) / per_series;
   const int64_t t_lo = part * t_len, t_hi = (t_lo + t_len < T) ? t_lo + t_len : T;
   for (int64_t n = n_first; n < N; n += n_step)
-  for (int64_t t = t_lo + threadIdx.x; t < t_hi; t += blockDim.x) {
-    unsigned long long key = 0;
-    int key_inc = -1;
-    for (int j = 0; j < nj; ++j) {
-      if (j == big0 || j == big1) {
-        const int inc = jobs[jb + j].inc;
-        if (inc != key_inc) {
-          key = order_key(diff_at(base + n * T, t, inc));
-          key_inc = inc;
-        }
-        const bool hit = (key >> kSelSmallShift) == (jobs[jb + j].prefix >> kSelSmallShift);
-        unsigned long long &ref = j == big0 ? ref0 : ref1;
-        // nobody has published a candidate yet: ONE lane of the wave tries (a compare-and-swap
-        // per thread on one address would serialise a hundred thousand of them) and tells
-        // the others what the reference is
-        const unsigned long long ask = __ballot(hit && ref == ~0ull);
-        if (ask != 0) {
-          const int leader = __ffsll((long long)ask) - 1;
-          unsigned long long got = 0;
-          if ((int)(threadIdx.x & 63) == leader) {
-            const unsigned long long old =
-                atomicCAS(&cand[(int64_t)(jb + j) * kSelSmall], ~0ull, key);
-            got = old == ~0ull ? key : old;
-          }
-          const unsigned long long told = __shfl(got, leader);
-          if (ref == ~0ull) ref = told;
-        }
-        if (hit && key != ref) (j == big0 ? other0 : other1) = true;
-        continue;
-      }
-      if (!(jobs[jb + j].pad & 4)) continue;
-      const int inc = jobs[jb + j].inc;
-      if (inc != key_inc) {
-        key = order_key(diff_at(base + n * T, t, inc));
-        key_inc = inc;
-      }
-      if ((key >> kSelSmallShift) == (jobs[jb + j].prefix >> kSelSmallShift)) {
-        const unsigned int slot = atomicAdd(&cnt[jb + j], 1u);
-        if (slot < (unsigned int)kSelSmall) cand[(int64_t)(jb + j) * kSelSmall + slot] = key;
-      }
+    for (int t = (int)t_lo + (int)threadIdx.x; t < (int)t_hi; t += (int)blockDim.x) {
+      double v[MI + 1];
+      element_load<MI>(base + n * T, t, v);
+      gather_level<MI, 0>(g, jb, t, v, above, gb, cand, cnt);
     }
-  }
-  if (other0) cand[(int64_t)(jb + big0) * kSelSmall + 1] = 1ull;
-  if (other1) cand[(int64_t)(jb + big1) * kSelSmall + 1] = 1ull;
+  if (gb.other0) cand[(int64_t)(jb + gb.big0) * kSelSmall + 1] = 1ull;
+  if (gb.other1) cand[(int64_t)(jb + gb.big1) * kSelSmall + 1] = 1ull;
+  gather_publish<MI, 0>(g, jb, above, succ);
 }
 
 // One workgroup per small job: the k-th smallest of its candidates (and the next one) by
@@ -661,9 +800,11 @@ __global__ __launch_bounds__(256) void select_small_kernel(SelJob *__restrict__ 
       if (key != ~0ull && cand[(int64_t)job * kSelSmall + 1] == 0ull) {
         out[job] = key_to_double(key);
         jobs[job].prefix = key;
+        // (the next one: another copy, else the smallest key above the bucket - already in
+        // succ[job], select_gather_kernel)
         if (jobs[job].pad & 1) {
           if (jobs[job].k + 1 < (long long)cnt[job]) succ[job] = key;
-          else jobs[job].pad |= 2;
+          else if (!(jobs[job].pad & 16)) jobs[job].pad |= 2;
         }
         jobs[job].pad |= 4;
         atomicSub(n_big, 1u);
@@ -698,7 +839,7 @@ __global__ __launch_bounds__(256) void select_small_kernel(SelJob *__restrict__ 
   __syncthreads();
   if (!(jobs[job].pad & 1) || next_key == ~0ull) return;
   // the next order statistic is the smallest candidate above the selected key - or, when the
-  // selected key is the largest candidate, outside the list (select_succ_kernel)
+  // selected key is the largest candidate, the smallest key above the bucket
   const unsigned long long sel = jobs[job].prefix;
   unsigned long long best = ~0ull;
   for (int i = threadIdx.x; i < n; i += blockDim.x)
@@ -712,81 +853,109 @@ __global__ __launch_bounds__(256) void select_small_kernel(SelJob *__restrict__ 
   __syncthreads();
   if ((threadIdx.x & 63) == 0 && best != ~0ull) atomicMin(&next_key, best);
   __syncthreads();
+  // (none: the selected key is the bucket's largest; succ[job] already holds the smallest key
+  // above the bucket when the gather pass tracked it - pad bit 4 - else a pass of its own finds it)
   if (threadIdx.x == 0) {
     if (next_key != ~0ull) succ[job] = next_key;
-    else jobs[job].pad |= 2;
+    else if (!(jobs[job].pad & 16)) jobs[job].pad |= 2;
   }
 }
 
-// smallest key above the selected one, for the jobs select_pick_kernel flagged (pad & 2);
+// smallest key above the selected one, for the jobs flagged pad & 2 (select_pick_kernel at the
+// last digit; select_small_kernel for jobs whose successor the gather pass did not track);
 // succ[] starts at the largest key
+template <int MI, int LVL>
+__device__ __forceinline__ void succ_level(const SelGroup &g, int jb, int t, double (&v)[MI + 1],
+                                           unsigned long long (&best)[MI + 1],
+                                           unsigned long long *__restrict__ succ) {
+  if constexpr (LVL <= MI) {
+    if constexpr (LVL > 0) next_level<MI, LVL>(t, v);
+    const int kb = __builtin_amdgcn_readfirstlane(g.lvl[LVL]), ke = __builtin_amdgcn_readfirstlane(g.lvl[LVL + 1]);
+    if (kb != ke) {
+      const unsigned long long key = order_key(v[0]);
+      // the level's first job: a running minimum in a register, published at the end
+      if (key > g.prefix[g.act[kb]] && key < best[LVL]) best[LVL] = key;
+      for (int k = kb + 1; k < ke; ++k) {
+        // (further jobs of a level are rare: the wave's smallest candidate straight to memory)
+        unsigned long long b = key > g.prefix[g.act[k]] ? key : ~0ull;
+        if (__ballot(b != ~0ull) == 0) continue;
+        for (int o = 32; o > 0; o >>= 1) {
+          const unsigned long long w = __shfl_xor(b, o);
+          b = w < b ? w : b;
+        }
+        if ((threadIdx.x & 63) == 0 && b < succ[jb + g.act[k]]) atomicMin(&succ[jb + g.act[k]], b);
+      }
+    }
+    succ_level<MI, LVL + 1>(g, jb, t, v, best, succ);
+  }
+}
+template <int MI, int LVL>
+__device__ __forceinline__ void succ_publish(const SelGroup &g, int jb, const unsigned long long (&best)[MI + 1],
+                                             unsigned long long *__restrict__ succ) {
+  if constexpr (LVL <= MI) {
+    if (g.lvl[LVL] != g.lvl[LVL + 1]) {
+      unsigned long long b = best[LVL];
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long w = __shfl_xor(b, o);
+        b = w < b ? w : b;
+      }
+      if ((threadIdx.x & 63) == 0 && b != ~0ull) atomicMin(&succ[jb + g.act[g.lvl[LVL]]], b);
+    }
+    succ_publish<MI, LVL + 1>(g, jb, best, succ);
+  }
+}
+template <int MI>
 __global__ __launch_bounds__(256) void select_succ_kernel(const SelJob *__restrict__ jobs,
                                                            const int2 *__restrict__ groups,
                                                            int64_t N, int64_t T,
-                                                           unsigned long long *__restrict__ succ) {
+                                                           unsigned long long *succ) {
+  __shared__ SelGroup g;
   const int jb = groups[blockIdx.y].x, nj = groups[blockIdx.y].y;
-  bool any = false;
-  for (int j = 0; j < nj; ++j) any = any || (jobs[jb + j].pad & 2);
-  if (!any) return;
+  if (load_group<MI>(g, jobs, jb, nj, [&](int j) { return (g.pad[j] & 2) != 0; }) == 0) return;
+  unsigned long long best[MI + 1];
+#pragma unroll
+  for (int i = 0; i <= MI; ++i) best[i] = ~0ull;
   const double *base = jobs[jb].base;
-  unsigned long long best[kSelGroupJobs];
-  for (int j = 0; j < kSelGroupJobs; ++j) best[j] = ~0ull;
   const int64_t per_series = (N >= (int64_t)gridDim.x) ? 1 : ((int64_t)gridDim.x + N - 1) / N;
   const int64_t n_first = (int64_t)blockIdx.x / per_series, part = (int64_t)blockIdx.x % per_series;
   const int64_t n_step = ((int64_t)gridDim.x + per_series - 1) / per_series;
   const int64_t t_len = (T + per_series - 1) / per_series;
   const int64_t t_lo = part * t_len, t_hi = (t_lo + t_len < T) ? t_lo + t_len : T;
   for (int64_t n = n_first; n < N; n += n_step)
-  for (int64_t t = t_lo + threadIdx.x; t < t_hi; t += blockDim.x) {
-    unsigned long long key = 0;
-    int key_inc = -1;
-#pragma unroll
-    for (int j = 0; j < kSelGroupJobs; ++j) {
-      if (j >= nj || !(jobs[jb + j].pad & 2)) continue;
-      const int inc = jobs[jb + j].inc;
-      if (inc != key_inc) {
-        key = order_key(diff_at(base + n * T, t, inc));
-        key_inc = inc;
-      }
-      if (key > jobs[jb + j].prefix && key < best[j]) best[j] = key;
+    for (int t = (int)t_lo + (int)threadIdx.x; t < (int)t_hi; t += (int)blockDim.x) {
+      double v[MI + 1];
+      element_load<MI>(base + n * T, t, v);
+      succ_level<MI, 0>(g, jb, t, v, best, succ);
     }
-  }
-#pragma unroll
-  for (int j = 0; j < kSelGroupJobs; ++j) {
-    if (j >= nj || !(jobs[jb + j].pad & 2)) continue;
-    unsigned long long b = best[j];
-    for (int o = 32; o > 0; o >>= 1) {
-      const unsigned long long w = __shfl_xor(b, o);
-      b = w < b ? w : b;
-    }
-    if ((threadIdx.x & 63) == 0 && b != ~0ull) atomicMin(&succ[jb + j], b);
-  }
+  succ_publish<MI, 0>(g, jb, best, succ);
 }
 
-hipError_t launch_select_ranks(void *jobs, int n_jobs, const void *groups, int n_groups, int64_t N,
-                               int64_t T, unsigned int *hist, double *out,
-                               unsigned long long *succ, unsigned long long *cand,
-                               unsigned int *cand_count, hipStream_t st) {
-  if (n_jobs <= 0 || n_groups <= 0 || N * T <= 0) return hipSuccess;
+// MI: the largest differencing order of the launch's jobs (kernels are compiled for 0, 1, 2 and
+// kMaxInc)
+template <int MI>
+static hipError_t select_ranks_mi(SelJob *jb, int n_jobs, const int2 *gr, int n_groups,
+                                  const int32_t *h_groups, int2 *gr_active, bool untracked, int64_t N, int64_t T,
+                                  unsigned int *hist, double *out, unsigned long long *succ,
+                                  unsigned long long *cand, unsigned int *cand_count, hipStream_t st) {
   int64_t bpj = (N * T + 256 * 16 - 1) / (256 * 16);
   if (bpj > 512) bpj = 512;
   if (bpj < 1) bpj = 1;
-  SelJob *jb = static_cast<SelJob *>(jobs);
-  const int2 *gr = static_cast<const int2 *>(groups);
+  const int2 *pass_groups = gr;
+  int pass_n = n_groups;
+  bool trailing = false;   // some jobs go through all eight digits
   for (int shift = 56; shift >= 0; shift -= 8) {
-    // (below kSelSmallShift only the jobs with too many candidates for a workgroup - heavy
-    // ties - are still in the histogram passes; groups without one return at once)
-    hipLaunchKernelGGL(select_hist_kernel, dim3((unsigned)bpj, (unsigned)n_groups), dim3(256), 0,
-                       st, jb, gr, N, T, shift, hist);
+    hipLaunchKernelGGL(select_hist_kernel<MI>, dim3((unsigned)bpj, (unsigned)pass_n), dim3(256), 0,
+                       st, jb, pass_groups, N, T, shift, hist);
     hipLaunchKernelGGL(select_pick_kernel, dim3((unsigned)n_jobs), dim3(64), 0, st, jb, shift,
                        hist, out, succ, cand_count + n_jobs, cand, cand_count);
     if (shift == kSelSmallShift) {
-      hipLaunchKernelGGL(select_gather_kernel, dim3((unsigned)bpj, (unsigned)n_groups), dim3(256),
-                         0, st, jb, gr, N, T, cand, cand_count);
+      hipLaunchKernelGGL(select_gather_kernel<MI>, dim3((unsigned)bpj, (unsigned)n_groups), dim3(256),
+                         0, st, jb, gr, N, T, cand, cand_count, succ);
       hipLaunchKernelGGL(select_small_kernel, dim3((unsigned)n_jobs), dim3(256), 0, st, jb, cand,
                          cand_count, out, succ, cand_count + n_jobs);
-      // no job left in the histogram passes (the usual case): the five remaining passes would
-      // launch tens of thousands of workgroups only to return - ask the device
+      // no job left in the histogram passes (the usual case): done.  Else only the jobs with
+      // too many candidates for a workgroup - heavy ties that are not ONE value - go on, and
+      // the five remaining passes run over THEIR groups alone (the host reads the jobs' flags)
       unsigned int n_big = 1;
       if (hipMemcpyAsync(&n_big, cand_count + n_jobs, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
           hipStreamSynchronize(st) != hipSuccess) {
@@ -794,11 +963,57 @@ hipError_t launch_select_ranks(void *jobs, int n_jobs, const void *groups, int n
         n_big = 1;
       }
       if (n_big == 0) break;
+      std::vector<SelJob> hj((size_t)n_jobs);
+      if (hipMemcpy(hj.data(), jb, (size_t)n_jobs * sizeof(SelJob), hipMemcpyDeviceToHost) == hipSuccess) {
+        std::vector<int32_t> active;
+        for (int g = 0; g < n_groups; ++g) {
+          bool left = false;
+          for (int j = 0; j < h_groups[2 * g + 1]; ++j) left = left || !(hj[h_groups[2 * g] + j].pad & 4);
+          if (left) {
+            active.push_back(h_groups[2 * g]);
+            active.push_back(h_groups[2 * g + 1]);
+          }
+        }
+        if (active.empty()) break;
+        if (hipMemcpy(gr_active, active.data(), active.size() * 4, hipMemcpyHostToDevice) == hipSuccess) {
+          pass_groups = gr_active;
+          pass_n = (int)active.size() / 2;
+        } else {
+          (void)hipGetLastError();
+        }
+      } else {
+        (void)hipGetLastError();
+      }
+      trailing = true;
     }
   }
-  hipLaunchKernelGGL(select_succ_kernel, dim3((unsigned)bpj, (unsigned)n_groups), dim3(256), 0, st,
-                     jb, gr, N, T, succ);
+  // (jobs that went through all eight digits and need a neighbour outside what they saw: one
+  // more pass over their groups; everybody else has it from the gather pass - unless a group
+  // asks for more neighbours per differencing order than that pass tracks)
+  if (untracked)
+    hipLaunchKernelGGL(select_succ_kernel<MI>, dim3((unsigned)bpj, (unsigned)n_groups), dim3(256), 0, st,
+                       jb, gr, N, T, succ);
+  else if (trailing)
+    hipLaunchKernelGGL(select_succ_kernel<MI>, dim3((unsigned)bpj, (unsigned)pass_n), dim3(256), 0, st,
+                       jb, pass_groups, N, T, succ);
   return hipGetLastError();
+}
+
+hipError_t launch_select_ranks(void *jobs, int n_jobs, const void *groups, int n_groups,
+                               const int32_t *h_groups, void *groups_scratch, int max_inc,
+                               bool untracked, int64_t N, int64_t T, unsigned int *hist, double *out,
+                               unsigned long long *succ, unsigned long long *cand,
+                               unsigned int *cand_count, hipStream_t st) {
+  if (n_jobs <= 0 || n_groups <= 0 || N * T <= 0) return hipSuccess;
+  SelJob *jb = static_cast<SelJob *>(jobs);
+  const int2 *gr = static_cast<const int2 *>(groups);
+  int2 *ga = static_cast<int2 *>(groups_scratch);
+  switch (max_inc) {
+    case 0: return select_ranks_mi<0>(jb, n_jobs, gr, n_groups, h_groups, ga, untracked, N, T, hist, out, succ, cand, cand_count, st);
+    case 1: return select_ranks_mi<1>(jb, n_jobs, gr, n_groups, h_groups, ga, untracked, N, T, hist, out, succ, cand, cand_count, st);
+    case 2: return select_ranks_mi<2>(jb, n_jobs, gr, n_groups, h_groups, ga, untracked, N, T, hist, out, succ, cand, cand_count, st);
+    default: return select_ranks_mi<kMaxInc>(jb, n_jobs, gr, n_groups, h_groups, ga, untracked, N, T, hist, out, succ, cand, cand_count, st);
+  }
 }
 
 // ---------------------------------------------------------------- launchers

@@ -34,6 +34,11 @@ def _check_batch(X) -> np.ndarray:
     return X
 
 
+# one helper thread: Fruit.fit overlaps the device-side selection of a slice with the host-side
+# bookkeeping (fr_select_ranks blocks until its results are on the host)
+from concurrent.futures import ThreadPoolExecutor as _ThreadPoolExecutor
+_SELECT_POOL = _ThreadPoolExecutor(max_workers=1, thread_name_prefix="fruits-select")
+
 class Fruit:
     """Feature extractor made of one or more :class:`FruitSlice` objects whose
     features are concatenated.
@@ -365,16 +370,25 @@ class FruitSlice:
             # (what a sieve asks for depends on its q and the sample size only: once per sieve,
             # not once per copy)
             asks = [sv._quantile_requests(n) if sv.requires_fitting else None for sv in self._sieves]
+            wanted = [(sv._inc, [(lo, hi) for (_, lo, hi, _) in reqs])
+                      for sv, reqs in zip(self._sieves, asks) if reqs is not None]
+            per_row = []
+            for k in range(block.shape[0]):
+                per_row.append([[(job(k, inc, lo), job(k, inc, hi)) for lo, hi in pairs]
+                                for inc, pairs in wanted])
+            # the selection runs on the device (the C call releases the interpreter lock) while
+            # this thread makes the per-row copies of the sieves
+            pending = (_SELECT_POOL.submit(nat.select_ranks, block, rows, incs, ranks, nat.stream_ptr())
+                       if rows else None)
             for k in range(block.shape[0]):
                 fitted = [sieve.copy() for sieve in self._sieves]
+                row_jobs = iter(per_row[k])
                 for sieve, reqs in zip(fitted, asks):
                     sieve._cache = cache
                     if reqs is not None:
-                        inc = sieve._inc
-                        owners.append((sieve, reqs, [(job(k, inc, lo), job(k, inc, hi))
-                                                     for (_, lo, hi, _) in reqs]))
+                        owners.append((sieve, reqs, next(row_jobs)))
                 copies.append(fitted)
-            vals = nat.select_ranks(block, rows, incs, ranks) if rows else np.zeros(0)
+            vals = pending.result() if pending is not None else np.zeros(0)
             for sieve, reqs, idx in owners:
                 sieve._set_quantiles_from_stats(reqs, [vals[a] for a, _ in idx],
                                                 [vals[b] for _, b in idx])
