@@ -673,6 +673,7 @@ struct GatherBig {   // up to two jobs of the group whose candidates may all be 
 template <int MI, int LVL>
 __device__ __forceinline__ void gather_level(const SelGroup &g, int jb, int t, double (&v)[MI + 1],
                                              unsigned long long (&above)[MI + 1][kSelTrack],
+                                             const unsigned int (&track)[MI + 1][kSelTrack],
                                              GatherBig &gb, unsigned long long *__restrict__ cand,
                                              unsigned int *__restrict__ cnt) {
   if constexpr (LVL <= MI) {
@@ -683,12 +684,8 @@ __device__ __forceinline__ void gather_level(const SelGroup &g, int jb, int t, d
       const unsigned int bucket = order_key_hi(v[0]) >> (kSelSmallShift - 32);
       const unsigned long long key = order_key(v[0]);
 #pragma unroll
-      for (int a = 0; a < kSelTrack; ++a) {   // (the level's first jobs: the host flags only those)
-        if (kb + a < ke && (g.pad[g.act[kb + a]] & 16)) {
-          const unsigned int pb = g.act_hi[kb + a] >> (kSelSmallShift - 32);
-          if (bucket > pb && key < above[LVL][a]) above[LVL][a] = key;
-        }
-      }
+      for (int a = 0; a < kSelTrack; ++a)   // (the level's first jobs: the host flags only those)
+        if (bucket > track[LVL][a] && key < above[LVL][a]) above[LVL][a] = key;
       for (int k = kb; k < ke; ++k) {
         const int j = g.act[k];
         const bool hit = bucket == (g.act_hi[k] >> (kSelSmallShift - 32));
@@ -716,7 +713,7 @@ __device__ __forceinline__ void gather_level(const SelGroup &g, int jb, int t, d
         }
       }
     }
-    gather_level<MI, LVL + 1>(g, jb, t, v, above, gb, cand, cnt);
+    gather_level<MI, LVL + 1>(g, jb, t, v, above, track, gb, cand, cnt);
   }
 }
 template <int MI, int LVL>
@@ -761,10 +758,16 @@ __global__ __launch_bounds__(256) void select_gather_kernel(const SelJob *__rest
   if (gb.big0 >= 0) gb.ref0 = cand[(int64_t)(jb + gb.big0) * kSelSmall];
   if (gb.big1 >= 0) gb.ref1 = cand[(int64_t)(jb + gb.big1) * kSelSmall];
   unsigned long long above[MI + 1][kSelTrack];
+  unsigned int track[MI + 1][kSelTrack];   // bucket of a tracked job (else: nothing lies above it)
 #pragma unroll
   for (int i = 0; i <= MI; ++i)
 #pragma unroll
-    for (int a = 0; a < kSelTrack; ++a) above[i][a] = ~0ull;
+    for (int a = 0; a < kSelTrack; ++a) {
+      above[i][a] = ~0ull;
+      const int k = g.lvl[i] + a;
+      const bool on = k < g.lvl[i + 1] && (g.pad[g.act[k < kSelGroupJobs ? k : 0]] & 16);
+      track[i][a] = on ? g.act_hi[k < kSelGroupJobs ? k : 0] >> (kSelSmallShift - 32) : ~0u;
+    }
   const double *base = jobs[jb].base;
   const int64_t per_series = (N >= (int64_t)gridDim.x) ? 1 : ((int64_t)gridDim.x + N - 1) / N;
   const int64_t n_first = (int64_t)blockIdx.x / per_series, part = (int64_t)blockIdx.x % per_series;
@@ -775,7 +778,7 @@ __global__ __launch_bounds__(256) void select_gather_kernel(const SelJob *__rest
     for (int t = (int)t_lo + (int)threadIdx.x; t < (int)t_hi; t += (int)blockDim.x) {
       double v[MI + 1];
       element_load<MI>(base + n * T, t, v);
-      gather_level<MI, 0>(g, jb, t, v, above, gb, cand, cnt);
+      gather_level<MI, 0>(g, jb, t, v, above, track, gb, cand, cnt);
     }
   if (gb.other0) cand[(int64_t)(jb + gb.big0) * kSelSmall + 1] = 1ull;
   if (gb.other1) cand[(int64_t)(jb + gb.big1) * kSelSmall + 1] = 1ull;

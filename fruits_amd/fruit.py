@@ -411,8 +411,9 @@ class FruitSlice:
             # the factorised CosWISS kernels fuse; the term-by-term path reduces first
             if type(last) is not CosWISS or not last._native():
                 return False
-            if last._ffn_size is not None:
-                return False     # every (word, frequency) reads its own transformed input
+            if last._ffn_size is not None and len(self._iss) != 1:
+                return False     # (every (word, frequency) reads its own transformed input:
+                                 # fused word by word, _transform_ffn_fused - single ISS only)
         for sv in self._sieves:
             if type(sv) not in (NPI, MPI, END):
                 return False
@@ -617,7 +618,8 @@ class FruitSlice:
             cache = SharedSeedCache(X)
         t = nat.torch()
         Xd = cache.input_device(X) if cache._input is X else nat.to_device(X)
-        if not callbacks and len(self._iss) == 1:
+        ffn = getattr(self._iss[-1], "_ffn_size", None) is not None
+        if not callbacks and len(self._iss) == 1 and not ffn:
             # INC / NEW(INC) / STD formed while the fused launch stages the RAW rows: no
             # prepared tensor is written (one launch [+ the STD statistics pre-pass])
             T = int(Xd.shape[2])
@@ -636,6 +638,8 @@ class FruitSlice:
         for cb in callbacks:
             cb.on_preparation_end(nat.to_host(Pd))
         self._attach(cache)
+        if ffn and not callbacks and self._fusable():
+            return self._transform_ffn_fused(Pd, cache)
         fused = None if callbacks else self._fused(int(Pd.shape[2]))
         if fused is not None and len(self._iss) > 1:
             return self._transform_chain_fused(Pd, cache)
@@ -681,6 +685,31 @@ class FruitSlice:
                 pipe.set_preparation(1)
             self._arm_series_cuts(pipe, N, T, cache)
             feats[:, r * width:(r + 1) * width] = pipe.run(Xin, last.lookup_device(Xin))
+        return feats
+
+    def _transform_ffn_fused(self, Pd, cache):
+        """CosWISS with the randomised ffn (fruits/iss/cos.py:93-137): every (word, frequency)
+        reads its own transformed copy of the input, so the slice runs word by word - the F copies
+        of a word (coswiss_ffn) go through ONE fused launch of that word's units and the sieves
+        (pipeline over the word alone, its rows' thresholds): W launches, and neither the
+        (W x F, N, T) iterated sums nor a sieve pass over them."""
+        t = nat.torch()
+        iss = self._iss[0]
+        N, D, T = (int(v) for v in Pd.shape)
+        F = len(iss._freqs)
+        width = F * sum(sv.nfeatures() for sv in self._sieves)
+        feats = t.empty((N, self.nfeatures()), dtype=t.float64, device=Pd.device)
+        Z = t.empty((F, N, D, T), dtype=t.float64, device=Pd.device)
+        for w in range(len(iss.words)):
+            pipe = self._fused(T, indices=(w,))
+            if pipe.plan.max_dim > D:
+                raise IndexError(f"a word references dimension {pipe.plan.max_dim} but "
+                                 f"the input has only {D}")
+            for f in range(F):
+                nat.coswiss_ffn(Pd, iss._A[w, f], iss._b[w, f], iss._C[w, f], Z[f])
+            nat.check(nat.lib().fr_coswiss_set_input_stride(pipe.plan._h, N * D * T))
+            self._arm_series_cuts(pipe, N, T, cache)
+            feats[:, w * width:(w + 1) * width] = pipe.run(Z[0], None)
         return feats
 
     def fit_transform(self, X: np.ndarray) -> np.ndarray:

@@ -1322,6 +1322,41 @@ def test_fused_preparation(fr, monkeypatch, chain, T):
     strict_transform_parity(fruit, spec, X, X, labels, np_seed=1, what=f"fused preparation {chain} T={T}")
 
 
+@pytest.mark.parametrize("T", [300, 700, 1300])
+def test_coswiss_ffn_fused(fr, T, monkeypatch):
+    """CosWISS with the randomised ffn: every (word, frequency) reads its own transformed input, so
+    the slice fuses word by word (FruitSlice._transform_ffn_fused) - same features as the unfused
+    path (materialised sums + sieve kernels) on the same fitted fruit."""
+    rng = np.random.default_rng(T)
+    X = rng.standard_normal((21, 2, T)).cumsum(axis=2) / 6.0
+    fruit = fr.Fruit("ffn")
+    fruit.add(fr.preparation.INC)
+    words = [fr.words.SimpleWord(s) for s in ["[1]", "[1][2]", "[2][1][1]"]]
+    fruit.add(fr.CosWISS(freqs=[0.1, 0.35], words=words, exponent=2, ffn_size=5))
+    fruit.add(fr.sieving.NPI(q=(0.4, 1.0)), fr.sieving.MPI(q=(0.4, 1.0), inc=0), fr.sieving.NPI(inc=2),
+              fr.sieving.END(cut=[T // 2, -1]))
+    fruit.get_slice().fit_sample_size = 1.0
+    np.random.seed(6)
+    fruit.fit(X)
+    got = fruit.transform(X)
+    pipe = fruit.get_slice()._fused(T, indices=(1,))
+    assert pipe is not None                       # the word-by-word pipelines exist
+    monkeypatch.setenv("FRUITS_AMD_FUSED", "0")
+    plain = fruit.transform(X)
+    labels = [fruit.label(i) for i in range(fruit.nfeatures())]
+    counts = np.array(["NPI" in lb for lb in labels])
+    ends = np.array(["END" in lb for lb in labels])
+    np.testing.assert_allclose(got[:, ends], plain[:, ends], rtol=1e-12, atol=1e-300)
+    # (counts: the fused epilogue forms an increment as the step of a sequential sum, the sieve
+    # kernels as the difference of two stored values - an element ON a fitted threshold, itself a
+    # data value, may fall on either side)
+    d = np.abs(got[:, counts] - plain[:, counts])
+    assert d.max() <= 2 and (d > 0).mean() <= 0.02, (d.max(), (d > 0).mean())
+    means = ~counts & ~ends
+    close = np.isclose(got[:, means], plain[:, means], rtol=1e-6, atol=1e-12)
+    assert close.mean() >= 0.98
+
+
 @pytest.mark.parametrize("T", [385, 700, 1500])
 def test_letter_whose_exponents_cancel(fr, T):
     """[2-2] multiplies by nothing (its node has no factor): the iterated sums against the C
