@@ -190,6 +190,8 @@ class _Pipeline:
         lookup_b = 0 if self.lk is None else 8.0 * self.lk.numel()
         return {
             "launch_us": t_us, "K": K, "features": pipe.n_features, "nodes": pipe.plan.nodes,
+            "kernel": ("fused walk compiled for this pipeline at prepare time (hipRTC: the sieves "
+                       "as immediates)" if pipe.jit_loaded() else "fused walk, generic instance"),
             "elements_per_s": N * K * T / (t_us * 1e-6),
             "algorithmic_bytes": 8.0 * N * T * d_used + lookup_b + 8.0 * N * pipe.n_features,
             "equivalent_materialised_GBs": (8.0 * N * T * (d_used + K) + lookup_b) / (t_us * 1e-6) / 1e9,

@@ -316,7 +316,7 @@ int64_t query_resident(const fr::Plan &p, int64_t N, int64_t T, bool fused, bool
 //                       rounds and their restaging hits the XCD's L2 (N = 4096: 135.5 vs
 //                       146.6 us, N = 8192: 272 vs 291 us); larger plans keep whole series
 //                       (config 3 / 4 / 5: no difference measured)
-int choose_groups_walk(const fr::Plan &p, int64_t N, int64_t resident, bool fused = false) {
+int choose_groups_walk(const fr::Plan &p, int64_t N, int64_t T, int64_t resident, bool fused = false) {
   const int U = p.units();
   if (U <= 1 || N <= 0) return 1;
   if (resident <= 0) return choose_groups(p, N, 0);
@@ -329,7 +329,12 @@ int choose_groups_walk(const fr::Plan &p, int64_t N, int64_t resident, bool fuse
   // 13.32 ms); on shorter ones every extra unit is one more staging of the series' rows - the
   // word shards of config 4 over 8 ranks (~170 nodes each): 1.86 ms with whole series, 2.40 ms
   // with two groups (tools/bench_shards.py)
-  if (fused) return p.nodes.size() >= 400 ? std::min(U, 2) : 1;   // (config 5, 511 nodes: 24.9 vs 25.3 ms)
+  // (round 3, the pipeline's own kernels: one-chunk plans of 668 / 683 nodes - two word shards of
+  // config 4 - 4.74 / 4.84 ms with whole series, 5.47 / 5.48 ms with two groups; 1351 nodes: 9.53
+  // vs 9.35 ms; config 5, 511 nodes over four time chunks - two groups also halve the LDS carries
+  // of a unit: 17.8 vs 17.3 ms)
+  if (fused)
+    return p.nodes.size() >= (T > fr::walk_chunk_elems(T) ? 400u : 1000u) ? std::min(U, 2) : 1;
   // materialising launches of long plans run one short-lived workgroup per unit too (the lean
   // walk, run_walk): two groups per series shorten the last round (of_weight(4,2), N = 2048:
   // 390 -> 372 us; the same at N = 8192) for one more staging of the series' rows
@@ -400,8 +405,8 @@ int prepare_plan(fr::Plan &p, int64_t N, int64_t T, int32_t groups, bool fused, 
   if (auto_groups) {
     // (the choice depends on the kernel instance - fused or not, 16-byte aligned or not -
     // which is only known when the pointers are: upload what either would ask for)
-    Gs.push_back(choose_groups_walk(p, N, query_resident(p, N, T, fused, true), fused));
-    if (!fused) Gs.push_back(choose_groups_walk(p, N, query_resident(p, N, T, false, false)));
+    Gs.push_back(choose_groups_walk(p, N, T, query_resident(p, N, T, fused, true), fused));
+    if (!fused) Gs.push_back(choose_groups_walk(p, N, T, query_resident(p, N, T, false, false)));
   } else {
     Gs.push_back(shape.G);
   }
@@ -931,7 +936,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
       }
     }
     const int G = static_prog ? static_groups
-                              : (auto_groups ? choose_groups_walk(p, N, resident, fu != nullptr) : shape.G);
+                              : (auto_groups ? choose_groups_walk(p, N, T, resident, fu != nullptr) : shape.G);
     gpp = &fr::grouped(p, G);   // (map nodes are stable: the reference outlives the lock)
     if (!static_prog) {
       int rc = ensure_device_program(p, *gpp, st, who);

@@ -501,13 +501,16 @@ class FruitSlice:
 
     @staticmethod
     def _auto_prepare(pipe, N: int, T: int) -> None:
-        """A fused launch over a large batch prepares its pipeline once per batch size: the
-        pipeline's own kernel is compiled at run time (hipRTC, ~2 s, cached on disk) with the
-        sieves as immediates - worth it from ~64 MiB of iterated sums on, like ISS.transform's
-        static programs (FRUITS_AMD_AUTO_PREPARE=0: never)."""
-        if os.environ.get("FRUITS_AMD_AUTO_PREPARE", "1") == "0":
+        """A fused launch over a very large batch prepares its pipeline once per batch size: the
+        pipeline's own kernel is compiled at run time (hipRTC) with the sieves as immediates, a
+        quarter faster than the generic instance.  The compilation takes ~2 s the first time on a
+        machine (then it comes from the disk cache), so only launches of tens of milliseconds
+        ask for it by themselves - 8 GiB of iterated sums (FRUITS_AMD_AUTO_PREPARE=0: never,
+        =all: every fused launch); ``pipeline.prepare(N)`` is the explicit way."""
+        mode = os.environ.get("FRUITS_AMD_AUTO_PREPARE", "1")
+        if mode == "0" or getattr(pipe, "_prepared_for", None) == N:
             return
-        if getattr(pipe, "_prepared_for", None) == N or 8 * N * pipe.plan.rows * T < (64 << 20):
+        if mode != "all" and 8 * N * pipe.plan.rows * T < (8 << 30):
             return
         pipe.prepare(N)
         pipe._prepared_for = N

@@ -265,7 +265,8 @@ int fr_sieve(int32_t kind, const double *d_A, int64_t N, int64_t T, int64_t a_st
  *   d_feats            (N, feat_stride >= F) output, F = fr_pipeline_info(p, 2)
  * Returns FR_E_LIMIT from create when a sieve is outside the fused set (the caller
  * then uses fr_iss_run + fr_sieve).  fr_pipeline_info: 0 features per iterated sum,
- * 1 q_stride, 2 total features. */
+ * 1 q_stride, 2 total features, 3 run-time compiled kernels the pipeline holds
+ * (fr_pipeline_prepare). */
 fr_pipeline_t *fr_pipeline_create(fr_plan_t *plan, int32_t n_sieves, const int32_t *kinds,
                                   const int32_t *incs, const int32_t *C1, const int32_t *Q1,
                                   const int64_t *cuts, int64_t T);
@@ -292,7 +293,12 @@ int fr_pipeline_set_preparation(fr_pipeline_t *pipeline, int32_t D, int32_t inc_
                                 int32_t as_new, int32_t standardize, double std_eps);
 /* fr_plan_prepare for the pipeline's plan and series length (after
  * fr_pipeline_set_quantiles): fr_pipeline_run for batches of N series then only
- * enqueues work (two memsets, the exp-table kernel, the walk, the MPI finalize). */
+ * enqueues work (the exp-table kernel, the walk, the MPI finalize).  It also compiles the
+ * pipeline's OWN walk kernel - the fused walk with the sieves' kinds, differencing orders
+ * and cuts as immediates (hipRTC, one code object per sieve list and kernel instantiation,
+ * cached on disk; ~2 s the first time on a machine, FRUITS_HIP_JIT=0: not) - which later
+ * runs on this device launch instead of the generic instance; results are identical.  No
+ * hipRTC, per-series cuts or rows with different op lists: the generic instance stays. */
 int fr_pipeline_prepare(fr_pipeline_t *pipeline, int64_t N, int32_t groups);
 /* Per-series segment boundaries for the sieves created with FR_SIEVE_SERIES_CUTS: device
  * table (N, slots) int32, row n = the boundaries of series n (values in [0, T]; the slots of
