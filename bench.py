@@ -271,11 +271,13 @@ def sweep(torch, fr, nat, dev, copy_GBs, budget_s=25.0):
     if time.perf_counter() - t_start <= budget_s + 5.0:
         c = cell(fr.words.of_weight(4, dim=2), N_SERIES, N_STEPS_T, True)
         if c is not None:
-            c["path"] = "run-time compiled static program if the scheduler accepts the plan, else interpreter"
+            c["path"] = "lean materialising walk (115 nodes: no static program; DESIGN.md 4.1c)"
             cells.append(c)
     return {"cells": cells, "on_box_copy_GBs": copy_GBs,
             "note": "static programs cover T in (512, 1024]; other lengths run the interpreter "
-                    "(or the wave-per-series kernels for T <= 384) on both lines"}
+                    "(or the wave-per-series kernels for T <= 384) on both lines; 'interpreter' = "
+                    "no static program: the record interpreter, and from two resident rounds of "
+                    "workgroups on the lean materialising walk (DESIGN.md 4.1c)"}
 
 
 def extras(torch, fr, nat, dev, quick=False):

@@ -134,6 +134,18 @@ def require_device():
     return t.device("cuda", t.cuda.current_device())
 
 
+_PREPARE_POOL = None
+
+
+def _prepare_pool():
+    """One helper thread for compilations nobody should wait for."""
+    global _PREPARE_POOL
+    if _PREPARE_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _PREPARE_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="fruits-prepare")
+    return _PREPARE_POOL
+
+
 def stream_ptr() -> C.c_void_p:
     return C.c_void_p(torch().cuda.current_stream().cuda_stream)
 
@@ -467,6 +479,20 @@ class Pipeline:
         kernel - the fused walk with its sieves as compile-time constants (hipRTC, cached on disk;
         FRUITS_HIP_JIT=0: not)."""
         check(lib().fr_pipeline_prepare(self._h, int(N), int(groups)), "fr_pipeline_prepare")
+
+    def prepare_in_background(self, N: int, groups: int = 0):
+        """``prepare`` on a helper thread: the caller goes on with the generic kernel and a later
+        ``run`` picks the pipeline's own kernel up once it is compiled and loaded (the library
+        guards the pipeline's compiled kernels with a lock).  Returns the future; a failure to
+        compile is not an error - the generic kernel stays - anything else is re-raised by
+        ``future.result()``."""
+        device = torch().cuda.current_device()
+
+        def work():
+            torch().cuda.set_device(device)      # (the current device is per thread)
+            self.prepare(N, groups)              # (self: the pipeline outlives the compilation)
+        self._pending = _prepare_pool().submit(work)
+        return self._pending
 
     def jit_loaded(self) -> int:
         """Run-time compiled kernels this pipeline holds."""

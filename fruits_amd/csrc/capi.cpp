@@ -6,6 +6,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <set>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -719,10 +721,16 @@ struct fr_pipeline {
   // differencing order / shape / cuts, the same for every output row, as immediates; compiled by
   // fr_pipeline_prepare for the kernel instantiation the plan and T select, dropped when the
   // thresholds (and with them the ops) are set again
+  // (fr_pipeline_prepare may run on another thread than fr_pipeline_run - a caller that does
+  // not want to wait for the compiler: jit_mu guards this block, jit_gen says whether the ops a
+  // compilation started from are still the pipeline's)
+  std::mutex jit_mu;
+  uint64_t jit_gen = 0;
   fr::FusedOps jit_ops;
   bool jit_uniform = false;        // every row's ops agree in what becomes an immediate
   std::map<uint32_t, fr::JitProgram> jit;
   std::map<uint32_t, std::string> jit_failed;
+  std::set<uint32_t> jit_pending;  // being compiled right now
 };
 
 
@@ -763,10 +771,26 @@ fr::FusedKey fused_key_for(const fr::Plan &p, int64_t T, bool total_inc) {
 // immediates, once per instantiation; a failure leaves the pipeline on the generic kernel.
 void ensure_fused_jit(fr_pipeline &pl, const fr::FusedKey &key) {
   const uint32_t id = key.packed();
-  if (!pl.jit_uniform || pl.jit.count(id) || pl.jit_failed.count(id)) return;
+  fr::FusedOps ops;
+  uint64_t gen;
+  {
+    std::lock_guard<std::mutex> lock(pl.jit_mu);
+    if (!pl.jit_uniform || pl.jit.count(id) || pl.jit_failed.count(id) || pl.jit_pending.count(id))
+      return;
+    pl.jit_pending.insert(id);
+    ops = pl.jit_ops;
+    gen = pl.jit_gen;
+  }
   fr::JitProgram prog;
   std::string err;
-  if (fr::jit_fused(pl.jit_ops, key, prog, err))
+  const bool ok = fr::jit_fused(ops, key, prog, err);   // (seconds: nobody waits on a lock for it)
+  std::lock_guard<std::mutex> lock(pl.jit_mu);
+  pl.jit_pending.erase(id);
+  if (gen != pl.jit_gen) {   // the thresholds were set again meanwhile: not this pipeline's kernel
+    if (ok) fr::jit_unload(prog);
+    return;
+  }
+  if (ok)
     pl.jit[id] = prog;
   else
     pl.jit_failed[id] = err;
@@ -1083,16 +1107,21 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   // static programs of several groups run one short-lived workgroup per unit: the hardware
   // dispatcher balances them and keeps the write front compact
   if (static_prog) a.persistent = 0;
-  if (fu && fu->pl && !packed && !fu->pl->jit.empty()) {
+  if (fu && fu->pl && !packed) {
     // the pipeline's run-time compiled kernel for this instantiation (fr_pipeline_prepare)
     const fr::FusedKey key = fused_key_for(p, T, fu->total_inc);
-    auto it = fu->pl->jit.find(key.packed());
-    if (it != fu->pl->jit.end() && it->second.device == fr::current_device()) {
+    fr::JitProgram own{};
+    {
+      std::lock_guard<std::mutex> lock(fu->pl->jit_mu);
+      auto it = fu->pl->jit.find(key.packed());
+      if (it != fu->pl->jit.end()) own = it->second;
+    }
+    if (own.fn != nullptr && own.device == fr::current_device()) {
       const int64_t chunk = fr::walk_chunk_elems(T);
       a.nchunks = (int32_t)((T + chunk - 1) / chunk);
       const size_t lds = ((size_t)a.R * chunk + 16 + 8 + (a.nchunks > 1 ? a.carry_slots : 0)) * 8 +
                          fr::feat_window_bytes(a.feat_window, a.has_mpi != 0, false);
-      hipError_t je = fr::jit_launch_fused(it->second, a, lds, st);
+      hipError_t je = fr::jit_launch_fused(own, a, lds, st);
       if (je != hipSuccess) return hip_fail(je, "fused walk (run-time compiled) launch");
       return FR_OK;
     }
@@ -1206,7 +1235,11 @@ int64_t fr_pipeline_info(const fr_pipeline_t *pl, int32_t what) {
     case 0: return pl->per_sum;
     case 1: return pl->q_stride;
     case 2: return (int64_t)pl->per_sum * pl->plan->p->K;
-    case 3: return (int64_t)pl->jit.size();      // run-time compiled kernels loaded
+    case 3: {                                    // run-time compiled kernels loaded
+      fr_pipeline *m = const_cast<fr_pipeline *>(pl);
+      std::lock_guard<std::mutex> lock(m->jit_mu);
+      return (int64_t)m->jit.size();
+    }
     default: return fail(FR_E_ARG, "fr_pipeline_info: unknown selector");
   }
 }
@@ -1305,6 +1338,8 @@ int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
   // What a run-time compiled kernel takes as immediates: per op kind | differencing order | shape
   // and the cuts - the same for every output row (the shape only if every row's thresholds agree
   // on it: an infinite threshold in one row alone keeps the generic band).
+  std::lock_guard<std::mutex> jit_lock(pl->jit_mu);
+  ++pl->jit_gen;
   for (auto &kv : pl->jit) fr::jit_unload(kv.second);
   pl->jit.clear();
   pl->jit_failed.clear();
@@ -1397,10 +1432,7 @@ int fr_pipeline_prepare(fr_pipeline_t *pl, int64_t N, int32_t groups) {
       if (sv.kind != FR_SIEVE_END && sv.inc >= 1) total_inc = true;
     const LaunchShape shape = launch_shape(p, N, pl->T, groups);
     const bool packed = shape.packed && !(total_inc && p.weighting == FR_W_TOTAL);
-    if (!packed && shape.fits) {
-      std::lock_guard<std::mutex> lock(p.mu);
-      ensure_fused_jit(*pl, fused_key_for(p, pl->T, total_inc));
-    }
+    if (!packed && shape.fits) ensure_fused_jit(*pl, fused_key_for(p, pl->T, total_inc));
   }
   return FR_OK;
 }

@@ -296,15 +296,17 @@ class FruitSlice:
             if not self._stage[stage]:
                 raise RuntimeError(f"No {what} given")
 
-    def _select_fit_sample(self, X: np.ndarray) -> np.ndarray:
+    def _select_fit_indices(self, X: np.ndarray) -> np.ndarray:
         # same draws from numpy's global generator as the reference
         # (fruits/fruit.py:430-438) so a seeded run picks the same series
         if isinstance(self.fit_sample_size, int) and self.fit_sample_size == 1:
             ind = np.random.randint(0, X.shape[0])
-            return X[ind:ind + 1, :, :]
+            return np.arange(ind, ind + 1)
         s = max(int(self.fit_sample_size * X.shape[0]), 1)
-        indices = np.random.choice(X.shape[0], size=s, replace=False)
-        return X[indices, :, :]
+        return np.random.choice(X.shape[0], size=s, replace=False)
+
+    def _select_fit_sample(self, X: np.ndarray) -> np.ndarray:
+        return X[self._select_fit_indices(X), :, :]
 
     # ---- device pipeline --------------------------------------------------------
     def _prepare_device(self, Xd, cache, callbacks=(), fit_on=None):
@@ -501,18 +503,22 @@ class FruitSlice:
 
     @staticmethod
     def _auto_prepare(pipe, N: int, T: int) -> None:
-        """A fused launch over a very large batch prepares its pipeline once per batch size: the
-        pipeline's own kernel is compiled at run time (hipRTC) with the sieves as immediates, a
-        quarter faster than the generic instance.  The compilation takes ~2 s the first time on a
-        machine (then it comes from the disk cache), so only launches of tens of milliseconds
-        ask for it by themselves - 8 GiB of iterated sums (FRUITS_AMD_AUTO_PREPARE=0: never,
-        =all: every fused launch); ``pipeline.prepare(N)`` is the explicit way."""
+        """A fused launch over a large batch asks for its pipeline's own kernel - the fused walk
+        compiled at run time (hipRTC) with the sieves as immediates, a quarter faster than the
+        generic instance - WITHOUT waiting for it: the compilation (1-2 s the first time on a
+        machine, then from the disk cache) runs on a helper thread, this launch and any other
+        before it is done take the generic kernel, later ones the compiled one (same results).
+        From 256 MiB of iterated sums on; FRUITS_AMD_AUTO_PREPARE=0: never, =all: every fused
+        launch, and waited for; ``pipeline.prepare(N)`` is the explicit, synchronous way."""
         mode = os.environ.get("FRUITS_AMD_AUTO_PREPARE", "1")
         if mode == "0" or getattr(pipe, "_prepared_for", None) == N:
             return
-        if mode != "all" and 8 * N * pipe.plan.rows * T < (8 << 30):
+        if mode == "all":
+            pipe.prepare(N)
+        elif 8 * N * pipe.plan.rows * T >= (256 << 20):
+            pipe.prepare_in_background(N)
+        else:
             return
-        pipe.prepare(N)
         pipe._prepared_for = N
 
     def _arm_series_cuts(self, pipe, N: int, T: int, cache) -> None:
@@ -579,8 +585,20 @@ class FruitSlice:
         X = _check_batch(X)
         if cache is None:
             cache = SharedSeedCache(X)
-        sample = self._select_fit_sample(X)
-        Sd = self._prepare_device(nat.to_device(sample), cache, fit_on=sample)
+        # the fit sample: rows of the input, gathered ON THE DEVICE from the cache's one upload of
+        # X when the cache holds this batch (every slice of a fruit draws its own sample: a host
+        # gather + upload per slice otherwise); the host copy only for a preparateur whose fit
+        # looks at the data
+        indices = self._select_fit_indices(X)
+        needs_host = any(prep._fit_needs_data() for prep in self._preparateurs)
+        whole = cache._input_dev is not None or 2 * len(indices) >= X.shape[0]   # (else: upload the sample alone)
+        if cache._input is X and not needs_host and whole:
+            sample = X[indices[:1], :, :]            # (what a data-blind Seed.fit is handed)
+            Sd0 = cache.input_device(X)[nat.to_device(indices, dtype=np.int64)]
+        else:
+            sample = X[indices, :, :]
+            Sd0 = nat.to_device(sample)
+        Sd = self._prepare_device(Sd0, cache, fit_on=sample)
         self._attach(cache)
         for iss in self._iss:
             if iss.requires_fitting:

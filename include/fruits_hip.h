@@ -298,7 +298,10 @@ int fr_pipeline_set_preparation(fr_pipeline_t *pipeline, int32_t D, int32_t inc_
  * and cuts as immediates (hipRTC, one code object per sieve list and kernel instantiation,
  * cached on disk; ~2 s the first time on a machine, FRUITS_HIP_JIT=0: not) - which later
  * runs on this device launch instead of the generic instance; results are identical.  No
- * hipRTC, per-series cuts or rows with different op lists: the generic instance stays. */
+ * hipRTC, per-series cuts or rows with different op lists: the generic instance stays.
+ * May be called from another thread than the one that runs the pipeline (a caller that does
+ * not want to wait for the compiler): fr_pipeline_run takes the compiled kernel once it is
+ * there. */
 int fr_pipeline_prepare(fr_pipeline_t *pipeline, int64_t N, int32_t groups);
 /* Per-series segment boundaries for the sieves created with FR_SIEVE_SERIES_CUTS: device
  * table (N, slots) int32, row n = the boundaries of series n (values in [0, T]; the slots of

@@ -1447,11 +1447,12 @@ def test_chained_iss_fuses_its_last_stage(fr, monkeypatch, T, semiring):
 
 
 @pytest.mark.parametrize("which", ["counts", "bands_means", "arctic_total", "multi_chunk", "cuts"])
-def test_fused_kernel_compiled_for_its_pipeline(fr, which):
+def test_fused_kernel_compiled_for_its_pipeline(fr, which, monkeypatch):
     """fr_pipeline_prepare compiles the pipeline's own kernel (hipRTC): the fused walk with the
     sieves' kind / differencing order / shape / cuts as immediates.  Same features as the generic
     kernel that decodes every op from its record - bit for bit (band means: their wave sums are
     added in LDS in arrival order)."""
+    monkeypatch.setenv("FRUITS_AMD_AUTO_PREPARE", "0")     # (the generic kernel first, then the own one)
     T = {"multi_chunk": 1500}.get(which, 700)
     rng = np.random.default_rng(len(which))
     X = rng.standard_normal((40, 2, T)).cumsum(axis=2) / 5.0
@@ -1487,6 +1488,37 @@ def test_fused_kernel_compiled_for_its_pipeline(fr, which):
     np.testing.assert_allclose(own, generic, rtol=1e-12, atol=1e-300)
     fruit.fit(X)                                   # new thresholds: the compiled kernel is dropped
     assert slc._fused(T).jit_loaded() == 0
+
+
+def test_own_kernel_compiled_in_the_background(fr, tmp_path, monkeypatch):
+    """Fruit.transform asks for a large pipeline's own kernel without waiting for the compiler:
+    launches before the kernel is loaded take the generic instance, later ones the compiled one -
+    all with the same features."""
+    monkeypatch.setenv("FRUITS_HIP_JIT_CACHE", str(tmp_path / "jit"))   # (a cold cache: a real compilation)
+    monkeypatch.setenv("FRUITS_AMD_AUTO_PREPARE", "1")
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((1024, 2, 1024)).cumsum(axis=2) / 5.0
+    fruit = fr.Fruit("background")
+    fruit.add(fr.preparation.INC)
+    fruit.add(fr.ISS(fr.words.of_weight(4, dim=2), mode=fr.ISSMode.EXTENDED,
+                     weighting=fr.iss.weighting.Indices()))
+    fruit.add(fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END)
+    fruit.get_slice().fit_sample_size = 0.1
+    np.random.seed(3)
+    fruit.fit(X)
+    first = fruit.transform(X)                       # 920 MiB of iterated sums: asks, does not wait
+    pipe = fruit.get_slice()._fused(1024)
+    assert getattr(pipe, "_pending", None) is not None
+    during = [fruit.transform(X) for _ in range(3)]
+    pipe._pending.result(timeout=120)
+    loaded = pipe.jit_loaded()
+    after = fruit.transform(X)
+    for other in during + [after]:
+        np.testing.assert_array_equal(other, first)
+    if loaded == 0:
+        pytest.skip("hipRTC is not installed")
+    fruit.fit(X)                                     # a refit drops the kernel with the thresholds
+    assert fruit.get_slice()._fused(1024).jit_loaded() == 0
 
 
 def test_fused_pipeline_is_cached_per_length(fr):
