@@ -494,9 +494,10 @@ class Pipeline:
         self._pending = _prepare_pool().submit(work)
         return self._pending
 
-    def jit_loaded(self) -> int:
-        """Run-time compiled kernels this pipeline holds."""
-        return int(lib().fr_pipeline_info(self._h, 3))
+    def jit_loaded(self, static_only: bool = False) -> int:
+        """Run-time compiled kernels this pipeline holds (``static_only``: those with the plan
+        as straight-line code)."""
+        return int(lib().fr_pipeline_info(self._h, 4 if static_only else 3))
 
     def run(self, Xd, lookup_d, feats=None, groups: int = 0, work=None):
         t = torch()

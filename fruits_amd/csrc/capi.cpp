@@ -731,6 +731,10 @@ struct fr_pipeline {
   std::map<uint32_t, fr::JitProgram> jit;
   std::map<uint32_t, std::string> jit_failed;
   std::set<uint32_t> jit_pending;  // being compiled right now
+  // the same with the PLAN as an immediate too (small plans: walk_fused.h, fwalk_static), by
+  // instantiation and groups per series: id | groups << 32
+  std::map<uint64_t, fr::JitProgram> jit_static;
+  std::set<uint64_t> jit_static_tried;
 };
 
 
@@ -794,6 +798,29 @@ void ensure_fused_jit(fr_pipeline &pl, const fr::FusedKey &key) {
     pl.jit[id] = prog;
   else
     pl.jit_failed[id] = err;
+}
+
+// The straight-line variant for the group program `gp` (a copy of its records goes into the source).
+void ensure_fused_static(fr_pipeline &pl, const fr::FusedKey &key, const fr::FusedPlan &plan) {
+  const uint64_t id = (uint64_t)key.packed() | (uint64_t)plan.groups() << 32;
+  fr::FusedOps ops;
+  uint64_t gen;
+  {
+    std::lock_guard<std::mutex> lock(pl.jit_mu);
+    if (!pl.jit_uniform || pl.jit_static.count(id) || pl.jit_static_tried.count(id)) return;
+    pl.jit_static_tried.insert(id);
+    ops = pl.jit_ops;
+    gen = pl.jit_gen;
+  }
+  fr::JitProgram prog;
+  std::string err;
+  const bool ok = fr::jit_fused(ops, key, prog, err, &plan);
+  std::lock_guard<std::mutex> lock(pl.jit_mu);
+  if (gen != pl.jit_gen) {
+    if (ok) fr::jit_unload(prog);
+    return;
+  }
+  if (ok) pl.jit_static[id] = prog;
 }
 
 // Shared body of fr_iss_run and fr_pipeline_run: validates, lays out the
@@ -1113,8 +1140,13 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     fr::JitProgram own{};
     {
       std::lock_guard<std::mutex> lock(fu->pl->jit_mu);
-      auto it = fu->pl->jit.find(key.packed());
-      if (it != fu->pl->jit.end()) own = it->second;
+      auto st_it = fu->pl->jit_static.find((uint64_t)key.packed() | (uint64_t)gp.groups << 32);
+      if (st_it != fu->pl->jit_static.end() && st_it->second.device == fr::current_device()) {
+        own = st_it->second;   // (the plan as straight-line code, for exactly this group program)
+      } else {
+        auto it = fu->pl->jit.find(key.packed());
+        if (it != fu->pl->jit.end()) own = it->second;
+      }
     }
     if (own.fn != nullptr && own.device == fr::current_device()) {
       const int64_t chunk = fr::walk_chunk_elems(T);
@@ -1226,6 +1258,7 @@ void fr_pipeline_destroy(fr_pipeline_t *pl) {
   if (pl->d_npi_pairs) (void)hipFree(pl->d_npi_pairs);
   if (pl->d_prep) (void)hipFree(pl->d_prep);
   for (auto &kv : pl->jit) fr::jit_unload(kv.second);
+  for (auto &kv : pl->jit_static) fr::jit_unload(kv.second);
   delete pl;
 }
 
@@ -1238,7 +1271,12 @@ int64_t fr_pipeline_info(const fr_pipeline_t *pl, int32_t what) {
     case 3: {                                    // run-time compiled kernels loaded
       fr_pipeline *m = const_cast<fr_pipeline *>(pl);
       std::lock_guard<std::mutex> lock(m->jit_mu);
-      return (int64_t)m->jit.size();
+      return (int64_t)(m->jit.size() + m->jit_static.size());
+    }
+    case 4: {                                    // ... of them with the plan as straight-line code
+      fr_pipeline *m = const_cast<fr_pipeline *>(pl);
+      std::lock_guard<std::mutex> lock(m->jit_mu);
+      return (int64_t)m->jit_static.size();
     }
     default: return fail(FR_E_ARG, "fr_pipeline_info: unknown selector");
   }
@@ -1341,9 +1379,13 @@ int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
   std::lock_guard<std::mutex> jit_lock(pl->jit_mu);
   ++pl->jit_gen;
   for (auto &kv : pl->jit) fr::jit_unload(kv.second);
+  for (auto &kv : pl->jit_static) fr::jit_unload(kv.second);
   pl->jit.clear();
+  pl->jit_static.clear();
+  pl->jit_static_tried.clear();
   pl->jit_failed.clear();
   pl->jit_ops = fr::FusedOps{};
+  pl->jit_ops.n_padded = pl->n_ops_padded;
   pl->jit_uniform = K > 0 && pl->n_ops_eff > 0 && pl->cut_slots_needed == 0;
   for (int i = 0; i < pl->n_ops_eff && pl->jit_uniform; ++i) {
     int32_t w0 = ops[i].kind_inc;
@@ -1432,7 +1474,26 @@ int fr_pipeline_prepare(fr_pipeline_t *pl, int64_t N, int32_t groups) {
       if (sv.kind != FR_SIEVE_END && sv.inc >= 1) total_inc = true;
     const LaunchShape shape = launch_shape(p, N, pl->T, groups);
     const bool packed = shape.packed && !(total_inc && p.weighting == FR_W_TOTAL);
-    if (!packed && shape.fits) ensure_fused_jit(*pl, fused_key_for(p, pl->T, total_inc));
+    if (!packed && shape.fits) {
+      const fr::FusedKey key = fused_key_for(p, pl->T, total_inc);
+      ensure_fused_jit(*pl, key);
+      // Small plans: the plan itself as straight-line code, for the group program a launch over
+      // N series will pick (another group count at run time simply takes the kernel above)
+      if ((int)p.nodes.size() <= fr::kFusedStaticMaxNodes && debug_knob("fused_static", 1) != 0) {
+        const int asked = groups > 0 ? groups : debug_knob("groups", 0);
+        fr::FusedPlan fp;
+        {
+          std::lock_guard<std::mutex> lock(p.mu);
+          const int G = asked > 0 ? shape.G
+                                  : choose_groups_walk(p, N, pl->T, query_resident(p, N, pl->T, true, true), true);
+          const fr::GroupedProgram &gp = fr::grouped(p, G);
+          fp.w.reserve(gp.recs.size() * 16);
+          for (const fr::NodeRec &r : gp.recs) fp.w.insert(fp.w.end(), r.w, r.w + 16);
+          fp.group_begin.assign(gp.group_begin.begin(), gp.group_begin.begin() + gp.groups);
+        }
+        ensure_fused_static(*pl, key, fp);
+      }
+    }
   }
   return FR_OK;
 }

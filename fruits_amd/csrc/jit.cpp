@@ -328,19 +328,19 @@ static const char *kFusedOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++1
                                       "-mllvm", "-structurizecfg-skip-uniform-regions"};
 constexpr int kNumFusedOptions = 6;
 
-static std::string fused_kernel_expr(const FusedKey &k) {
+static std::string fused_kernel_expr(const FusedKey &k, bool with_plan) {
   std::ostringstream o;
   o << "fr::iss_fused_kernel<fr::WalkCfg<" << k.E << ", 1, " << k.LV << ", " << k.MULTI << ", true, "
     << (k.W ? "true" : "false") << ", 4, 1, " << k.SEMI << ", false, " << (k.TI ? "true" : "false")
-    << ">, " << (k.TOTAL ? "true" : "false") << ", fr::JitOps>";
+    << ">, " << (k.TOTAL ? "true" : "false") << ", fr::JitOps" << (with_plan ? ", fr::JitPlan>" : ">");
   return o.str();
 }
 
-std::string jit_fused_source(const FusedOps &ops) {
+std::string jit_fused_source(const FusedOps &ops, const FusedPlan *plan) {
   std::ostringstream o;
   o << kJitDeviceSource << "\nnamespace fr {\nstruct JitOps {\n  static constexpr bool is_static = true;\n";
   const size_t n = ops.w0.size();
-  o << "  static constexpr int n = " << n << ";\n";
+  o << "  static constexpr int n = " << n << ", n_padded = " << ops.n_padded << ";\n";
   auto list = [&](const char *name, const std::vector<int32_t> &v) {
     o << "  static constexpr int32_t " << name << "[" << (n ? n : 1) << "] = {";
     for (size_t i = 0; i < n; ++i) o << (i ? ", " : "") << v[i];
@@ -350,16 +350,26 @@ std::string jit_fused_source(const FusedOps &ops) {
   list("w0", ops.w0);
   list("lo", ops.lo);
   list("hi", ops.hi);
-  o << "};\n}  // namespace fr\n";
+  o << "};\n";
+  if (plan != nullptr) {
+    o << "struct JitPlan {\n  static constexpr bool is_static = true;\n  static constexpr int groups = "
+      << plan->groups() << ";\n  static constexpr int32_t group_begin[" << plan->groups() << "] = {";
+    for (int g = 0; g < plan->groups(); ++g) o << (g ? ", " : "") << plan->group_begin[g];
+    o << "};\n  static constexpr int32_t w[" << plan->w.size() << "] = {";
+    for (size_t i = 0; i < plan->w.size(); ++i) o << (i ? (i % 16 ? ", " : ",\n    ") : "\n    ") << plan->w[i];
+    o << "};\n};\n";
+  }
+  o << "}  // namespace fr\n";
   return o.str();
 }
 
-bool jit_fused(const FusedOps &ops, const FusedKey &key, JitProgram &out, std::string &err) {
+bool jit_fused(const FusedOps &ops, const FusedKey &key, JitProgram &out, std::string &err,
+               const FusedPlan *plan) {
   if (ops.w0.empty() || ops.w0.size() > 64) {
     err = "no ops (or more than 64) per output row";
     return false;
   }
-  const std::string src = jit_fused_source(ops), expr = fused_kernel_expr(key);
+  const std::string src = jit_fused_source(ops, plan), expr = fused_kernel_expr(key, plan != nullptr);
   for (int attempt = 0; attempt < 2; ++attempt) {
     std::string code;
     bool from_cache = false;
@@ -372,6 +382,7 @@ bool jit_fused(const FusedOps &ops, const FusedKey &key, JitProgram &out, std::s
       out.module = mod;
       out.fn = fn;
       out.device = current_device();
+      out.groups = plan != nullptr ? plan->groups() : 0;
       return true;
     }
     if (!from_cache) return false;

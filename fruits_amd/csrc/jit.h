@@ -36,6 +36,14 @@ void jit_unload(JitProgram &p);
 // The fused walk of one pipeline with its sieves as compile-time constants (walk_fused.h, JitOps).
 struct FusedOps {        // per op of an output row, the same for every row
   std::vector<int32_t> w0, lo, hi;   // FeatOp::kind_inc (kind, differencing order, shape), cuts
+  int n_padded = 0;                  // ops per row of the device table (row stride / 32 bytes)
+};
+// The plan as an immediate too (walk_fused.h, fwalk_static): the records of the group program
+// the launch will use (16 words each, sentinels included) and the groups' first records.
+struct FusedPlan {
+  std::vector<int32_t> w;
+  std::vector<int32_t> group_begin;   // groups entries
+  int groups() const { return (int)group_begin.size(); }
 };
 struct FusedKey {        // the WalkCfg instantiation a (plan, series length, sieves) selects
   int E, LV, MULTI, W, SEMI, TI, TOTAL;
@@ -43,9 +51,11 @@ struct FusedKey {        // the WalkCfg instantiation a (plan, series length, si
     return (uint32_t)(E | LV << 4 | MULTI << 8 | W << 9 | SEMI << 10 | TI << 12 | TOTAL << 13);
   }
 };
-std::string jit_fused_source(const FusedOps &ops);
+std::string jit_fused_source(const FusedOps &ops, const FusedPlan *plan = nullptr);
 // Compiles (or takes from the disk cache) and loads on the current device; needs hipRTC.
-bool jit_fused(const FusedOps &ops, const FusedKey &key, JitProgram &out, std::string &err);
+// `plan`: the straight-line walk of exactly this group program (JitProgram::groups says which).
+bool jit_fused(const FusedOps &ops, const FusedKey &key, JitProgram &out, std::string &err,
+               const FusedPlan *plan = nullptr);
 hipError_t jit_launch_fused(const JitProgram &p, const IssArgs &a, size_t lds_bytes, hipStream_t st);
 hipError_t jit_launch(const JitProgram &p, const IssArgs &a, hipStream_t st);
 

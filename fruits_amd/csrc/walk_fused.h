@@ -694,6 +694,121 @@ __device__ __forceinline__ void fwalk(WalkCtx &cx, int node_begin, int &sink) {
   }
 }
 
+// ---------------------------------------------------------------- the plan as an immediate too
+// A run-time compiled kernel may also know the PLAN (jit.cpp: a pipeline of at most
+// kFusedStaticMaxNodes nodes): PG::w holds the records of the group program the launch will use,
+// 16 words per record like NodeRec, PG::group_begin the groups' first records.  The walk is then
+// straight-line code - a node's level, flags, factor rows, output rows, carry slot and op offsets
+// are immediates, the register frames are indexed directly, nothing of a record is loaded or
+// decoded - and what is left per node is the arithmetic, the thresholds of its ops and the feature
+// window's bookkeeping.  Same sums in the same order as fwalk (same functions).
+struct NoProg {
+  static constexpr bool is_static = false;
+};
+template <class PG, int PC>
+struct SRec {
+  static constexpr int w(int i) { return PG::w[PC * 16 + i]; }
+  static constexpr int level = PG::w[PC * 16] & 0xff, flags = PG::w[PC * 16] >> 8;
+  static constexpr int nf = PG::w[PC * 16 + 1] & 0xffff;
+  static constexpr int z_mul = ((PG::w[PC * 16 + 1] >> 16) & 0xff) - 1;
+  static constexpr int emit_mul = ((PG::w[PC * 16 + 1] >> 24) & 0xff) - 1;
+  static constexpr int ne = PG::w[PC * 16 + 6];
+};
+// PC: the record; GB: the first record of its group (carry slots count from there)
+template <class C, bool TOTAL, class OPS, class PG, int PC, int GB>
+__device__ __forceinline__ void fwalk_static(WalkCtx &cx, const Hot &a, double (&f)[C::MAXLV][C::EP]) {
+  using R = SRec<PG, PC>;
+  constexpr int EP = C::EP;
+  if constexpr (R::level != kRecSentinelLevel) {
+    static_assert(R::level < C::MAXLV, "a record deeper than the kernel's register frames");
+    constexpr int slot = kCarrySlots * (PC - GB);
+    constexpr uint32_t me = (uint32_t)PC * 64u;
+    constexpr uint32_t op_off = (uint32_t)R::w(7) * (uint32_t)(OPS::n_padded * 32);
+    feat_reserve<C, true>(cx, R::ne * OPS::n);
+    cx.slot = slot;
+    double s[EP];
+    if constexpr ((R::flags & F_SLOW) != 0) {
+      if constexpr ((R::flags & F_CHAIN) != 0) {
+#pragma unroll
+        for (int i = 0; i < EP; ++i) s[i] = f[R::level][i];
+      } else if constexpr (R::level > 0) {
+#pragma unroll
+        for (int i = 0; i < EP; ++i) s[i] = f[R::level - 1][i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < EP; ++i) s[i] = C::SEMI != 1 ? 1.0 : 0.0;
+      }
+      slow_factors<C>(cx, R::w(12), R::nf, s, s, false);
+    } else {
+      if constexpr ((R::flags & F_CHAIN) != 0) {
+        mul_row_from<C>(cx, R::w(2), f[R::level], s);
+      } else if constexpr (R::level > 0) {
+        mul_row_from<C>(cx, R::w(2), f[R::level - 1], s);
+      } else {
+        double ones[EP];
+#pragma unroll
+        for (int i = 0; i < EP; ++i) ones[i] = C::SEMI != 1 ? 1.0 : 0.0;
+        mul_row_from<C>(cx, R::w(2), ones, s);
+      }
+      if constexpr (R::nf > 1) mul_rowp<C>(cx, R::w(3), s);
+      if constexpr (R::nf > 2) mul_rowp<C>(cx, R::w(4), s);
+      if constexpr (R::nf > 3) mul_rowp<C>(cx, R::w(5), s);
+    }
+    if constexpr ((R::flags & F_NEED1) != 0) {
+      double c[EP], x[EP];
+      fscan<C>(cx, s, c, x, slot);
+      if constexpr ((R::flags & (F_CHILDREN | F_NEED2)) == F_CHILDREN) {
+#pragma unroll
+        for (int i = 0; i < EP; ++i) f[R::level][i] = C::SEMI == 0 ? x[i] : c[i];
+      }
+      if constexpr ((R::flags & F_EMIT) != 0) {
+        if constexpr (C::WEIGHTED && TOTAL) {
+          mul_rowp<C>(cx, C::SEMI != 1 ? R::emit_mul : fac_arctic(R::emit_mul, -1), c);
+          if constexpr (C::TOTALINC) {
+            double xs[EP];
+            previous_weighted<C>(cx, R::emit_mul, x, xs);
+            fops_all<C, false, OPS>(cx, a, R::ne, op_off, me, c, xs, s);
+          } else {
+            fops_all<C, false, OPS>(cx, a, R::ne, op_off, me, c, x, s);
+          }
+        } else {
+          fops_all<C, true, OPS>(cx, a, R::ne, op_off, me, c, x, s);
+        }
+      }
+    }
+    if constexpr (C::WEIGHTED && !TOTAL && (R::flags & F_NEED2) != 0) {
+      double c2[EP], x2[EP];
+      mul_rowp<C>(cx, C::SEMI != 1 ? R::z_mul : fac_arctic(R::z_mul, 1), s);
+      fscan<C>(cx, s, c2, x2, slot + 1);
+#pragma unroll
+      for (int i = 0; i < EP; ++i) f[R::level][i] = C::SEMI == 0 ? x2[i] : c2[i];
+    }
+    fwalk_static<C, TOTAL, OPS, PG, PC + 1, GB>(cx, a, f);
+  }
+}
+// the group a unit walks is a run-time value: one straight-line walk per group
+template <class C, bool TOTAL, class OPS, class PG, int G>
+__device__ __forceinline__ void fwalk_static_group(WalkCtx &cx, int g0) {
+  if constexpr (G < PG::groups) {
+    if (g0 == G) {
+      Hot a;
+      const IssArgs &ka = *cx.a;
+      a.recs = reinterpret_cast<const NodeRec *>(uniform_ptr(ka.recs));
+      a.ops = reinterpret_cast<const FeatOp *>(uniform_ptr(ka.ops));
+      a.n_ops = OPS::n;
+      a.op_row_bytes = (uint32_t)(OPS::n_padded * 32);
+      double f[C::MAXLV][C::EP];
+#pragma unroll
+      for (int k = 0; k < C::MAXLV; ++k)
+#pragma unroll
+        for (int i = 0; i < C::EP; ++i) f[k][i] = 0.0;
+      fwalk_static<C, TOTAL, OPS, PG, PG::group_begin[G], PG::group_begin[G]>(cx, a, f);
+    } else {
+      fwalk_static_group<C, TOTAL, OPS, PG, G + 1>(cx, g0);
+    }
+  }
+}
+
 // Stages the rows of one time chunk of series n into LDS (coalesced 16-byte units, the loads of
 // kStageRows rows in flight before the first LDS write); with a fused preparation the rows are
 // formed from the RAW input on the way (INC / NEW(INC) / STD, see IssArgs::prep).
@@ -774,7 +889,7 @@ __device__ __forceinline__ void stage_chunk(const WalkCtx &cx, const IssArgs &a,
 // [carry_slots] (MULTI) | feature window (values, populations, columns)
 // (No waves-per-SIMD attribute: every instance fits 128 VGPRs - four waves - without one, and
 // with it the 8-level one-chunk instances spilled a few registers for nothing.)
-template <class C, bool TOTAL, class OPS = DynOps>
+template <class C, bool TOTAL, class OPS = DynOps, class PG = NoProg>
 __global__ __launch_bounds__(kWalkThreads) void iss_fused_kernel(const IssArgs a) {
   static_assert((C::MODE == 1 || C::MODE == 2) && C::TEAM == 4 && (C::P == 1 || C::MODE == 2) && C::MULTI != 2,
                 "fused (MODE 1) or lean materialising (MODE 2) configuration");
@@ -841,7 +956,12 @@ __global__ __launch_bounds__(kWalkThreads) void iss_fused_kernel(const IssArgs a
     } else {
       cx.fused_used = 0;  // same slots in every chunk
       cx.frow0 = as_const(a.group_row_begin)[g0];
-      fwalk<C, TOTAL, OPS>(cx, node_begin, sink);
+      if constexpr (PG::is_static) {
+        static_assert(OPS::is_static && C::MODE == 1, "a static plan comes with static ops");
+        fwalk_static_group<C, TOTAL, OPS, PG, 0>(cx, g0);
+      } else {
+        fwalk<C, TOTAL, OPS>(cx, node_begin, sink);
+      }
       // a unit whose features fit the window keeps them there over its time chunks; else every
       // chunk leaves its share (added onto the earlier chunks' in global memory)
       if (!a.feat_fits || chunk + 1 == a.nchunks) feat_flush<C, true>(cx, !a.feat_fits && chunk > 0);

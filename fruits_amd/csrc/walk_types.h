@@ -62,6 +62,10 @@ constexpr int kSchedPrefetch = 0xfd;   // entry kind: load the next unit's rows 
 constexpr int kStaticMaxRows = 4;      // staged rows held in registers while in flight
 constexpr int kStaticMaxFrames = 4;    // open prefixes
 constexpr int kStaticMaxNodes = 32;
+// fused pipelines: plans of at most this many nodes may be compiled with the plan as straight-line
+// code (walk_fused.h, fwalk_static; ~0.7 KB of code per node against a 64 KB instruction cache
+// that two CUs share - measured on the 115-node of_weight(4,2))
+constexpr int kFusedStaticMaxNodes = 128;
 
 constexpr int kWalkThreads = 256;
 

@@ -266,7 +266,7 @@ int fr_sieve(int32_t kind, const double *d_A, int64_t N, int64_t T, int64_t a_st
  * Returns FR_E_LIMIT from create when a sieve is outside the fused set (the caller
  * then uses fr_iss_run + fr_sieve).  fr_pipeline_info: 0 features per iterated sum,
  * 1 q_stride, 2 total features, 3 run-time compiled kernels the pipeline holds
- * (fr_pipeline_prepare). */
+ * (fr_pipeline_prepare), 4 those of them with the plan as straight-line code. */
 fr_pipeline_t *fr_pipeline_create(fr_plan_t *plan, int32_t n_sieves, const int32_t *kinds,
                                   const int32_t *incs, const int32_t *C1, const int32_t *Q1,
                                   const int64_t *cuts, int64_t T);
@@ -297,7 +297,9 @@ int fr_pipeline_set_preparation(fr_pipeline_t *pipeline, int32_t D, int32_t inc_
  * pipeline's OWN walk kernel - the fused walk with the sieves' kinds, differencing orders
  * and cuts as immediates (hipRTC, one code object per sieve list and kernel instantiation,
  * cached on disk; ~2 s the first time on a machine, FRUITS_HIP_JIT=0: not) - which later
- * runs on this device launch instead of the generic instance; results are identical.  No
+ * runs on this device launch instead of the generic instance; results are identical.  For
+ * a plan of at most 128 nodes a second kernel carries the plan itself as straight-line code
+ * (for the group count a batch of N series selects; ~15 s for 115 nodes, cached too).  No
  * hipRTC, per-series cuts or rows with different op lists: the generic instance stays.
  * May be called from another thread than the one that runs the pipeline (a caller that does
  * not want to wait for the compiler): fr_pipeline_run takes the compiled kernel once it is

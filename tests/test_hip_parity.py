@@ -1446,13 +1446,18 @@ def test_chained_iss_fuses_its_last_stage(fr, monkeypatch, T, semiring):
     compare_features(got, plain, labels, what=f"chained ISS {semiring} T={T} vs unfused")
 
 
+@pytest.mark.parametrize("plan_too", [False, True], ids=["sieves", "sieves+plan"])
 @pytest.mark.parametrize("which", ["counts", "bands_means", "arctic_total", "multi_chunk", "cuts"])
-def test_fused_kernel_compiled_for_its_pipeline(fr, which, monkeypatch):
+def test_fused_kernel_compiled_for_its_pipeline(fr, which, plan_too, monkeypatch):
     """fr_pipeline_prepare compiles the pipeline's own kernel (hipRTC): the fused walk with the
-    sieves' kind / differencing order / shape / cuts as immediates.  Same features as the generic
-    kernel that decodes every op from its record - bit for bit (band means: their wave sums are
-    added in LDS in arrival order)."""
+    sieves' kind / differencing order / shape / cuts as immediates - and, for a small plan, with the
+    plan itself as straight-line code (fwalk_static).  Same features as the generic kernel that
+    decodes every record and op - bit for bit (band means: their wave sums are added in LDS in
+    arrival order)."""
     monkeypatch.setenv("FRUITS_AMD_AUTO_PREPARE", "0")     # (the generic kernel first, then the own one)
+    if not plan_too:
+        monkeypatch.setenv("FRUITS_HIP_DEBUG", ",".join(
+            v for v in (os.environ.get("FRUITS_HIP_DEBUG", ""), "fused_static=0") if v))
     T = {"multi_chunk": 1500}.get(which, 700)
     rng = np.random.default_rng(len(which))
     X = rng.standard_normal((40, 2, T)).cumsum(axis=2) / 5.0
@@ -1481,6 +1486,7 @@ def test_fused_kernel_compiled_for_its_pipeline(fr, which, monkeypatch):
     pipe.prepare(X.shape[0])
     if pipe.jit_loaded() == 0:
         pytest.skip("hipRTC is not installed")
+    assert pipe.jit_loaded(static_only=True) == (1 if plan_too else 0)
     own = fruit.transform(X)
     labels = [fruit.label(i) for i in range(fruit.nfeatures())]
     exact = np.array(["MPI" not in lb for lb in labels])
