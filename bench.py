@@ -95,8 +95,15 @@ def cpu_baseline(words, seconds_budget: float = 12.0):
 
 # --------------------------------------------------------------------------- timing helpers
 def _event_time_us(torch, fn, reps=20):
+    # steady state: at least 20 ms of the launch itself first (a measurement that follows seconds
+    # of host work - a hipRTC compilation, a fit - otherwise starts on an idle chip's clocks:
+    # the 48-word launch read 172 us after a cold compilation and 152 us after a cached one)
     fn()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.02:
+        fn()
+        torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):
