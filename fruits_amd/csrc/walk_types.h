@@ -63,8 +63,10 @@ constexpr int kStaticMaxRows = 4;      // staged rows held in registers while in
 constexpr int kStaticMaxFrames = 4;    // open prefixes
 constexpr int kStaticMaxNodes = 32;
 // fused pipelines: plans of at most this many nodes may be compiled with the plan as straight-line
-// code (walk_fused.h, fwalk_static; ~0.7 KB of code per node against a 64 KB instruction cache
-// that two CUs share - measured on the 115-node of_weight(4,2))
+// code (walk_fused.h, fwalk_static).  The limit is the compiler's time, not the instruction cache:
+// one function of ~1.7 KB per node - 33 nodes 7 s, 115 nodes (of_weight(4,2), 200 KB, a quarter
+// faster than the record loop although two CUs share 64 KB of cache) 15 s, growing faster than
+// linearly.
 constexpr int kFusedStaticMaxNodes = 128;
 
 constexpr int kWalkThreads = 256;

@@ -8,7 +8,7 @@ for kv in ${KNOBS:-FRUITS_HIP_STATIC=0 FRUITS_HIP_DEBUG=persist=1 FRUITS_HIP_DEB
   echo "== $kv" | tee -a $O/knobs.log
   # (every fused launch through its pipeline's own kernel: the sieves as immediates; the plans
   # as straight-line code too would compile for minutes over the suite's hundreds of plans)
-  [ "$kv" = "FRUITS_AMD_AUTO_PREPARE=all" ] && export FRUITS_HIP_DEBUG=fused_static=0
-  env $kv FRUITS_HIP_JIT_CACHE=$JITC python -m pytest tests -q -m gpu -x -k "not jit and not packed and not short_series and not fused_preparation" > $O/pytest_$kv.log 2>&1
+  extra=""; [ "$kv" = "FRUITS_AMD_AUTO_PREPARE=all" ] && extra="FRUITS_HIP_DEBUG=fused_static=0"
+  env $kv $extra FRUITS_HIP_JIT_CACHE=$JITC python -m pytest tests -q -m gpu -x -k "not jit and not packed and not short_series and not fused_preparation" > $O/pytest_$kv.log 2>&1
   tail -1 $O/pytest_$kv.log | tee -a $O/knobs.log
 done
