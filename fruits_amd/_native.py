@@ -35,7 +35,7 @@ EXPORTS = [
     "fr_pipeline_create", "fr_pipeline_destroy", "fr_pipeline_info",
     "fr_pipeline_workspace_bytes", "fr_pipeline_run", "fr_pipeline_set_quantiles",
     "fr_select_ranks", "fr_coswiss_combine", "fr_plan_create_coswiss", "fr_nan_to_num",
-    "fr_plan_prepare", "fr_pipeline_prepare", "fr_plan_fits", "fr_release_scratch",
+    "fr_plan_prepare", "fr_pipeline_prepare", "fr_pipeline_compile_plan", "fr_plan_fits", "fr_release_scratch",
     "fr_pipeline_set_preparation", "fr_pipeline_set_series_cuts", "fr_arctic_argmax", "fr_coswiss_set_dropout",
     "fr_coswiss_set_input_stride", "fr_coswiss_ffn",
 ]
@@ -96,6 +96,7 @@ def lib():
     L.fr_plan_fits.argtypes = [C.c_void_p, C.c_int64]
     L.fr_plan_prepare.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32]
     L.fr_pipeline_prepare.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
+    L.fr_pipeline_compile_plan.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     L.fr_pipeline_set_series_cuts.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     L.fr_pipeline_set_preparation.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                               C.c_int32, C.c_double]
@@ -473,12 +474,20 @@ class Pipeline:
         self.raw_dims = int(D) if (inc_lag or standardize) else 0
         return self.raw_dims > 0
 
-    def prepare(self, N: int, groups: int = 0) -> None:
+    # plans up to this size are compiled as straight-line code by a prepare nobody waits for
+    # (a few seconds of compiler; the interpreter joins its helper threads at exit)
+    QUICK_PLAN_NODES = 48
+
+    def prepare(self, N: int, groups: int = 0, plan_too: bool = True) -> None:
         """fr_pipeline_prepare: uploads the plan's tables for batches of N series so
         that ``run`` only enqueues work (hipGraph capture), and compiles the pipeline's own
         kernel - the fused walk with its sieves as compile-time constants (hipRTC, cached on disk;
-        FRUITS_HIP_JIT=0: not)."""
+        FRUITS_HIP_JIT=0: not); ``plan_too``: for a plan of at most 128 nodes also the variant
+        with the plan itself as straight-line code (fr_pipeline_compile_plan: seconds to tens of
+        seconds the first time on a machine)."""
         check(lib().fr_pipeline_prepare(self._h, int(N), int(groups)), "fr_pipeline_prepare")
+        if plan_too and self.plan.nodes <= 128:
+            check(lib().fr_pipeline_compile_plan(self._h, int(N), int(groups)), "fr_pipeline_compile_plan")
 
     def prepare_in_background(self, N: int, groups: int = 0):
         """``prepare`` on a helper thread: the caller goes on with the generic kernel and a later
@@ -490,7 +499,8 @@ class Pipeline:
 
         def work():
             torch().cuda.set_device(device)      # (the current device is per thread)
-            self.prepare(N, groups)              # (self: the pipeline outlives the compilation)
+            # (self: the pipeline outlives the compilation)
+            self.prepare(N, groups, plan_too=self.plan.nodes <= self.QUICK_PLAN_NODES)
         self._pending = _prepare_pool().submit(work)
         return self._pending
 

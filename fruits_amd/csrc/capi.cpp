@@ -443,7 +443,7 @@ extern "C" {
 
 const char *fr_last_error(void) { return g_err.c_str(); }
 
-int fr_version(void) { return 130; }
+int fr_version(void) { return 131; }
 
 int fr_device_count(void) {
   int n = 0;
@@ -1457,6 +1457,22 @@ int fr_pipeline_set_preparation(fr_pipeline_t *pl, int32_t D, int32_t inc_lag, i
   return FR_OK;
 }
 
+// The kernel instantiation a fused launch of this pipeline over N series takes, or false when
+// it has none of its own (CosWISS, wave-per-series kernels, letter sums, nothing fits).
+static bool fused_instance_of(fr_pipeline_t *pl, int64_t N, int32_t groups, fr::FusedKey &key,
+                              LaunchShape &shape) {
+  fr::Plan &p = *pl->plan->p;
+  if (p.cos || N <= 0 || env_int("FRUITS_HIP_JIT", 1) == 0 || p.letter_sum) return false;
+  bool total_inc = false;
+  for (const PipeSieve &sv : pl->sieves)
+    if (sv.kind != FR_SIEVE_END && sv.inc >= 1) total_inc = true;
+  shape = launch_shape(p, N, pl->T, groups);
+  const bool packed = shape.packed && !(total_inc && p.weighting == FR_W_TOTAL);
+  if (packed || !shape.fits) return false;
+  key = fused_key_for(p, pl->T, total_inc);
+  return true;
+}
+
 int fr_pipeline_prepare(fr_pipeline_t *pl, int64_t N, int32_t groups) {
   if (!pl || !pl->plan || !pl->plan->p || N < 0)
     return fail(FR_E_ARG, "fr_pipeline_prepare: bad argument");
@@ -1466,35 +1482,41 @@ int fr_pipeline_prepare(fr_pipeline_t *pl, int64_t N, int32_t groups) {
   int rc = prepare_plan(p, N, pl->T, groups, true, "fr_pipeline_prepare");
   if (rc != FR_OK) return rc;
   // The pipeline's own kernel: the fused walk with the sieves as compile-time constants (hipRTC,
-  // ~2 s once per pipeline shape, cached on disk); a failure is not the caller's - the generic
+  // 1-2 s once per pipeline shape, cached on disk); a failure is not the caller's - the generic
   // kernel runs the pipeline.  Not for the wave-per-series kernels (T <= 384) and CosWISS.
-  if (!p.cos && N > 0 && env_int("FRUITS_HIP_JIT", 1) != 0 && !p.letter_sum) {
-    bool total_inc = false;
-    for (const PipeSieve &sv : pl->sieves)
-      if (sv.kind != FR_SIEVE_END && sv.inc >= 1) total_inc = true;
-    const LaunchShape shape = launch_shape(p, N, pl->T, groups);
-    const bool packed = shape.packed && !(total_inc && p.weighting == FR_W_TOTAL);
-    if (!packed && shape.fits) {
-      const fr::FusedKey key = fused_key_for(p, pl->T, total_inc);
-      ensure_fused_jit(*pl, key);
-      // Small plans: the plan itself as straight-line code, for the group program a launch over
-      // N series will pick (another group count at run time simply takes the kernel above)
-      if ((int)p.nodes.size() <= fr::kFusedStaticMaxNodes && debug_knob("fused_static", 1) != 0) {
-        const int asked = groups > 0 ? groups : debug_knob("groups", 0);
-        fr::FusedPlan fp;
-        {
-          std::lock_guard<std::mutex> lock(p.mu);
-          const int G = asked > 0 ? shape.G
-                                  : choose_groups_walk(p, N, pl->T, query_resident(p, N, pl->T, true, true), true);
-          const fr::GroupedProgram &gp = fr::grouped(p, G);
-          fp.w.reserve(gp.recs.size() * 16);
-          for (const fr::NodeRec &r : gp.recs) fp.w.insert(fp.w.end(), r.w, r.w + 16);
-          fp.group_begin.assign(gp.group_begin.begin(), gp.group_begin.begin() + gp.groups);
-        }
-        ensure_fused_static(*pl, key, fp);
-      }
-    }
+  fr::FusedKey key;
+  LaunchShape shape;
+  if (fused_instance_of(pl, N, groups, key, shape)) ensure_fused_jit(*pl, key);
+  return FR_OK;
+}
+
+int fr_pipeline_compile_plan(fr_pipeline_t *pl, int64_t N, int32_t groups) {
+  if (!pl || !pl->plan || !pl->plan->p || N < 0)
+    return fail(FR_E_ARG, "fr_pipeline_compile_plan: bad argument");
+  if (!pl->have_quantiles)
+    return fail(FR_E_ARG, "fr_pipeline_compile_plan: call fr_pipeline_set_quantiles first");
+  fr::Plan &p = *pl->plan->p;
+  if ((int)p.nodes.size() > fr::kFusedStaticMaxNodes)
+    return fail(FR_E_LIMIT, "fr_pipeline_compile_plan: plans of more than " +
+                                std::to_string(fr::kFusedStaticMaxNodes) +
+                                " nodes keep the record loop (the compiler's time)");
+  fr::FusedKey key;
+  LaunchShape shape;
+  if (!fused_instance_of(pl, N, groups, key, shape) || debug_knob("fused_static", 1) == 0) return FR_OK;
+  // for the group program a launch over N series will pick (another group count at run time
+  // simply takes the kernel of fr_pipeline_prepare)
+  const int asked = groups > 0 ? groups : debug_knob("groups", 0);
+  fr::FusedPlan fp;
+  {
+    std::lock_guard<std::mutex> lock(p.mu);
+    const int G = asked > 0 ? shape.G
+                            : choose_groups_walk(p, N, pl->T, query_resident(p, N, pl->T, true, true), true);
+    const fr::GroupedProgram &gp = fr::grouped(p, G);
+    fp.w.reserve(gp.recs.size() * 16);
+    for (const fr::NodeRec &r : gp.recs) fp.w.insert(fp.w.end(), r.w, r.w + 16);
+    fp.group_begin.assign(gp.group_begin.begin(), gp.group_begin.begin() + gp.groups);
   }
+  ensure_fused_static(*pl, key, fp);
   return FR_OK;
 }
 

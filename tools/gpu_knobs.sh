@@ -6,9 +6,8 @@ O=gpurun_out/$1; mkdir -p $O
 JITC=$(mktemp -d)   # a private directory: a code object is executable input
 for kv in ${KNOBS:-FRUITS_HIP_STATIC=0 FRUITS_HIP_DEBUG=persist=1 FRUITS_HIP_DEBUG=persist=0 FRUITS_HIP_DEBUG=lean=0 FRUITS_HIP_JIT=2 FRUITS_AMD_FUSED_PREP=0 FRUITS_HIP_DEBUG=packed=0 FRUITS_AMD_AUTO_PREPARE=all}; do
   echo "== $kv" | tee -a $O/knobs.log
-  # (every fused launch through its pipeline's own kernel: the sieves as immediates; the plans
-  # as straight-line code too would compile for minutes over the suite's hundreds of plans)
-  extra=""; [ "$kv" = "FRUITS_AMD_AUTO_PREPARE=all" ] && extra="FRUITS_HIP_DEBUG=fused_static=0"
-  env $kv $extra FRUITS_HIP_JIT_CACHE=$JITC python -m pytest tests -q -m gpu -x -k "not jit and not packed and not short_series and not fused_preparation" > $O/pytest_$kv.log 2>&1
+  # (FRUITS_AMD_AUTO_PREPARE=all: every fused launch through its pipeline's own kernels - the
+  # sieves as immediates, small plans as straight-line code: ~4.5 min of suite + compiler)
+  env $kv FRUITS_HIP_JIT_CACHE=$JITC python -m pytest tests -q -m gpu -x -k "not jit and not packed and not short_series and not fused_preparation" > $O/pytest_$kv.log 2>&1
   tail -1 $O/pytest_$kv.log | tee -a $O/knobs.log
 done
