@@ -474,19 +474,20 @@ class Pipeline:
         self.raw_dims = int(D) if (inc_lag or standardize) else 0
         return self.raw_dims > 0
 
-    # plans up to this size are compiled as straight-line code by a prepare nobody waits for
-    # (a few seconds of compiler; the interpreter joins its helper threads at exit)
+    # plans up to this size are compiled as straight-line code by a prepare nobody waits for, and
+    # the node shapes of plans beyond 128 nodes (a few seconds of compiler either way; the
+    # interpreter joins its helper threads at exit) - between, ten seconds and more
     QUICK_PLAN_NODES = 48
 
     def prepare(self, N: int, groups: int = 0, plan_too: bool = True) -> None:
         """fr_pipeline_prepare: uploads the plan's tables for batches of N series so
         that ``run`` only enqueues work (hipGraph capture), and compiles the pipeline's own
         kernel - the fused walk with its sieves as compile-time constants (hipRTC, cached on disk;
-        FRUITS_HIP_JIT=0: not); ``plan_too``: for a plan of at most 128 nodes also the variant
-        with the plan itself as straight-line code (fr_pipeline_compile_plan: seconds to tens of
-        seconds the first time on a machine)."""
+        FRUITS_HIP_JIT=0: not); ``plan_too``: also the variant that knows the plan
+        (fr_pipeline_compile_plan: a plan of at most 128 nodes as straight-line code, of a larger
+        one the node shapes - seconds to tens of seconds the first time on a machine)."""
         check(lib().fr_pipeline_prepare(self._h, int(N), int(groups)), "fr_pipeline_prepare")
-        if plan_too and self.plan.nodes <= 128:
+        if plan_too:
             check(lib().fr_pipeline_compile_plan(self._h, int(N), int(groups)), "fr_pipeline_compile_plan")
 
     def prepare_in_background(self, N: int, groups: int = 0):
@@ -500,7 +501,8 @@ class Pipeline:
         def work():
             torch().cuda.set_device(device)      # (the current device is per thread)
             # (self: the pipeline outlives the compilation)
-            self.prepare(N, groups, plan_too=self.plan.nodes <= self.QUICK_PLAN_NODES)
+            nodes = self.plan.nodes
+            self.prepare(N, groups, plan_too=nodes <= self.QUICK_PLAN_NODES or nodes > 128)
         self._pending = _prepare_pool().submit(work)
         return self._pending
 

@@ -129,9 +129,11 @@ int ensure_device_program(fr::Plan &p, fr::GroupedProgram &gp, hipStream_t st, c
   const size_t o_alpha = off;       off = align_up(off + p.alphas.size() * 4, 64);
   const size_t o_srows = off;       off = align_up(off + gp.slot_rows.size() * 4, 64);
   const size_t o_grb = off;         off = align_up(off + gp.group_row_begin.size() * 4, 64);
+  const size_t o_shape = off;       off = align_up(off + gp.shape_ids.size() * 4, 64);
   std::vector<char> host(off + 64, 0);
   std::memcpy(host.data() + o_srows, gp.slot_rows.data(), gp.slot_rows.size() * 4);
   std::memcpy(host.data() + o_grb, gp.group_row_begin.data(), gp.group_row_begin.size() * 4);
+  std::memcpy(host.data() + o_shape, gp.shape_ids.data(), gp.shape_ids.size() * 4);
   std::memcpy(host.data() + o_nodes, gp.recs.data(), n_recs * sizeof(fr::NodeRec));
   std::memcpy(host.data() + o_gb, gp.group_begin.data(), gp.group_begin.size() * 4);
   std::memcpy(host.data() + o_fac, p.factors.data(), p.factors.size() * 4);
@@ -155,6 +157,7 @@ int ensure_device_program(fr::Plan &p, fr::GroupedProgram &gp, hipStream_t st, c
   gp.d_alphas = reinterpret_cast<const float *>(b + o_alpha);
   gp.d_slot_rows = reinterpret_cast<const int32_t *>(b + o_srows);
   gp.d_group_row_begin = reinterpret_cast<const int32_t *>(b + o_grb);
+  gp.d_shape_ids = reinterpret_cast<const int32_t *>(b + o_shape);
   return FR_OK;
 }
 
@@ -1009,6 +1012,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   a.emit_rows = gp.d_emit_rows;
   a.slot_rows = gp.d_slot_rows;
   a.group_row_begin = gp.d_group_row_begin;
+  a.shape_ids = gp.d_shape_ids;
   a.group_begin = gp.d_group_begin;
   a.row_src = gp.d_row_src;
   a.G = gp.groups;
@@ -1496,10 +1500,6 @@ int fr_pipeline_compile_plan(fr_pipeline_t *pl, int64_t N, int32_t groups) {
   if (!pl->have_quantiles)
     return fail(FR_E_ARG, "fr_pipeline_compile_plan: call fr_pipeline_set_quantiles first");
   fr::Plan &p = *pl->plan->p;
-  if ((int)p.nodes.size() > fr::kFusedStaticMaxNodes)
-    return fail(FR_E_LIMIT, "fr_pipeline_compile_plan: plans of more than " +
-                                std::to_string(fr::kFusedStaticMaxNodes) +
-                                " nodes keep the record loop (the compiler's time)");
   fr::FusedKey key;
   LaunchShape shape;
   if (!fused_instance_of(pl, N, groups, key, shape) || debug_knob("fused_static", 1) == 0) return FR_OK;
@@ -1512,9 +1512,18 @@ int fr_pipeline_compile_plan(fr_pipeline_t *pl, int64_t N, int32_t groups) {
     const int G = asked > 0 ? shape.G
                             : choose_groups_walk(p, N, pl->T, query_resident(p, N, pl->T, true, true), true);
     const fr::GroupedProgram &gp = fr::grouped(p, G);
-    fp.w.reserve(gp.recs.size() * 16);
-    for (const fr::NodeRec &r : gp.recs) fp.w.insert(fp.w.end(), r.w, r.w + 16);
-    fp.group_begin.assign(gp.group_begin.begin(), gp.group_begin.begin() + gp.groups);
+    if ((int)p.nodes.size() <= fr::kFusedStaticMaxNodes) {
+      // a small plan: the records themselves (straight-line code)
+      fp.w.reserve(gp.recs.size() * 16);
+      for (const fr::NodeRec &r : gp.recs) fp.w.insert(fp.w.end(), r.w, r.w + 16);
+      fp.group_begin.assign(gp.group_begin.begin(), gp.group_begin.begin() + gp.groups);
+    } else {
+      // a large one: its most frequent node shapes (the loop stays, the bodies are compiled
+      // per shape; the rest takes the generic body)
+      const size_t n = std::min<size_t>(gp.shapes.size(), fr::kFusedShapes);
+      fp.shapes.assign(gp.shapes.begin(), gp.shapes.begin() + n);
+      fp.n_groups = gp.groups;
+    }
   }
   ensure_fused_static(*pl, key, fp);
   return FR_OK;

@@ -43,7 +43,11 @@ struct FusedOps {        // per op of an output row, the same for every row
 struct FusedPlan {
   std::vector<int32_t> w;
   std::vector<int32_t> group_begin;   // groups entries
-  int groups() const { return (int)group_begin.size(); }
+  // ... or, for a large plan, only its most frequent node SHAPES (walk_fused.h, fwalk_shaped;
+  // GroupedProgram::shapes): `w` empty, `n_groups` = the group program they were counted on
+  std::vector<int32_t> shapes;
+  int n_groups = 0;
+  int groups() const { return shapes.empty() ? (int)group_begin.size() : n_groups; }
 };
 struct FusedKey {        // the WalkCfg instantiation a (plan, series length, sieves) selects
   int E, LV, MULTI, W, SEMI, TI, TOTAL;

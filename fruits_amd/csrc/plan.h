@@ -36,11 +36,16 @@ struct GroupedProgram {       // node order for one choice of G (groups per seri
   // output rows in the order a group's walk emits them (the fused walk's feature window
   // maps slot -> column through it when it leaves: walk_device.h, feat_flush) + G offsets
   std::vector<int32_t> slot_rows, group_row_begin;
+  // SHAPES of the nodes (walk_fused.h, fwalk_shaped): what a node's body branches on - level,
+  // flags, output rows - as one word, the distinct ones by falling
+  // frequency (`shapes`), and per record the index of its shape (`shape_ids`; the sentinel: -1)
+  std::vector<int32_t> shapes, shape_ids;
   // device copies
   void *d_blob = nullptr;
   const NodeRec *d_recs = nullptr;
   const int32_t *d_group_begin = nullptr;
   const int32_t *d_slot_rows = nullptr, *d_group_row_begin = nullptr;
+  const int32_t *d_shape_ids = nullptr;
   const int32_t *d_factors = nullptr;
   const int32_t *d_emit_rows = nullptr;
   const int32_t *d_row_src = nullptr;

@@ -587,27 +587,112 @@ __device__ __forceinline__ void frame_put(unsigned lv_bit, double (&f)[C::MAXLV]
   }
 }
 
-// Walks the records of one group (DFS order, sentinel at the end): per node the letters into
-// the prefix it continues (the frame of the level below; its own level's for an only child,
-// F_CHAIN), the scan, the feature ops, the hand-over to the children.
+// One node of the record loop: the letters into the prefix it continues (the frame of the level
+// below; its own level's for an only child, F_CHAIN), the scan, the feature ops (MODE 2: the
+// stores), the hand-over to the children.  `nd` comes in as the node's record and leaves as the
+// NEXT one (requested behind the first scan: a scalar-cache hit, in flight over the second).
+template <class C, bool TOTAL, class OPS>
+__device__ __forceinline__ void fnode(WalkCtx &cx, const Hot &a, double (&f)[C::MAXLV][C::EP],
+                                      Rec8 &nd, uint32_t me, int slot, int &sink) {
+  constexpr int EP = C::EP;
+  const uint32_t rec_off = me + 64u;
+  const int ne = nd.emit_count();
+  const uint32_t op_off = (uint32_t)nd.w[7] * a.op_row_bytes;
+  // the lines of the next record and of this node's ops, on their way to the scalar cache
+  // (a node without output rows names row 0: a harmless touch)
+  const int t_rec = touch(a.recs, rec_off);
+  int t_ops = 0;
+  if constexpr (C::MODE == 1) {
+    t_ops = touch(a.ops, op_off);
+    feat_reserve<C, true>(cx, ne * (OPS::is_static ? OPS::n : a.n_ops));
+  }
+  cx.slot = slot;
+  const int nf = nd.fac_count(), flags = nd.flags(), lv = nd.level();
+  const unsigned lv_bit = 1u << lv;
+  const unsigned rd_bit = (flags & F_CHAIN) ? (lv_bit << 1) : lv_bit;   // 2 << (level read)
+  double s[EP];
+  if (flags & F_SLOW) {
+    // a reciprocal factor, more than four or none: the factor table, one factor at a time
+    frame_get<C, C::MAXLV - 1>(rd_bit, f, s);
+    slow_factors<C>(cx, rec_field(a.recs, me, 12), nf, s, s, false);
+  } else {
+    frame_mul<C, C::MAXLV - 1>(cx, rd_bit, nd.w[2], f, s);
+    if (nf > 1) {
+      mul_rowp<C>(cx, nd.w[3], s);
+      if (nf > 2) mul_rowp<C>(cx, nd.w[4], s);
+      if (nf > 3) mul_rowp<C>(cx, nd.w[5], s);
+    }
+  }
+  const int w1 = nd.w[1];
+  if (flags & F_NEED1) {
+    double c[EP], x[EP];
+    fscan<C>(cx, s, c, x, slot);
+    // Reals: children start from the exclusive shift; Arctic / Bayesian: from the inclusive
+    // maximum (taken before the emitted values are rescaled)
+    if ((flags & (F_CHILDREN | F_NEED2)) == F_CHILDREN) {
+      if constexpr (C::SEMI == 0) frame_put<C, C::MAXLV - 1>(lv_bit, f, x);
+      else frame_put<C, C::MAXLV - 1>(lv_bit, f, c);
+    }
+    if (flags & F_EMIT) {
+      if constexpr (C::WEIGHTED && TOTAL) {
+        // total weighting: the sieves see c * exp(-g alpha_k) (Arctic: c - g alpha_k)
+        const int emit_mul = ((w1 >> 24) & 0xff) - 1;
+        mul_rowp<C>(cx, C::SEMI != 1 ? emit_mul : fac_arctic(emit_mul, -1), c);
+        if constexpr (C::MODE == 2) {
+          emit_lean<C>(cx, a, ne, nd.w[7], me, c);
+        } else if constexpr (C::TOTALINC) {
+          double xs[EP];
+          previous_weighted<C>(cx, emit_mul, x, xs);
+          fops_all<C, false, OPS>(cx, a, ne, op_off, me, c, xs, s);
+        } else {
+          fops_all<C, false, OPS>(cx, a, ne, op_off, me, c, x, s);
+        }
+      } else if constexpr (C::MODE == 2) {
+        emit_lean<C>(cx, a, ne, nd.w[7], me, c);
+      } else {
+        fops_all<C, true, OPS>(cx, a, ne, op_off, me, c, x, s);
+      }
+    }
+  }
+  sink += t_rec + t_ops;
+  nd = load_rec8(a.recs, rec_off);   // (a scalar-cache hit; in flight over the second scan)
+  if constexpr (C::WEIGHTED && !TOTAL) {
+    if (flags & F_NEED2) {
+      // non-total weighting: the children continue from the scan of s * exp(+g alpha_k)
+      const int z_mul = ((w1 >> 16) & 0xff) - 1;
+      double c2[EP], x2[EP];
+      mul_rowp<C>(cx, C::SEMI != 1 ? z_mul : fac_arctic(z_mul, 1), s);
+      fscan<C>(cx, s, c2, x2, slot + 1);
+      if constexpr (C::SEMI == 0) frame_put<C, C::MAXLV - 1>(lv_bit, f, x2);
+      else frame_put<C, C::MAXLV - 1>(lv_bit, f, c2);
+    }
+  }
+}
+
+// what the node loop reads of the kernel arguments (see Hot)
+template <class C>
+__device__ __forceinline__ Hot hot_args(const WalkCtx &cx) {
+  Hot a;
+  const IssArgs &ka = *cx.a;
+  // (through readfirstlane: scalars of their own, not pieces of one wide kernel-argument load
+  // that is spilled and restored as a whole)
+  a.recs = reinterpret_cast<const NodeRec *>(uniform_ptr(ka.recs));
+  a.ops = reinterpret_cast<const FeatOp *>(uniform_ptr(ka.ops));
+  a.n_ops = __builtin_amdgcn_readfirstlane(ka.n_ops);
+  a.op_row_bytes = __builtin_amdgcn_readfirstlane(ka.n_ops_padded * 32);
+  if constexpr (C::MODE == 2) {
+    a.out = static_cast<char *>(const_cast<void *>(uniform_ptr(cx.out_base)));
+    a.k_stride = __builtin_amdgcn_readfirstlane(ka.k_stride_bytes32);
+    a.fast_store = cx.full_chunk && ka.vec_ok != 0;
+  }
+  return a;
+}
+
+// Walks the records of one group (DFS order, sentinel at the end).
 template <class C, bool TOTAL, class OPS>
 __device__ __forceinline__ void fwalk(WalkCtx &cx, int node_begin, int &sink) {
   constexpr int EP = C::EP;
-  Hot a;
-  {
-    const IssArgs &ka = *cx.a;
-    // (through readfirstlane: scalars of their own, not pieces of one wide kernel-argument load
-    // that is spilled and restored as a whole)
-    a.recs = reinterpret_cast<const NodeRec *>(uniform_ptr(ka.recs));
-    a.ops = reinterpret_cast<const FeatOp *>(uniform_ptr(ka.ops));
-    a.n_ops = __builtin_amdgcn_readfirstlane(ka.n_ops);
-    a.op_row_bytes = __builtin_amdgcn_readfirstlane(ka.n_ops_padded * 32);
-    if constexpr (C::MODE == 2) {
-      a.out = static_cast<char *>(const_cast<void *>(uniform_ptr(cx.out_base)));
-      a.k_stride = __builtin_amdgcn_readfirstlane(ka.k_stride_bytes32);
-      a.fast_store = cx.full_chunk && ka.vec_ok != 0;
-    }
-  }
+  const Hot a = hot_args<C>(cx);
   double f[C::MAXLV][EP];
 #pragma unroll
   for (int k = 0; k < C::MAXLV; ++k)
@@ -617,79 +702,142 @@ __device__ __forceinline__ void fwalk(WalkCtx &cx, int node_begin, int &sink) {
   int slot = 0;   // carry slots of the node: three per record of the group
   Rec8 nd = load_rec8(a.recs, rec_off);
   while (nd.level() != kRecSentinelLevel) {
-    const uint32_t me = rec_off;
+    fnode<C, TOTAL, OPS>(cx, a, f, nd, rec_off, slot, sink);
     rec_off += 64u;
-    const int ne = nd.emit_count();
-    const uint32_t op_off = (uint32_t)nd.w[7] * a.op_row_bytes;
-    // the lines of the next record and of this node's ops, on their way to the scalar cache
-    // (a node without output rows names row 0: a harmless touch)
-    const int t_rec = touch(a.recs, rec_off);
-    int t_ops = 0;
-    if constexpr (C::MODE == 1) {
-      t_ops = touch(a.ops, op_off);
-      feat_reserve<C, true>(cx, ne * (OPS::is_static ? OPS::n : a.n_ops));
-    }
-    cx.slot = slot;
-    const int nf = nd.fac_count(), flags = nd.flags(), lv = nd.level();
-    const unsigned lv_bit = 1u << lv;
-    const unsigned rd_bit = (flags & F_CHAIN) ? (lv_bit << 1) : lv_bit;   // 2 << (level read)
-    double s[EP];
-    if (flags & F_SLOW) {
-      // a reciprocal factor or more than four: the factor table, one factor at a time
-      frame_get<C, C::MAXLV - 1>(rd_bit, f, s);
-      slow_factors<C>(cx, rec_field(a.recs, me, 12), nf, s, s, false);
+    slot += kCarrySlots;
+  }
+}
+
+// ---------------------------------------------------------------- node shapes as immediates
+// Between the record loop and a plan that is straight-line code (below): a run-time compiled
+// kernel of a LARGE plan knows the plan's node SHAPES - what the body of a node branches on:
+// level, flags, output rows (GroupedProgram::shapes, the most frequent first).  The loop stays a loop over records, but a node's shape index (one more dword per
+// node, IssArgs::shape_ids) selects a body compiled for that shape: frames indexed directly, no
+// level dispatch, no flag or count tests - the rows, weights and offsets still come from the
+// record.  Shapes beyond the SH::n compiled ones take the generic body.
+template <class SH, int I>
+struct SShape {
+  static constexpr int d = SH::desc[I];
+  static constexpr int level = d & 0xff, flags = (d >> 8) & 0xff;
+  static constexpr int ne = (d >> 20) & 0xf;   // output rows; 3: more than two (read from the record)
+};
+template <class C, bool TOTAL, class OPS, class SH, int I>
+__device__ __forceinline__ void fnode_shaped(WalkCtx &cx, const Hot &a, double (&f)[C::MAXLV][C::EP],
+                                             Rec8 &nd, uint32_t me, int slot, int &sink) {
+  using S = SShape<SH, I>;
+  constexpr int EP = C::EP;
+  static_assert(S::level < C::MAXLV, "a shape deeper than the kernel's register frames");
+  const uint32_t rec_off = me + 64u;
+  const int ne = S::ne < 3 ? S::ne : nd.emit_count();
+  const uint32_t op_off = (uint32_t)nd.w[7] * (uint32_t)(OPS::n_padded * 32);
+  const int t_rec = touch(a.recs, rec_off);
+  int t_ops = 0;
+  if constexpr ((S::flags & F_EMIT) != 0) {
+    t_ops = touch(a.ops, op_off);
+    feat_reserve<C, true>(cx, ne * OPS::n);
+  }
+  cx.slot = slot;
+  double s[EP];
+  if constexpr ((S::flags & F_SLOW) != 0) {
+    if constexpr ((S::flags & F_CHAIN) != 0) {
+#pragma unroll
+      for (int i = 0; i < EP; ++i) s[i] = f[S::level][i];
+    } else if constexpr (S::level > 0) {
+#pragma unroll
+      for (int i = 0; i < EP; ++i) s[i] = f[S::level - 1][i];
     } else {
-      frame_mul<C, C::MAXLV - 1>(cx, rd_bit, nd.w[2], f, s);
-      if (nf > 1) {
-        mul_rowp<C>(cx, nd.w[3], s);
-        if (nf > 2) mul_rowp<C>(cx, nd.w[4], s);
-        if (nf > 3) mul_rowp<C>(cx, nd.w[5], s);
-      }
+#pragma unroll
+      for (int i = 0; i < EP; ++i) s[i] = C::SEMI != 1 ? 1.0 : 0.0;
     }
-    const int w1 = nd.w[1];
-    if (flags & F_NEED1) {
-      double c[EP], x[EP];
-      fscan<C>(cx, s, c, x, slot);
-      // Reals: children start from the exclusive shift; Arctic / Bayesian: from the inclusive
-      // maximum (taken before the emitted values are rescaled)
-      if ((flags & (F_CHILDREN | F_NEED2)) == F_CHILDREN) {
-        if constexpr (C::SEMI == 0) frame_put<C, C::MAXLV - 1>(lv_bit, f, x);
-        else frame_put<C, C::MAXLV - 1>(lv_bit, f, c);
-      }
-      if (flags & F_EMIT) {
-        if constexpr (C::WEIGHTED && TOTAL) {
-          // total weighting: the sieves see c * exp(-g alpha_k) (Arctic: c - g alpha_k)
-          const int emit_mul = ((w1 >> 24) & 0xff) - 1;
-          mul_rowp<C>(cx, C::SEMI != 1 ? emit_mul : fac_arctic(emit_mul, -1), c);
-          if constexpr (C::MODE == 2) {
-            emit_lean<C>(cx, a, ne, nd.w[7], me, c);
-          } else if constexpr (C::TOTALINC) {
-            double xs[EP];
-            previous_weighted<C>(cx, emit_mul, x, xs);
-            fops_all<C, false, OPS>(cx, a, ne, op_off, me, c, xs, s);
-          } else {
-            fops_all<C, false, OPS>(cx, a, ne, op_off, me, c, x, s);
-          }
-        } else if constexpr (C::MODE == 2) {
-          emit_lean<C>(cx, a, ne, nd.w[7], me, c);
+    slow_factors<C>(cx, rec_field(a.recs, me, 12), nd.fac_count(), s, s, false);
+  } else {
+    if constexpr ((S::flags & F_CHAIN) != 0) {
+      mul_row_from<C>(cx, nd.w[2], f[S::level], s);
+    } else if constexpr (S::level > 0) {
+      mul_row_from<C>(cx, nd.w[2], f[S::level - 1], s);
+    } else {
+      double ones[EP];
+#pragma unroll
+      for (int i = 0; i < EP; ++i) ones[i] = C::SEMI != 1 ? 1.0 : 0.0;
+      mul_row_from<C>(cx, nd.w[2], ones, s);
+    }
+    const int nf = nd.fac_count();
+    if (nf > 1) {
+      mul_rowp<C>(cx, nd.w[3], s);
+      if (nf > 2) mul_rowp<C>(cx, nd.w[4], s);
+      if (nf > 3) mul_rowp<C>(cx, nd.w[5], s);
+    }
+  }
+  const int w1 = nd.w[1];
+  if constexpr ((S::flags & F_NEED1) != 0) {
+    double c[EP], x[EP];
+    fscan<C>(cx, s, c, x, slot);
+    if constexpr ((S::flags & (F_CHILDREN | F_NEED2)) == F_CHILDREN) {
+#pragma unroll
+      for (int i = 0; i < EP; ++i) f[S::level][i] = C::SEMI == 0 ? x[i] : c[i];
+    }
+    if constexpr ((S::flags & F_EMIT) != 0) {
+      if constexpr (C::WEIGHTED && TOTAL) {
+        const int emit_mul = ((w1 >> 24) & 0xff) - 1;
+        mul_rowp<C>(cx, C::SEMI != 1 ? emit_mul : fac_arctic(emit_mul, -1), c);
+        if constexpr (C::TOTALINC) {
+          double xs[EP];
+          previous_weighted<C>(cx, emit_mul, x, xs);
+          fops_all<C, false, OPS>(cx, a, ne, op_off, me, c, xs, s);
         } else {
-          fops_all<C, true, OPS>(cx, a, ne, op_off, me, c, x, s);
+          fops_all<C, false, OPS>(cx, a, ne, op_off, me, c, x, s);
         }
+      } else {
+        fops_all<C, true, OPS>(cx, a, ne, op_off, me, c, x, s);
       }
     }
-    sink += t_rec + t_ops;
-    nd = load_rec8(a.recs, rec_off);   // (a scalar-cache hit; in flight over the second scan)
-    if constexpr (C::WEIGHTED && !TOTAL) {
-      if (flags & F_NEED2) {
-        // non-total weighting: the children continue from the scan of s * exp(+g alpha_k)
-        const int z_mul = ((w1 >> 16) & 0xff) - 1;
-        double c2[EP], x2[EP];
-        mul_rowp<C>(cx, C::SEMI != 1 ? z_mul : fac_arctic(z_mul, 1), s);
-        fscan<C>(cx, s, c2, x2, slot + 1);
-        if constexpr (C::SEMI == 0) frame_put<C, C::MAXLV - 1>(lv_bit, f, x2);
-        else frame_put<C, C::MAXLV - 1>(lv_bit, f, c2);
-      }
+  }
+  sink += t_rec + t_ops;
+  nd = load_rec8(a.recs, rec_off);
+  if constexpr (C::WEIGHTED && !TOTAL && (S::flags & F_NEED2) != 0) {
+    const int z_mul = ((w1 >> 16) & 0xff) - 1;
+    double c2[EP], x2[EP];
+    mul_rowp<C>(cx, C::SEMI != 1 ? z_mul : fac_arctic(z_mul, 1), s);
+    fscan<C>(cx, s, c2, x2, slot + 1);
+#pragma unroll
+    for (int i = 0; i < EP; ++i) f[S::level][i] = C::SEMI == 0 ? x2[i] : c2[i];
+  }
+}
+// a chain of uniform tests, the most frequent shape first
+template <class C, bool TOTAL, class OPS, class SH, int I>
+__device__ __forceinline__ void fnode_by_shape(int shape, WalkCtx &cx, const Hot &a,
+                                               double (&f)[C::MAXLV][C::EP], Rec8 &nd, uint32_t me,
+                                               int slot, int &sink) {
+  if constexpr (I < SH::n) {
+    if (shape == I) {
+      fnode_shaped<C, TOTAL, OPS, SH, I>(cx, a, f, nd, me, slot, sink);
+      asm volatile("" ::: "memory");  // (keeps the bodies apart)
+    } else {
+      fnode_by_shape<C, TOTAL, OPS, SH, I + 1>(shape, cx, a, f, nd, me, slot, sink);
     }
+  } else {
+    fnode<C, TOTAL, OPS>(cx, a, f, nd, me, slot, sink);
+  }
+}
+template <class C, bool TOTAL, class OPS, class SH>
+__device__ __forceinline__ void fwalk_shaped(WalkCtx &cx, int node_begin, int &sink) {
+  constexpr int EP = C::EP;
+  const Hot a = hot_args<C>(cx);
+  const void *shape_ids = uniform_ptr(cx.a->shape_ids);
+  double f[C::MAXLV][EP];
+#pragma unroll
+  for (int k = 0; k < C::MAXLV; ++k)
+#pragma unroll
+    for (int i = 0; i < EP; ++i) f[k][i] = 0.0;
+  uint32_t rec_off = (uint32_t)node_begin * 64u;
+  int slot = 0;
+  Rec8 nd = load_rec8(a.recs, rec_off);
+  int shape = at_offset(shape_ids, rec_off >> 4)[0];
+  while (shape >= 0) {   // (the sentinel's shape index is -1)
+    const int next_shape = at_offset(shape_ids, (rec_off + 64u) >> 4)[0];   // (in flight over the node)
+    fnode_by_shape<C, TOTAL, OPS, SH, 0>(shape, cx, a, f, nd, rec_off, slot, sink);
+    shape = next_shape;
+    rec_off += 64u;
     slot += kCarrySlots;
   }
 }
@@ -703,7 +851,7 @@ __device__ __forceinline__ void fwalk(WalkCtx &cx, int node_begin, int &sink) {
 // decoded - and what is left per node is the arithmetic, the thresholds of its ops and the feature
 // window's bookkeeping.  Same sums in the same order as fwalk (same functions).
 struct NoProg {
-  static constexpr bool is_static = false;
+  static constexpr bool is_static = false, is_shaped = false;
 };
 template <class PG, int PC>
 struct SRec {
@@ -959,6 +1107,9 @@ __global__ __launch_bounds__(kWalkThreads) void iss_fused_kernel(const IssArgs a
       if constexpr (PG::is_static) {
         static_assert(OPS::is_static && C::MODE == 1, "a static plan comes with static ops");
         fwalk_static_group<C, TOTAL, OPS, PG, 0>(cx, g0);
+      } else if constexpr (PG::is_shaped) {
+        static_assert(OPS::is_static && C::MODE == 1, "node shapes come with static ops");
+        fwalk_shaped<C, TOTAL, OPS, PG>(cx, node_begin, sink);
       } else {
         fwalk<C, TOTAL, OPS>(cx, node_begin, sink);
       }

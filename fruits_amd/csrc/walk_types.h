@@ -68,6 +68,9 @@ constexpr int kStaticMaxNodes = 32;
 // faster than the record loop although two CUs share 64 KB of cache) 15 s, growing faster than
 // linearly.
 constexpr int kFusedStaticMaxNodes = 128;
+// larger plans: this many of their most frequent node shapes get a body of their own in the
+// pipeline's kernel (fwalk_shaped); the others take the generic body
+constexpr int kFusedShapes = 24;
 
 constexpr int kWalkThreads = 256;
 
@@ -102,6 +105,7 @@ struct IssArgs {
   const int32_t *emit_rows;
   const int32_t *slot_rows;        // fused walk: output rows in the order a group emits them,
   const int32_t *group_row_begin;  // and where a group's rows start in it (GroupedProgram)
+  const int32_t *shape_ids;        // per record: index of its shape (GroupedProgram::shapes; fwalk_shaped)
   const int32_t *group_begin;
   const int32_t *row_src;
   int64_t N, D, T;

@@ -298,18 +298,20 @@ int fr_pipeline_set_preparation(fr_pipeline_t *pipeline, int32_t D, int32_t inc_
  * and cuts as immediates (hipRTC, one code object per sieve list and kernel instantiation,
  * cached on disk; ~2 s the first time on a machine, FRUITS_HIP_JIT=0: not) - which later
  * runs on this device launch instead of the generic instance; results are identical
- * (fr_pipeline_compile_plan: the plan of a small pipeline as straight-line code too).  No
+ * (fr_pipeline_compile_plan: a second kernel that knows the plan too).  No
  * hipRTC, per-series cuts or rows with different op lists: the generic instance stays.
  * May be called from another thread than the one that runs the pipeline (a caller that does
  * not want to wait for the compiler): fr_pipeline_run takes the compiled kernel once it is
  * there. */
 int fr_pipeline_prepare(fr_pipeline_t *pipeline, int64_t N, int32_t groups);
-/* The second kernel of a SMALL plan (at most 128 nodes, else FR_E_LIMIT): the pipeline's own
- * kernel with the plan itself as straight-line code, for the group program a batch of N
- * series selects - nothing of a node is loaded or decoded at run time (BASELINE configs[2]:
- * 243 -> 177 us).  Apart from fr_pipeline_prepare because of what it costs: seconds to tens of
- * seconds of hipRTC per plan (115 nodes: ~15 s), cached on disk like the other.  Same results;
- * safe from another thread like fr_pipeline_prepare. */
+/* The second kernel of a pipeline: one that also knows the PLAN, for the group program a
+ * batch of N series selects.  A plan of at most 128 nodes becomes straight-line code - nothing
+ * of a node is loaded or decoded at run time (BASELINE configs[2]: 243 -> 177 us); of a larger
+ * one the kernel knows the node SHAPES (level, flags, output rows: a body per shape, the record
+ * loop stays; configs[3] / [4] on one GPU: 9.3 -> 8.7 ms, 17.7 -> 15.9 ms).  Apart from
+ * fr_pipeline_prepare because of what it costs: seconds to tens of seconds of hipRTC per plan
+ * (115 nodes as straight-line code: ~15 s), cached on disk like the other.  Same results; safe
+ * from another thread like fr_pipeline_prepare. */
 int fr_pipeline_compile_plan(fr_pipeline_t *pipeline, int64_t N, int32_t groups);
 /* Per-series segment boundaries for the sieves created with FR_SIEVE_SERIES_CUTS: device
  * table (N, slots) int32, row n = the boundaries of series n (values in [0, T]; the slots of

@@ -1447,29 +1447,34 @@ def test_chained_iss_fuses_its_last_stage(fr, monkeypatch, T, semiring):
 
 
 @pytest.mark.parametrize("plan_too", [False, True], ids=["sieves", "sieves+plan"])
-@pytest.mark.parametrize("which", ["counts", "bands_means", "arctic_total", "multi_chunk", "cuts"])
+@pytest.mark.parametrize("which", ["counts", "bands_means", "arctic_total", "multi_chunk", "cuts",
+                                   "large_plan", "large_plan_chunks"])
 def test_fused_kernel_compiled_for_its_pipeline(fr, which, plan_too, monkeypatch):
     """fr_pipeline_prepare compiles the pipeline's own kernel (hipRTC): the fused walk with the
-    sieves' kind / differencing order / shape / cuts as immediates - and, for a small plan, with the
-    plan itself as straight-line code (fwalk_static).  Same features as the generic kernel that
-    decodes every record and op - bit for bit (band means: their wave sums are added in LDS in
-    arrival order)."""
+    sieves' kind / differencing order / shape / cuts as immediates - and fr_pipeline_compile_plan
+    one that knows the plan: a small plan as straight-line code (fwalk_static), of a large one
+    (more than 128 nodes) the node shapes (fwalk_shaped).  Same features as the generic kernel
+    that decodes every record and op - bit for bit (band means: their wave sums are added in LDS
+    in arrival order)."""
     monkeypatch.setenv("FRUITS_AMD_AUTO_PREPARE", "0")     # (the generic kernel first, then the own one)
     if not plan_too:
         monkeypatch.setenv("FRUITS_HIP_DEBUG", ",".join(
             v for v in (os.environ.get("FRUITS_HIP_DEBUG", ""), "fused_static=0") if v))
-    T = {"multi_chunk": 1500}.get(which, 700)
+    T = {"multi_chunk": 1500, "large_plan_chunks": 2100}.get(which, 700)
     rng = np.random.default_rng(len(which))
     X = rng.standard_normal((40, 2, T)).cumsum(axis=2) / 5.0
     fruit = fr.Fruit(which)
     fruit.add(fr.preparation.INC)
-    if which == "arctic_total":
+    if which.startswith("large_plan"):
+        words = list(fr.words.of_weight(5, dim=2)) + [fr.words.SimpleWord("[1][-2][11][2]")]
+        fruit.add(fr.ISS(words, mode=fr.ISSMode.EXTENDED, weighting=fr.iss.weighting.Indices()))
+    elif which == "arctic_total":
         fruit.add(fr.ISS(fr.words.of_weight(3, dim=2), mode=fr.ISSMode.EXTENDED, semiring=fr.iss.semiring.Arctic(),
                          weighting=fr.iss.weighting.Indices(total=True)))
     else:
         fruit.add(fr.ISS(fr.words.of_weight(3, dim=2), mode=fr.ISSMode.EXTENDED,
                          weighting=fr.iss.weighting.Indices()))
-    if which == "counts":
+    if which in ("counts", "large_plan_chunks"):
         fruit.add(fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.NPI, fr.sieving.END)
     elif which == "cuts":
         fruit.add(fr.sieving.NPI(cut=[T // 3, -1], q=(0.25, 0.5, 1.0)), fr.sieving.END(cut=[T // 2, -1]))
