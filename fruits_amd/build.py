@@ -39,6 +39,9 @@ def units():
     for lv in (2, 4, 6, 8):
         out.append((f"walk_m1ti_l{lv}", "walk_inst.hip",
                     ["-DWALK_MODE=1", f"-DWALK_LV={lv}", "-DWALK_TI"] + fused))
+    for lv in (2, 4, 6, 8):
+        out.append((f"walk_m1ho_l{lv}", "walk_inst.hip",
+                    ["-DWALK_MODE=1", f"-DWALK_LV={lv}", "-DWALK_HO"] + fused))
     for mode in (0, 1):
         out.append((f"walk_packed_m{mode}", "walk_packed_inst.hip", [f"-DWALK_MODE={mode}"]))
     for s in (1, 2, 3, 4, 5, 6, 7, 8):

@@ -753,6 +753,7 @@ struct FusedArgs {          // non-null feats selects the fused sieve kernels
   const int32_t *series_cuts = nullptr;   // device (N, cut_slots) per-series boundaries
   int32_t cut_slots = 0;
   bool total_inc = false;   // a differencing sieve on a totally weighted plan
+  int carry_per_node = 3;   // chunk-carry slots of a node: 3, + 2 per differencing order >= 3
   // fused preparation: d_X is the raw input, the staging forms the prepared rows
   const int32_t *prep = nullptr;   // device (n_prep, 4) table
   const double *stats = nullptr;   // device (N, n_prep, 2) or nullptr (no STD)
@@ -761,7 +762,7 @@ struct FusedArgs {          // non-null feats selects the fused sieve kernels
 
 // The instantiation of the fused walk a (plan, series length, sieves) selects - what
 // walk_inst.hip's dispatch picks at launch time, as a key for the run-time compiled variants.
-fr::FusedKey fused_key_for(const fr::Plan &p, int64_t T, bool total_inc) {
+fr::FusedKey fused_key_for(const fr::Plan &p, int64_t T, bool total_inc, bool high_order) {
   const int64_t chunk = fr::walk_chunk_elems(T);
   fr::FusedKey k{};
   k.E = chunk == 512 ? 2 : 4;
@@ -771,6 +772,7 @@ fr::FusedKey fused_key_for(const fr::Plan &p, int64_t T, bool total_inc) {
   k.SEMI = p.semiring;
   k.TI = (k.W && total_inc && p.weighting == FR_W_TOTAL) ? 1 : 0;
   k.TOTAL = (k.W && p.weighting == FR_W_TOTAL) ? 1 : 0;
+  k.HO = (k.MULTI && high_order) ? 1 : 0;
   return k;
 }
 
@@ -1062,12 +1064,14 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
                            ? (uint32_t)(out_k_stride * 8) : 0u;
   a.xcd_map = (a.G > 1 && N % 8 == 0) ? 1 : 0;
   a.carry_slots = carry_slots_for(p, gp.groups);
+  a.carry_per_node = 3;
   a.carry_in_lds = carries_fit_lds(p, T, gp.groups) ? 1 : 0;
   if (fu && !packed) {
     // the fused walk keeps its chunk carries in LDS, three slots per record of the largest group
     int most = 0;
     for (int g = 0; g < gp.groups; ++g) most = std::max(most, gp.group_begin[g + 1] - gp.group_begin[g]);
-    a.carry_slots = 3 * most;
+    a.carry_per_node = fu->carry_per_node;
+    a.carry_slots = a.carry_per_node * most;
     a.carry_in_lds = 1;
   }
   if (fu) {
@@ -1080,6 +1084,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
     a.series_cuts = fu->series_cuts;
     a.cut_slots = fu->cut_slots;
     a.total_inc = (fu->total_inc && p.weighting == FR_W_TOTAL) ? 1 : 0;
+    a.high_order = fu->carry_per_node > 3 ? 1 : 0;
     a.total_weighting = p.weighting == FR_W_TOTAL ? 1 : 0;
     a.has_mpi = fu->has_mpi ? 1 : 0;
     if ((int64_t)p.K * fu->n_ops_padded * 32 >= (int64_t(1) << 32) || gp.recs.size() >= (size_t(1) << 26))
@@ -1140,7 +1145,7 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   if (static_prog) a.persistent = 0;
   if (fu && fu->pl && !packed) {
     // the pipeline's run-time compiled kernel for this instantiation (fr_pipeline_prepare)
-    const fr::FusedKey key = fused_key_for(p, T, fu->total_inc);
+    const fr::FusedKey key = fused_key_for(p, T, fu->total_inc, fu->carry_per_node > 3);
     fr::JitProgram own{};
     {
       std::lock_guard<std::mutex> lock(fu->pl->jit_mu);
@@ -1204,9 +1209,12 @@ fr_pipeline_t *fr_pipeline_create(fr_plan_t *plan, int32_t n_sieves, const int32
     int code = FR_E_ARG;
     if (bad.empty() && sv.kind != FR_SIEVE_END) {
       if (sv.Q1 < 2) bad = "a band sieve needs >= 2 thresholds";
-      else if (sv.inc < -8 || sv.inc > 8 ||
-               ((sv.inc > 2 || sv.inc < 0) && T > fr::walk_chunk_elems(T))) {
-        bad = "the fused epilogue supports inc 0, 1 and 2 (-8 to 8 on series of one time chunk)";
+      else if (sv.inc < -8 || sv.inc > 8 || (sv.inc < 0 && T > fr::walk_chunk_elems(T))) {
+        bad = "the fused epilogue supports inc 0 to 8 (-8 to 8 on series of one time chunk)";
+        code = FR_E_LIMIT;
+      } else if (sv.inc > 2 && T > fr::walk_chunk_elems(T) && plan->p->weighting == FR_W_TOTAL) {
+        bad = "differencing orders above 2 on a totally weighted plan: fused on series of one time "
+              "chunk only (no kernel instance carries both)";
         code = FR_E_LIMIT;
       }
     }
@@ -1390,6 +1398,8 @@ int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
   pl->jit_failed.clear();
   pl->jit_ops = fr::FusedOps{};
   pl->jit_ops.n_padded = pl->n_ops_padded;
+  for (const PipeSieve &sv : pl->sieves)   // (a slot pair per differencing order >= 3: walk_fused.h)
+    if (sv.kind != FR_SIEVE_END && sv.inc > 2) pl->jit_ops.cps = std::max(pl->jit_ops.cps, 3 + 2 * (sv.inc - 2));
   pl->jit_uniform = K > 0 && pl->n_ops_eff > 0 && pl->cut_slots_needed == 0;
   for (int i = 0; i < pl->n_ops_eff && pl->jit_uniform; ++i) {
     int32_t w0 = ops[i].kind_inc;
@@ -1473,7 +1483,7 @@ static bool fused_instance_of(fr_pipeline_t *pl, int64_t N, int32_t groups, fr::
   shape = launch_shape(p, N, pl->T, groups);
   const bool packed = shape.packed && !(total_inc && p.weighting == FR_W_TOTAL);
   if (packed || !shape.fits) return false;
-  key = fused_key_for(p, pl->T, total_inc);
+  key = fused_key_for(p, pl->T, total_inc, pl->jit_ops.cps > 3);
   return true;
 }
 
@@ -1569,6 +1579,7 @@ int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, 
   fu.n_ops_padded = pl->n_ops_padded;
   for (const PipeSieve &sv : pl->sieves)
     if (sv.kind != FR_SIEVE_END && sv.inc >= 1) fu.total_inc = true;
+  fu.carry_per_node = pl->jit_ops.cps;
   if (pl->cut_slots_needed > 0) {
     if (!pl->d_series_cuts || pl->cuts_N != N || pl->cut_slots < pl->cut_slots_needed)
       return fail(FR_E_ARG, "fr_pipeline_run: a sieve has per-series cuts - call "

@@ -332,7 +332,8 @@ static std::string fused_kernel_expr(const FusedKey &k, bool with_plan) {
   std::ostringstream o;
   o << "fr::iss_fused_kernel<fr::WalkCfg<" << k.E << ", 1, " << k.LV << ", " << k.MULTI << ", true, "
     << (k.W ? "true" : "false") << ", 4, 1, " << k.SEMI << ", false, " << (k.TI ? "true" : "false")
-    << ">, " << (k.TOTAL ? "true" : "false") << ", fr::JitOps" << (with_plan ? ", fr::JitPlan>" : ">");
+    << ", " << (k.HO ? "true" : "false") << ">, " << (k.TOTAL ? "true" : "false") << ", fr::JitOps"
+    << (with_plan ? ", fr::JitPlan>" : ">");
   return o.str();
 }
 
@@ -340,7 +341,8 @@ std::string jit_fused_source(const FusedOps &ops, const FusedPlan *plan) {
   std::ostringstream o;
   o << kJitDeviceSource << "\nnamespace fr {\nstruct JitOps {\n  static constexpr bool is_static = true;\n";
   const size_t n = ops.w0.size();
-  o << "  static constexpr int n = " << n << ", n_padded = " << ops.n_padded << ";\n";
+  o << "  static constexpr int n = " << n << ", n_padded = " << ops.n_padded << ", cps = " << ops.cps
+    << ";\n";
   auto list = [&](const char *name, const std::vector<int32_t> &v) {
     o << "  static constexpr int32_t " << name << "[" << (n ? n : 1) << "] = {";
     for (size_t i = 0; i < n; ++i) o << (i ? ", " : "") << v[i];

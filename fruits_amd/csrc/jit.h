@@ -37,6 +37,7 @@ void jit_unload(JitProgram &p);
 struct FusedOps {        // per op of an output row, the same for every row
   std::vector<int32_t> w0, lo, hi;   // FeatOp::kind_inc (kind, differencing order, shape), cuts
   int n_padded = 0;                  // ops per row of the device table (row stride / 32 bytes)
+  int cps = 3;                       // carry slots per node (IssArgs::carry_per_node)
 };
 // The plan as an immediate too (walk_fused.h, fwalk_static): the records of the group program
 // the launch will use (16 words each, sentinels included) and the groups' first records.
@@ -50,9 +51,9 @@ struct FusedPlan {
   int groups() const { return shapes.empty() ? (int)group_begin.size() : n_groups; }
 };
 struct FusedKey {        // the WalkCfg instantiation a (plan, series length, sieves) selects
-  int E, LV, MULTI, W, SEMI, TI, TOTAL;
+  int E, LV, MULTI, W, SEMI, TI, TOTAL, HO;
   uint32_t packed() const {
-    return (uint32_t)(E | LV << 4 | MULTI << 8 | W << 9 | SEMI << 10 | TI << 12 | TOTAL << 13);
+    return (uint32_t)(E | LV << 4 | MULTI << 8 | W << 9 | SEMI << 10 | TI << 12 | TOTAL << 13 | HO << 14);
   }
 };
 std::string jit_fused_source(const FusedOps &ops, const FusedPlan *plan = nullptr);

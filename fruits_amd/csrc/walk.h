@@ -51,11 +51,11 @@ static hipError_t launch_walk_cfg(const IssArgs &a, hipStream_t st) {
 }
 
 // launch of the fused walk (walk_fused.h): one workgroup per (series, group) unit
-template <int E, int LV, int MULTI, bool W, int SEMI, bool TI, bool TOTAL, int MODE = 1>
+template <int E, int LV, int MULTI, bool W, int SEMI, bool TI, bool TOTAL, int MODE = 1, bool HO = false>
 static hipError_t launch_fused_mode(const IssArgs &a, hipStream_t st) {
   // (MODE 2, the tensor is written: "E = 4" is two pieces of two elements per lane - every store
   // instruction of a wave then covers its 1 KiB without holes)
-  using C = WalkCfg<MODE == 2 ? 2 : E, (MODE == 2 && E == 4) ? 2 : 1, LV, MULTI, true, W, 4, MODE, SEMI, false, TI>;
+  using C = WalkCfg<MODE == 2 ? 2 : E, (MODE == 2 && E == 4) ? 2 : 1, LV, MULTI, true, W, 4, MODE, SEMI, false, TI, HO>;
   const size_t lds = ((size_t)a.R * C::CHUNK + 16 + 8 + (MULTI == 1 ? a.carry_slots : 0)) * sizeof(double) +
                      feat_window_bytes(a.feat_window, a.has_mpi != 0, false) + (size_t)a.lds_pad;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -76,13 +76,13 @@ static hipError_t launch_fused_mode(const IssArgs &a, hipStream_t st) {
   return hipGetLastError();
 }
 // (the weighting mode of a plan - total or not - is a compile-time property of the fused walk)
-template <int E, int LV, int MULTI, bool W, int SEMI = 0, bool TI = false, int MODE = 1>
+template <int E, int LV, int MULTI, bool W, int SEMI = 0, bool TI = false, int MODE = 1, bool HO = false>
 static hipError_t launch_fused_cfg(const IssArgs &a, hipStream_t st) {
-  if constexpr (TI) return launch_fused_mode<E, LV, MULTI, W, SEMI, true, true, MODE>(a, st);
+  if constexpr (TI) return launch_fused_mode<E, LV, MULTI, W, SEMI, true, true, MODE, HO>(a, st);
   if constexpr (W) {
-    if (a.total_weighting) return launch_fused_mode<E, LV, MULTI, true, SEMI, false, true, MODE>(a, st);
+    if (a.total_weighting) return launch_fused_mode<E, LV, MULTI, true, SEMI, false, true, MODE, HO>(a, st);
   }
-  return launch_fused_mode<E, LV, MULTI, W, SEMI, false, false, MODE>(a, st);
+  return launch_fused_mode<E, LV, MULTI, W, SEMI, false, false, MODE, HO>(a, st);
 }
 
 // launch of a static program: same persistent grid as the interpreter's

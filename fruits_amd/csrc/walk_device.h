@@ -24,13 +24,18 @@ namespace fr {
 // every piece.  So every 16-byte global access of a wave is lane-contiguous
 // (E = 2: 1 KiB per instruction) and only NW wave totals cross waves.
 template <int E_, int P_, int MAXLV_, int MULTI_, bool VEC_, bool WEIGHTED_, int TEAM_ = 4,
-          int MODE_ = 0, int SEMI_ = 0, bool NT_ = false, bool TOTALINC_ = false>
+          int MODE_ = 0, int SEMI_ = 0, bool NT_ = false, bool TOTALINC_ = false,
+          bool HIGHORD_ = false>
 struct WalkCfg {
   // TOTALINC: fused epilogue of a TOTALLY weighted plan with differencing sieves - the
   // increments need the weight one step to the left (previous_weighted).  Its own
   // instantiation: compiled into the common weighted kernels it costs them 130-400 more
   // SGPR spills and 20 % of their speed (config 4: 21.5 -> 26.5 ms).
   static constexpr bool TOTALINC = TOTALINC_;
+  // HIGHORD: fused epilogue with differencing orders >= 3 on series of SEVERAL time chunks (a
+  // carry per order between chunks).  Its own instantiation like TOTALINC: compiled into the
+  // common multi-chunk kernels it took them past 128 VGPRs (config 5: 24.9 -> 30.5 ms).
+  static constexpr bool HIGHORD = HIGHORD_;
   // NT: the rows of X are staged with non-temporal loads (load_input; the host asks for it
   // when every row is read once per launch and the batch is about the size of the cache)
   static constexpr bool NT = NT_;
@@ -88,6 +93,8 @@ struct WalkCtx {
   double *tail;         // LDS: last first-difference of every wave [2][NW] (fused inc = 2)
   int tail_buf;
   int slot;             // carry slot base of the node being processed
+  int parity;           // fused walk: time chunk & 1 (the carries of differencing orders >= 3 have two
+                        // buffers: several ops of a node read the old one and write the same new one)
   double *out_base;     // out + n*out_n_stride + t0
   double *feat_row;     // MODE 1: feats + n*feat_stride
   double *cnt_row;      // MODE 1: band population of MPI features
@@ -439,10 +446,18 @@ __device__ __forceinline__ double bits_to_double(int lo, int hi) {
 // elements (second differences need them): inside a lane the neighbour, across lanes
 // a DPP shift, across pieces lane 63, across waves an LDS exchange (one extra barrier,
 // taken by every wave since the op list is uniform), across chunks a carry slot.
+// `carry_at`: the node's carry slot of this exchange (2: the first differences' - advanced once
+// per node and chunk, FusedScratch); `two_buffers` (orders >= 3 of the fused walk): the slot pair
+// carry_at, carry_at + 1 - this chunk reads buffer `parity` and writes the other.
 template <class C>
 __device__ __forceinline__ void prev_first_differences(WalkCtx &cx, const double (&d1)[C::EP],
-                                                       double (&dp)[C::EP]) {
+                                                       double (&dp)[C::EP], int carry_at = 2,
+                                                       bool two_buffers = false) {
   constexpr int E = C::E, P = C::P, NW = C::NW;
+  const int rd = cx.slot + carry_at + (two_buffers ? cx.parity : 0);
+  const int wr = cx.slot + carry_at + (two_buffers ? (cx.parity ^ 1) : 0);
+  (void)rd;
+  (void)wr;
   double last[P];
 #pragma unroll
   for (int h = 0; h < P; ++h) {
@@ -460,15 +475,15 @@ __device__ __forceinline__ void prev_first_differences(WalkCtx &cx, const double
     if (cx.wave > 0) before_wave = tl[cx.wave - 1];
     cx.tail_buf ^= 1;
     if constexpr (C::MULTI != 0) {
-      const double carried = cx.first_chunk ? 0.0 : cx.carry[cx.slot + 2];
+      const double carried = cx.first_chunk ? 0.0 : cx.carry[rd];
       if (cx.wave == 0) before_wave = carried;
       const double chunk_last = tl[NW - 1];
       if (C::MULTI == 1 ? (cx.wave == 0 && cx.lane == 0) : (cx.lane == 0))
-        cx.carry[cx.slot + 2] = chunk_last;
+        cx.carry[wr] = chunk_last;
     }
   } else if constexpr (C::MULTI != 0) {
-    before_wave = cx.first_chunk ? 0.0 : cx.carry[cx.slot + 2];
-    if (cx.lane == 0) cx.carry[cx.slot + 2] = last[P - 1];
+    before_wave = cx.first_chunk ? 0.0 : cx.carry[rd];
+    if (cx.lane == 0) cx.carry[wr] = last[P - 1];
   }
   if (cx.lane == 0) {
     dp[0] = before_wave;

@@ -19,8 +19,19 @@
 //   * feature ops carry host-resolved flags (whole series, one-sided band), the epilogue
 //     takes the short path for them;
 //   * features accumulate in the LDS window of walk_device.h (feat_flush) and leave with
-//     plain stores.
+//     plain stores; a slot's column follows from the walk order (GroupedProgram::slot_rows).
 // Results are bit-identical to the interpreter's (same association everywhere).
+//
+// What a kernel of this file knows at compile time is a template parameter:
+//   iss_fused_kernel<C, TOTAL>                     the generic instances (walk_inst.hip): records
+//                                                  and feature ops are decoded as they are read
+//   iss_fused_kernel<C, TOTAL, JitOps>             a pipeline's own kernel (jit.cpp,
+//                                                  fr_pipeline_prepare): the sieves as immediates
+//   iss_fused_kernel<C, TOTAL, JitOps, JitPlan>    ... and the plan (fr_pipeline_compile_plan): a
+//                                                  small one as straight-line code (fwalk_static),
+//                                                  of a large one the node shapes (fwalk_shaped)
+// and C::MODE == 2 is the same node loop with a store epilogue: the lean MATERIALISING walk of the
+// plans that have no static program of walk_device.h's kind (emit_lean, two pieces per wave).
 #pragma once
 #include "walk_device.h"
 
@@ -387,11 +398,13 @@ __device__ __forceinline__ void fop(WalkCtx &cx, const int32_t *w, int slot, con
 #pragma unroll
       for (int e = 0; e < E; ++e) d[e] = d[e] - sc.dp[e];
       d[0] = at0 ? 0.0 : d[0];
-      if constexpr (C::MULTI == 0) {
-        // third to eighth differences: one more neighbour exchange per order (one-chunk series)
+      // third to eighth differences: one more neighbour exchange per order; on series of several
+      // chunks (WalkCfg::HIGHORD) every order carries its last value of the chunk in a slot pair
+      // of its own (IssArgs::carry_per_node = 3 + 2 * (highest order - 2))
+      if constexpr (C::MULTI == 0 || C::HIGHORD) {
         for (int k = 3; k <= inc; ++k) {
           double dq[E];
-          prev_first_differences<C>(cx, d, dq);
+          prev_first_differences<C>(cx, d, dq, 3 + 2 * (k - 3), C::MULTI != 0);
 #pragma unroll
           for (int e = 0; e < E; ++e) d[e] = d[e] - dq[e];
           d[0] = at0 ? 0.0 : d[0];
@@ -436,6 +449,7 @@ struct Hot {
   const FeatOp *ops;
   int n_ops;
   uint32_t op_row_bytes;   // bytes of one output row's ops (the host checks the table < 4 GiB)
+  int cps;                 // carry slots per node (kCarrySlots; more with differencing orders >= 3)
   // MODE 2 (the tensor is written): row 0 of this series' chunk, bytes between two output rows
   // (0: beyond 32 bits - the general product), whole aligned chunk (no per-lane checks)
   char *out;
@@ -680,6 +694,7 @@ __device__ __forceinline__ Hot hot_args(const WalkCtx &cx) {
   a.ops = reinterpret_cast<const FeatOp *>(uniform_ptr(ka.ops));
   a.n_ops = __builtin_amdgcn_readfirstlane(ka.n_ops);
   a.op_row_bytes = __builtin_amdgcn_readfirstlane(ka.n_ops_padded * 32);
+  a.cps = C::MULTI != 0 ? __builtin_amdgcn_readfirstlane(ka.carry_per_node) : kCarrySlots;
   if constexpr (C::MODE == 2) {
     a.out = static_cast<char *>(const_cast<void *>(uniform_ptr(cx.out_base)));
     a.k_stride = __builtin_amdgcn_readfirstlane(ka.k_stride_bytes32);
@@ -704,7 +719,7 @@ __device__ __forceinline__ void fwalk(WalkCtx &cx, int node_begin, int &sink) {
   while (nd.level() != kRecSentinelLevel) {
     fnode<C, TOTAL, OPS>(cx, a, f, nd, rec_off, slot, sink);
     rec_off += 64u;
-    slot += kCarrySlots;
+    slot += a.cps;
   }
 }
 
@@ -838,7 +853,7 @@ __device__ __forceinline__ void fwalk_shaped(WalkCtx &cx, int node_begin, int &s
     fnode_by_shape<C, TOTAL, OPS, SH, 0>(shape, cx, a, f, nd, rec_off, slot, sink);
     shape = next_shape;
     rec_off += 64u;
-    slot += kCarrySlots;
+    slot += a.cps;
   }
 }
 
@@ -869,7 +884,7 @@ __device__ __forceinline__ void fwalk_static(WalkCtx &cx, const Hot &a, double (
   constexpr int EP = C::EP;
   if constexpr (R::level != kRecSentinelLevel) {
     static_assert(R::level < C::MAXLV, "a record deeper than the kernel's register frames");
-    constexpr int slot = kCarrySlots * (PC - GB);
+    constexpr int slot = (C::MULTI != 0 ? OPS::cps : kCarrySlots) * (PC - GB);
     constexpr uint32_t me = (uint32_t)PC * 64u;
     constexpr uint32_t op_off = (uint32_t)R::w(7) * (uint32_t)(OPS::n_padded * 32);
     feat_reserve<C, true>(cx, R::ne * OPS::n);
@@ -945,6 +960,7 @@ __device__ __forceinline__ void fwalk_static_group(WalkCtx &cx, int g0) {
       a.ops = reinterpret_cast<const FeatOp *>(uniform_ptr(ka.ops));
       a.n_ops = OPS::n;
       a.op_row_bytes = (uint32_t)(OPS::n_padded * 32);
+      a.cps = OPS::cps;
       double f[C::MAXLV][C::EP];
 #pragma unroll
       for (int k = 0; k < C::MAXLV; ++k)
@@ -1093,6 +1109,7 @@ __global__ __launch_bounds__(kWalkThreads) void iss_fused_kernel(const IssArgs a
   for (int chunk = 0; chunk < a.nchunks; ++chunk) {
     const int64_t t0 = (int64_t)chunk * C::CHUNK;
     cx.t0 = t0;
+    cx.parity = chunk & 1;
     cx.first_chunk = chunk == 0;
     cx.full_chunk = t0 + C::CHUNK <= a.T;
     if (chunk > 0) lds_barrier();  // all reads of the old rows are done

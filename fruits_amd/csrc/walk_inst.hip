@@ -56,7 +56,25 @@ static hipError_t inst_p(const IssArgs &a, hipStream_t st) {
 #endif
 #define WALK_CAT2(a, b, c, d) a##b##c##d
 #define WALK_CAT(a, b, c, d) WALK_CAT2(a, b, c, d)
-#ifdef WALK_TI
+#ifdef WALK_HO
+// Translation unit of the HIGHORD instantiations (WalkCfg::HIGHORD: differencing orders >= 3 on
+// series of several time chunks), apart from the common fused kernels like the TOTALINC ones.
+template <int E>
+static hipError_t inst_ho(const IssArgs &a, hipStream_t st) {
+  if (a.semiring == kSemiArctic)
+    return a.aux ? launch_fused_cfg<E, WALK_LV, 1, true, 1, false, 1, true>(a, st)
+                 : launch_fused_cfg<E, WALK_LV, 1, false, 1, false, 1, true>(a, st);
+  if (a.semiring == kSemiBayesian)
+    return a.aux ? launch_fused_cfg<E, WALK_LV, 1, true, 2, false, 1, true>(a, st)
+                 : launch_fused_cfg<E, WALK_LV, 1, false, 2, false, 1, true>(a, st);
+  return a.aux ? launch_fused_cfg<E, WALK_LV, 1, true, 0, false, 1, true>(a, st)
+               : launch_fused_cfg<E, WALK_LV, 1, false, 0, false, 1, true>(a, st);
+}
+hipError_t WALK_CAT(walk_inst_ho, , _l, WALK_LV)(const IssArgs &a, int chunk, hipStream_t st) {
+  if (a.nchunks < 2 || !a.carry_in_lds) return hipErrorInvalidValue;
+  return chunk == 512 ? inst_ho<2>(a, st) : inst_ho<4>(a, st);
+}
+#elif defined(WALK_TI)
 // Translation unit of the TOTALINC instantiations (WalkCfg::TOTALINC: fused epilogue of a
 // totally weighted plan with differencing sieves), apart from the common fused kernels so the
 // build stays parallel.
@@ -78,10 +96,15 @@ hipError_t WALK_CAT(walk_inst_ti, , _l, WALK_LV)(const IssArgs &a, int chunk, hi
 #else
 #if WALK_MODE == 1
 hipError_t WALK_CAT(walk_inst_ti, , _l, WALK_LV)(const IssArgs &, int, hipStream_t);
+hipError_t WALK_CAT(walk_inst_ho, , _l, WALK_LV)(const IssArgs &, int, hipStream_t);
 #endif
 hipError_t WALK_CAT(walk_inst_m, WALK_MODE, _l, WALK_LV)(const IssArgs &a, int chunk,
                                                           hipStream_t st) {
 #if WALK_MODE == 1
+  if (a.high_order && a.nchunks > 1) {
+    if (a.aux && a.total_inc) return hipErrorInvalidValue;   // (no instantiation of both)
+    return WALK_CAT(walk_inst_ho, , _l, WALK_LV)(a, chunk, st);
+  }
   if (a.aux && a.total_inc) return WALK_CAT(walk_inst_ti, , _l, WALK_LV)(a, chunk, st);
 #endif
   return chunk == 512 ? inst_p<1>(a, st) : inst_p<2>(a, st);

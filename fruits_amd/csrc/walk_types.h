@@ -119,7 +119,8 @@ struct IssArgs {
   int32_t nchunks;
   int32_t xcd_map;          // strided schedule: the groups of one series share an XCD
   int32_t persistent;       // grid = one resident round of workgroups
-  int32_t carry_slots;      // 3 * (records of the program): LDS carry slots
+  int32_t carry_slots;      // carry_per_node * (records of the largest group): LDS carry slots
+  int32_t carry_per_node;   // fused walk: 3, + 2 per differencing order >= 3 of the sieves (0 = 3)
   int32_t carry_in_lds;     // multi-chunk carries fit in LDS
   int32_t letter_sum;       // Arctic: sum a letter's terms before adding them to the prefix
   int32_t semiring;         // kSemiReals / kSemiArctic
@@ -153,6 +154,7 @@ struct IssArgs {
   int64_t cw_x_unit_stride;
   int32_t cw_Lmax;
   int32_t lds_pad;          // experiments: extra dynamic LDS bytes per workgroup (fewer resident ones)
+  int32_t high_order;       // 1: a fused sieve differences more than twice (WalkCfg::HIGHORD on multi-chunk series)
   int32_t total_inc;        // 1: totally weighted plan whose fused sieves difference (WalkCfg::TOTALINC)
   int32_t total_weighting;  // 1: the plan's weighting is total (the fused walk is compiled per mode)
   int32_t nt_input;         // 1: stage the rows of X with non-temporal loads (interpreter, one group)

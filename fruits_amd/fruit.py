@@ -420,7 +420,7 @@ class FruitSlice:
             if type(sv) not in (NPI, MPI, END):
                 return False
             if type(sv) is not END and not -8 <= sv._inc <= 8:
-                return False     # (beyond 0..2: series of one time chunk; the pipeline says if not)
+                return False     # (cumulated rows: series of one time chunk; the pipeline says if not)
         return True
 
     def _fused(self, T: int, indices=None, chain_row: int = 0):

@@ -2017,11 +2017,11 @@ def test_total_weighting_increments_fused(fr, monkeypatch, semiring, T):
     np.testing.assert_allclose(a[:, ~counts], b[:, ~counts], rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize("T", [200, 700, 1024])
+@pytest.mark.parametrize("T", [200, 700, 1024, 1500, 2100, 4200])
 def test_high_order_increments_fused(fr, monkeypatch, T):
     """NPI / MPI with inc = 3 ... 8 (IncrementSieve._pre_transform applies the increments inc
-    times): fused on series of one time chunk - same counts as the materialising kernels;
-    longer series keep the unfused path."""
+    times): fused - same counts as the materialising kernels - also on series of several time
+    chunks (every order carries its last value of a chunk to the next one)."""
     rng = np.random.default_rng(T)
     X = rng.standard_normal((13, 2, T)).cumsum(axis=2)
 
@@ -2048,14 +2048,11 @@ def test_high_order_increments_fused(fr, monkeypatch, T):
     labels = [fused.label(i) for i in range(fused.nfeatures())]
     counts = np.array([("NPI" in s) for s in labels])
     np.testing.assert_array_equal(a[:, counts], b[:, counts])
-    np.testing.assert_allclose(a[:, ~counts], b[:, ~counts], rtol=1e-9, atol=1e-9)
+    # (band means and END values: the fused walk holds four consecutive elements per lane, the
+    # materialising one two pieces of two - the same sums in another association)
+    np.testing.assert_allclose(a[:, ~counts], b[:, ~counts], rtol=1e-9,
+                               atol=1e-11 * max(1.0, float(np.abs(b[:, ~counts]).max())))
     monkeypatch.delenv("FRUITS_AMD_FUSED")
-    long_fruit = build()
-    XL = rng.standard_normal((5, 2, 2100)).cumsum(axis=2)
-    np.random.seed(2)
-    long_fruit.fit(XL)
-    assert long_fruit.get_slice()._fused(2100) is None        # an order needs its own carry
-    assert long_fruit.transform(XL).shape == (5, long_fruit.nfeatures())
 
 
 @pytest.mark.parametrize("semiring", ["Reals", "Arctic"])
