@@ -1209,12 +1209,13 @@ fr_pipeline_t *fr_pipeline_create(fr_plan_t *plan, int32_t n_sieves, const int32
     int code = FR_E_ARG;
     if (bad.empty() && sv.kind != FR_SIEVE_END) {
       if (sv.Q1 < 2) bad = "a band sieve needs >= 2 thresholds";
-      else if (sv.inc < -8 || sv.inc > 8 || (sv.inc < 0 && T > fr::walk_chunk_elems(T))) {
-        bad = "the fused epilogue supports inc 0 to 8 (-8 to 8 on series of one time chunk)";
+      else if (sv.inc < -8 || sv.inc > 8) {
+        bad = "the fused epilogue supports inc -8 to 8";
         code = FR_E_LIMIT;
-      } else if (sv.inc > 2 && T > fr::walk_chunk_elems(T) && plan->p->weighting == FR_W_TOTAL) {
-        bad = "differencing orders above 2 on a totally weighted plan: fused on series of one time "
-              "chunk only (no kernel instance carries both)";
+      } else if ((sv.inc > 2 || sv.inc < 0) && T > fr::walk_chunk_elems(T) &&
+                 plan->p->weighting == FR_W_TOTAL) {
+        bad = "differencing orders above 2 / cumulated rows on a totally weighted plan: fused on "
+              "series of one time chunk only (no kernel instance carries both)";
         code = FR_E_LIMIT;
       }
     }
@@ -1398,8 +1399,11 @@ int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
   pl->jit_failed.clear();
   pl->jit_ops = fr::FusedOps{};
   pl->jit_ops.n_padded = pl->n_ops_padded;
-  for (const PipeSieve &sv : pl->sieves)   // (a slot pair per differencing order >= 3: walk_fused.h)
-    if (sv.kind != FR_SIEVE_END && sv.inc > 2) pl->jit_ops.cps = std::max(pl->jit_ops.cps, 3 + 2 * (sv.inc - 2));
+  for (const PipeSieve &sv : pl->sieves) {   // (a slot pair per differencing order >= 3 and per
+    if (sv.kind == FR_SIEVE_END) continue;    // cumulation of a row: walk_fused.h, fop)
+    if (sv.inc > 2) pl->jit_ops.cps = std::max(pl->jit_ops.cps, 3 + 2 * (sv.inc - 2));
+    if (sv.inc < 0) pl->jit_ops.cps = std::max(pl->jit_ops.cps, 15 + 2 * (-sv.inc));
+  }
   pl->jit_uniform = K > 0 && pl->n_ops_eff > 0 && pl->cut_slots_needed == 0;
   for (int i = 0; i < pl->n_ops_eff && pl->jit_uniform; ++i) {
     int32_t w0 = ops[i].kind_inc;

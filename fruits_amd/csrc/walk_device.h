@@ -84,6 +84,10 @@ __device__ __forceinline__ int lds_pos(int i) {
 }
 
 constexpr int kCarrySlots = 3;  // per node: scan, second scan (non-total), d1 tail (inc = 2)
+// fused walk, series of several chunks (WalkCfg::HIGHORD): a slot pair per differencing order
+// 3 .. 8 at kCarrySlots + 2 (k - 3), and per cumulation 1 .. 8 (inc < 0) from kCumCarryBase on
+constexpr int kCumCarryBase = kCarrySlots + 2 * 6;
+constexpr int kCarrySlotsAll = kCumCarryBase + 2 * 8;
 constexpr int kStageRows = 3;  // rows staged per batch (registers: 4 * U VGPRs per row)
 
 struct WalkCtx {

@@ -221,9 +221,11 @@ __device__ __forceinline__ void fscan_pieces(WalkCtx &cx, const double (&s)[C::E
 // block_scan; the cross-wave step reads the totals window (see the file comment).
 // WINDOW = false: the identity slots hold another semiring's zero (the plain sums of a max-plus
 // plan's cumulated rows, inc < 0) - select instead.
+// `carry_wr`: the slot the advanced chunk carry goes to (default: the one it was read from; the
+// cumulations of the epilogue keep two buffers, see fop).
 template <class C, bool WINDOW = true>
 __device__ __forceinline__ void fscan(WalkCtx &cx, const double (&s)[C::EP], double (&c)[C::EP],
-                                      double (&x)[C::EP], int carry_slot) {
+                                      double (&x)[C::EP], int carry_slot, int carry_wr = -1) {
   static_assert(C::NW == 4, "four waves");
   if constexpr (C::P != 1) {
     fscan_pieces<C>(cx, s, c, x, carry_slot);
@@ -257,7 +259,7 @@ __device__ __forceinline__ void fscan(WalkCtx &cx, const double (&s)[C::EP], dou
     // the carry of earlier chunks: every wave read it before the barrier, the last lane of the
     // chunk advances it
     if (cx.wave == 3)
-      lds_store_lane63(lds_offset((lds_f64 *)cx.carry + carry_slot),
+      lds_store_lane63(lds_offset((lds_f64 *)cx.carry + (carry_wr < 0 ? carry_slot : carry_wr)),
                        semi_add<C::SEMI>(carry_in, semi_add<C::SEMI>(base, incl)));
     base = semi_add<C::SEMI>(base, carry_in);
   }
@@ -369,13 +371,17 @@ __device__ __forceinline__ void fop(WalkCtx &cx, const int32_t *w, int slot, con
   if (inc <= 0) {
 #pragma unroll
     for (int i = 0; i < E; ++i) d[i] = c[i];
-    if constexpr (C::MULTI == 0) {
+    if constexpr (C::MULTI == 0 || C::HIGHORD) {
       // inc < 0: the row cumulated -inc times (np.cumsum, fruits/sieving/increment.py:68-70) -
-      // a plain sum whatever the semiring of the plan; one-chunk series only
-      using CR = WalkCfg<C::E, C::P, C::MAXLV, 0, C::VEC, C::WEIGHTED, C::TEAM, C::MODE, 0>;
+      // a plain sum whatever the semiring of the plan.  On series of several chunks
+      // (WalkCfg::HIGHORD) the j-th cumulation carries its running sum in a slot pair of its
+      // own behind the differencing orders' (kCumCarryBase + 2 (j - 1)): this chunk reads buffer
+      // `parity` and writes the other, so several sieves of a node read the same old value
+      using CR = WalkCfg<C::E, C::P, C::MAXLV, C::MULTI, C::VEC, C::WEIGHTED, C::TEAM, C::MODE, 0>;
       for (int k = inc; k < 0; ++k) {
         double cs[E], xs[E];
-        fscan<CR, false>(cx, d, cs, xs, 0);
+        const int at = cx.slot + kCumCarryBase + 2 * (k - inc);
+        fscan<CR, false>(cx, d, cs, xs, at + cx.parity, at + (cx.parity ^ 1));
 #pragma unroll
         for (int i = 0; i < E; ++i) d[i] = cs[i];
       }

@@ -2056,11 +2056,12 @@ def test_high_order_increments_fused(fr, monkeypatch, T):
 
 
 @pytest.mark.parametrize("semiring", ["Reals", "Arctic"])
-@pytest.mark.parametrize("T", [200, 1024])
+@pytest.mark.parametrize("T", [200, 1024, 1500, 2300])
 def test_cumulated_rows_fused(fr, monkeypatch, semiring, T):
     """NPI / MPI with inc < 0 (the row cumulated -inc times, fruits/sieving/increment.py:68-70):
-    fused on one-chunk series; against the materialising path, whose cumulation is the
-    same parallel sum in another association (counts on exact ties may move by one)."""
+    fused, also on series of several time chunks (every cumulation carries its running sum);
+    against the materialising path, whose cumulation is the same parallel sum in another
+    association (counts on exact ties may move by one)."""
     rng = np.random.default_rng(T + len(semiring))
     X = rng.standard_normal((11, 2, T)) / np.sqrt(T)
 
