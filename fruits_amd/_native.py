@@ -35,7 +35,7 @@ EXPORTS = [
     "fr_pipeline_create", "fr_pipeline_destroy", "fr_pipeline_info",
     "fr_pipeline_workspace_bytes", "fr_pipeline_run", "fr_pipeline_set_quantiles",
     "fr_select_ranks", "fr_coswiss_combine", "fr_plan_create_coswiss", "fr_nan_to_num",
-    "fr_plan_prepare", "fr_pipeline_prepare", "fr_pipeline_compile_plan", "fr_plan_fits", "fr_release_scratch",
+    "fr_plan_prepare", "fr_pipeline_prepare", "fr_pipeline_compile_plan", "fr_pipeline_prepare_cached", "fr_plan_fits", "fr_release_scratch",
     "fr_pipeline_set_preparation", "fr_pipeline_set_series_cuts", "fr_arctic_argmax", "fr_coswiss_set_dropout",
     "fr_coswiss_set_input_stride", "fr_coswiss_ffn",
 ]
@@ -97,6 +97,7 @@ def lib():
     L.fr_plan_prepare.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32]
     L.fr_pipeline_prepare.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     L.fr_pipeline_compile_plan.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
+    L.fr_pipeline_prepare_cached.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     L.fr_pipeline_set_series_cuts.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     L.fr_pipeline_set_preparation.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                               C.c_int32, C.c_double]
@@ -489,6 +490,13 @@ class Pipeline:
         check(lib().fr_pipeline_prepare(self._h, int(N), int(groups)), "fr_pipeline_prepare")
         if plan_too:
             check(lib().fr_pipeline_compile_plan(self._h, int(N), int(groups)), "fr_pipeline_compile_plan")
+
+    def prepare_cached(self, N: int, groups: int = 0) -> int:
+        """fr_pipeline_prepare_cached: the uploads, and the pipeline's own kernels if an earlier
+        process on this machine compiled them (the disk cache: milliseconds; nothing is
+        compiled).  Returns the number of kernels the pipeline now holds."""
+        check(lib().fr_pipeline_prepare_cached(self._h, int(N), int(groups)), "fr_pipeline_prepare_cached")
+        return self.jit_loaded()
 
     def prepare_in_background(self, N: int, groups: int = 0):
         """``prepare`` on a helper thread: the caller goes on with the generic kernel and a later

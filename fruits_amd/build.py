@@ -27,15 +27,19 @@ def units():
     out = [("kernels_misc", "kernels_misc.hip", []), ("plan", "plan.cpp", []),
            ("capi", "capi.cpp", []), ("jit", "jit.cpp", []),
            ("walk_static_reg", "walk_static_inst.hip", ["-DSTATIC_REGISTRY"])]
-    # The fused walk (mode 1): no a*b+c contraction - the reference rounds a letter's product
-    # before the cumulative sum adds it (fruits/iss/semiring.py:143-149), and so do the static
-    # programs below; and its uniform branches stay branches - structurised like divergent ones,
-    # every case of its level dispatch costs six scalar instructions and a speculative copy
+    # The walks: no a*b+c contraction - the reference rounds a letter's product before the
+    # cumulative sum adds it (fruits/iss/semiring.py:143-149) - in EVERY unit, so that the record
+    # interpreter (mode 0), the lean materialising walk (mode 2), the fused walk (mode 1), the
+    # wave-per-series kernels and the static programs below agree bit for bit wherever they sum in
+    # the same association (with contraction the interpreter fused the weight multiply of a
+    # weighted plan's second scan with its first add: 1e-13 beside the others); and uniform
+    # branches stay branches - structurised like divergent ones, every case of the fused walk's
+    # level dispatch costs six scalar instructions and a speculative copy
     fused = ["-ffp-contract=off", "-mllvm", "-structurizecfg-skip-uniform-regions"]
     for mode in (0, 1, 2):
         for lv in (2, 4, 6, 8):
             out.append((f"walk_m{mode}_l{lv}", "walk_inst.hip",
-                        [f"-DWALK_MODE={mode}", f"-DWALK_LV={lv}"] + (fused if mode else fused[1:])))
+                        [f"-DWALK_MODE={mode}", f"-DWALK_LV={lv}"] + fused))
     for lv in (2, 4, 6, 8):
         out.append((f"walk_m1ti_l{lv}", "walk_inst.hip",
                     ["-DWALK_MODE=1", f"-DWALK_LV={lv}", "-DWALK_TI"] + fused))
@@ -43,7 +47,8 @@ def units():
         out.append((f"walk_m1ho_l{lv}", "walk_inst.hip",
                     ["-DWALK_MODE=1", f"-DWALK_LV={lv}", "-DWALK_HO"] + fused))
     for mode in (0, 1):
-        out.append((f"walk_packed_m{mode}", "walk_packed_inst.hip", [f"-DWALK_MODE={mode}"]))
+        out.append((f"walk_packed_m{mode}", "walk_packed_inst.hip",
+                    [f"-DWALK_MODE={mode}", "-ffp-contract=off"]))
     for s in (1, 2, 3, 4, 5, 6, 7, 8):
         out.append((f"coswiss_s{s}", "coswiss_inst.hip", [f"-DCOS_S={s}"]))
     for i in range(static_program_count()):

@@ -446,7 +446,7 @@ extern "C" {
 
 const char *fr_last_error(void) { return g_err.c_str(); }
 
-int fr_version(void) { return 131; }
+int fr_version(void) { return 132; }
 
 int fr_device_count(void) {
   int n = 0;
@@ -778,7 +778,8 @@ fr::FusedKey fused_key_for(const fr::Plan &p, int64_t T, bool total_inc, bool hi
 
 // Compiles (hipRTC, disk cache) and loads the pipeline's fused kernel with its sieves as
 // immediates, once per instantiation; a failure leaves the pipeline on the generic kernel.
-void ensure_fused_jit(fr_pipeline &pl, const fr::FusedKey &key) {
+// (`cache_only`: from the disk cache or not at all - a miss leaves no trace, a later call compiles)
+void ensure_fused_jit(fr_pipeline &pl, const fr::FusedKey &key, bool cache_only = false) {
   const uint32_t id = key.packed();
   fr::FusedOps ops;
   uint64_t gen;
@@ -792,9 +793,10 @@ void ensure_fused_jit(fr_pipeline &pl, const fr::FusedKey &key) {
   }
   fr::JitProgram prog;
   std::string err;
-  const bool ok = fr::jit_fused(ops, key, prog, err);   // (seconds: nobody waits on a lock for it)
+  const bool ok = fr::jit_fused(ops, key, prog, err, nullptr, cache_only);   // (seconds: nobody waits on a lock for it)
   std::lock_guard<std::mutex> lock(pl.jit_mu);
   pl.jit_pending.erase(id);
+  if (!ok && cache_only && fr::jit_not_cached(err)) return;
   if (gen != pl.jit_gen) {   // the thresholds were set again meanwhile: not this pipeline's kernel
     if (ok) fr::jit_unload(prog);
     return;
@@ -806,7 +808,8 @@ void ensure_fused_jit(fr_pipeline &pl, const fr::FusedKey &key) {
 }
 
 // The straight-line variant for the group program `gp` (a copy of its records goes into the source).
-void ensure_fused_static(fr_pipeline &pl, const fr::FusedKey &key, const fr::FusedPlan &plan) {
+void ensure_fused_static(fr_pipeline &pl, const fr::FusedKey &key, const fr::FusedPlan &plan,
+                         bool cache_only = false) {
   const uint64_t id = (uint64_t)key.packed() | (uint64_t)plan.groups() << 32;
   fr::FusedOps ops;
   uint64_t gen;
@@ -819,8 +822,9 @@ void ensure_fused_static(fr_pipeline &pl, const fr::FusedKey &key, const fr::Fus
   }
   fr::JitProgram prog;
   std::string err;
-  const bool ok = fr::jit_fused(ops, key, prog, err, &plan);
+  const bool ok = fr::jit_fused(ops, key, prog, err, &plan, cache_only);
   std::lock_guard<std::mutex> lock(pl.jit_mu);
+  if (!ok && cache_only && fr::jit_not_cached(err)) pl.jit_static_tried.erase(id);
   if (gen != pl.jit_gen) {
     if (ok) fr::jit_unload(prog);
     return;
@@ -1491,7 +1495,9 @@ static bool fused_instance_of(fr_pipeline_t *pl, int64_t N, int32_t groups, fr::
   return true;
 }
 
-int fr_pipeline_prepare(fr_pipeline_t *pl, int64_t N, int32_t groups) {
+static int pipeline_compile_plan(fr_pipeline_t *pl, int64_t N, int32_t groups, bool cache_only);
+
+static int pipeline_prepare(fr_pipeline_t *pl, int64_t N, int32_t groups, bool cache_only) {
   if (!pl || !pl->plan || !pl->plan->p || N < 0)
     return fail(FR_E_ARG, "fr_pipeline_prepare: bad argument");
   if (!pl->have_quantiles)
@@ -1504,11 +1510,24 @@ int fr_pipeline_prepare(fr_pipeline_t *pl, int64_t N, int32_t groups) {
   // kernel runs the pipeline.  Not for the wave-per-series kernels (T <= 384) and CosWISS.
   fr::FusedKey key;
   LaunchShape shape;
-  if (fused_instance_of(pl, N, groups, key, shape)) ensure_fused_jit(*pl, key);
+  if (fused_instance_of(pl, N, groups, key, shape)) ensure_fused_jit(*pl, key, cache_only);
   return FR_OK;
 }
 
+int fr_pipeline_prepare(fr_pipeline_t *pl, int64_t N, int32_t groups) {
+  return pipeline_prepare(pl, N, groups, false);
+}
+
 int fr_pipeline_compile_plan(fr_pipeline_t *pl, int64_t N, int32_t groups) {
+  return pipeline_compile_plan(pl, N, groups, false);
+}
+
+int fr_pipeline_prepare_cached(fr_pipeline_t *pl, int64_t N, int32_t groups) {
+  int rc = pipeline_prepare(pl, N, groups, true);
+  return rc != FR_OK ? rc : pipeline_compile_plan(pl, N, groups, true);
+}
+
+static int pipeline_compile_plan(fr_pipeline_t *pl, int64_t N, int32_t groups, bool cache_only) {
   if (!pl || !pl->plan || !pl->plan->p || N < 0)
     return fail(FR_E_ARG, "fr_pipeline_compile_plan: bad argument");
   if (!pl->have_quantiles)
@@ -1539,7 +1558,7 @@ int fr_pipeline_compile_plan(fr_pipeline_t *pl, int64_t N, int32_t groups) {
       fp.n_groups = gp.groups;
     }
   }
-  ensure_fused_static(*pl, key, fp);
+  ensure_fused_static(*pl, key, fp, cache_only);
   return FR_OK;
 }
 

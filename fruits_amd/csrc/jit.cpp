@@ -215,8 +215,12 @@ std::string jit_source(const StaticSchedule &sc) {
 // Compiles `src` for gfx950 and returns the payload jit_load takes (code object, lowered name of
 // `kernel_expr`, the name's length); served from the disk cache when it holds a valid object for
 // this source, toolchain and option set.
+// `cache_only`: take the code object from the disk cache or fail (err = kNotCached) - nothing is
+// compiled
+static const char *const kNotCached = "not in the disk cache";
 static bool compile_source(const std::string &src, const char *kernel_expr, const char *const *opts,
-                           int n_opts, std::string &code, std::string &err, bool *from_cache) {
+                           int n_opts, std::string &code, std::string &err, bool *from_cache,
+                           bool cache_only = false) {
   if (from_cache) *from_cache = false;
   std::string keyed = src + "\n//" + kernel_expr;
   for (int i = 0; i < n_opts; ++i) keyed += std::string(" ") + opts[i];
@@ -228,6 +232,10 @@ static bool compile_source(const std::string &src, const char *kernel_expr, cons
       return true;
     }
     code.clear();
+  }
+  if (cache_only) {
+    err = kNotCached;
+    return false;
   }
   Rtc &r = rtc();
   if (!r.ok) {
@@ -371,8 +379,10 @@ std::string jit_fused_source(const FusedOps &ops, const FusedPlan *plan) {
   return o.str();
 }
 
+bool jit_not_cached(const std::string &err) { return err == kNotCached; }
+
 bool jit_fused(const FusedOps &ops, const FusedKey &key, JitProgram &out, std::string &err,
-               const FusedPlan *plan) {
+               const FusedPlan *plan, bool cache_only) {
   if (ops.w0.empty() || ops.w0.size() > 64) {
     err = "no ops (or more than 64) per output row";
     return false;
@@ -381,7 +391,8 @@ bool jit_fused(const FusedOps &ops, const FusedKey &key, JitProgram &out, std::s
   for (int attempt = 0; attempt < 2; ++attempt) {
     std::string code;
     bool from_cache = false;
-    if (!compile_source(src, expr.c_str(), kFusedOptions, kNumFusedOptions, code, err, &from_cache))
+    if (!compile_source(src, expr.c_str(), kFusedOptions, kNumFusedOptions, code, err, &from_cache,
+                        cache_only))
       return false;
     hipModule_t mod;
     hipFunction_t fn;
@@ -396,6 +407,10 @@ bool jit_fused(const FusedOps &ops, const FusedKey &key, JitProgram &out, std::s
     if (!from_cache) return false;
     // a cached object the loader refuses (another ROCm, a damaged file): compile afresh, once
     drop_cached(src, expr.c_str(), kFusedOptions, kNumFusedOptions);
+    if (cache_only) {
+      err = kNotCached;
+      return false;
+    }
   }
   return false;
 }

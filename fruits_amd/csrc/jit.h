@@ -59,8 +59,10 @@ struct FusedKey {        // the WalkCfg instantiation a (plan, series length, si
 std::string jit_fused_source(const FusedOps &ops, const FusedPlan *plan = nullptr);
 // Compiles (or takes from the disk cache) and loads on the current device; needs hipRTC.
 // `plan`: the straight-line walk of exactly this group program (JitProgram::groups says which).
+// `cache_only`: only what the disk cache holds (milliseconds); a miss is jit_not_cached(err).
 bool jit_fused(const FusedOps &ops, const FusedKey &key, JitProgram &out, std::string &err,
-               const FusedPlan *plan = nullptr);
+               const FusedPlan *plan = nullptr, bool cache_only = false);
+bool jit_not_cached(const std::string &err);
 hipError_t jit_launch_fused(const JitProgram &p, const IssArgs &a, size_t lds_bytes, hipStream_t st);
 hipError_t jit_launch(const JitProgram &p, const IssArgs &a, hipStream_t st);
 

@@ -313,6 +313,10 @@ int fr_pipeline_prepare(fr_pipeline_t *pipeline, int64_t N, int32_t groups);
  * (115 nodes as straight-line code: ~15 s), cached on disk like the other.  Same results; safe
  * from another thread like fr_pipeline_prepare. */
 int fr_pipeline_compile_plan(fr_pipeline_t *pipeline, int64_t N, int32_t groups);
+/* fr_pipeline_prepare + fr_pipeline_compile_plan with what the disk cache holds and nothing
+ * else: the one-time uploads, and the pipeline's own kernels when an earlier process on this
+ * machine compiled them (milliseconds); a miss compiles nothing and leaves no trace. */
+int fr_pipeline_prepare_cached(fr_pipeline_t *pipeline, int64_t N, int32_t groups);
 /* Per-series segment boundaries for the sieves created with FR_SIEVE_SERIES_CUTS: device
  * table (N, slots) int32, row n = the boundaries of series n (values in [0, T]; the slots of
  * one sieve sorted ascending, the first one its leading 0) - what

@@ -1528,8 +1528,13 @@ def test_own_kernel_compiled_in_the_background(fr, tmp_path, monkeypatch):
         np.testing.assert_array_equal(other, first)
     if loaded == 0:
         pytest.skip("hipRTC is not installed")
+    np.random.seed(3)
     fruit.fit(X)                                     # a refit drops the kernel with the thresholds
-    assert fruit.get_slice()._fused(1024).jit_loaded() == 0
+    again = fruit.get_slice()._fused(1024)
+    assert again.jit_loaded() == 0
+    # ... and what the first compilation left in the disk cache is there at once, without a compiler
+    assert again.prepare_cached(X.shape[0]) >= 1
+    np.testing.assert_array_equal(fruit.transform(X), first)
 
 
 def test_fused_pipeline_is_cached_per_length(fr):
