@@ -1216,11 +1216,6 @@ fr_pipeline_t *fr_pipeline_create(fr_plan_t *plan, int32_t n_sieves, const int32
       else if (sv.inc < -8 || sv.inc > 8) {
         bad = "the fused epilogue supports inc -8 to 8";
         code = FR_E_LIMIT;
-      } else if ((sv.inc > 2 || sv.inc < 0) && T > fr::walk_chunk_elems(T) &&
-                 plan->p->weighting == FR_W_TOTAL) {
-        bad = "differencing orders above 2 / cumulated rows on a totally weighted plan: fused on "
-              "series of one time chunk only (no kernel instance carries both)";
-        code = FR_E_LIMIT;
       }
     }
     if (!bad.empty()) {

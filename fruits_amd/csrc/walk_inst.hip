@@ -61,6 +61,11 @@ static hipError_t inst_p(const IssArgs &a, hipStream_t st) {
 // series of several time chunks), apart from the common fused kernels like the TOTALINC ones.
 template <int E>
 static hipError_t inst_ho(const IssArgs &a, hipStream_t st) {
+  if (a.aux && a.total_inc) {   // ... on a totally weighted plan whose sieves difference: both variants
+    if (a.semiring == kSemiArctic) return launch_fused_cfg<E, WALK_LV, 1, true, 1, true, 1, true>(a, st);
+    if (a.semiring == kSemiBayesian) return launch_fused_cfg<E, WALK_LV, 1, true, 2, true, 1, true>(a, st);
+    return launch_fused_cfg<E, WALK_LV, 1, true, 0, true, 1, true>(a, st);
+  }
   if (a.semiring == kSemiArctic)
     return a.aux ? launch_fused_cfg<E, WALK_LV, 1, true, 1, false, 1, true>(a, st)
                  : launch_fused_cfg<E, WALK_LV, 1, false, 1, false, 1, true>(a, st);
@@ -101,10 +106,7 @@ hipError_t WALK_CAT(walk_inst_ho, , _l, WALK_LV)(const IssArgs &, int, hipStream
 hipError_t WALK_CAT(walk_inst_m, WALK_MODE, _l, WALK_LV)(const IssArgs &a, int chunk,
                                                           hipStream_t st) {
 #if WALK_MODE == 1
-  if (a.high_order && a.nchunks > 1) {
-    if (a.aux && a.total_inc) return hipErrorInvalidValue;   // (no instantiation of both)
-    return WALK_CAT(walk_inst_ho, , _l, WALK_LV)(a, chunk, st);
-  }
+  if (a.high_order && a.nchunks > 1) return WALK_CAT(walk_inst_ho, , _l, WALK_LV)(a, chunk, st);
   if (a.aux && a.total_inc) return WALK_CAT(walk_inst_ti, , _l, WALK_LV)(a, chunk, st);
 #endif
   return chunk == 512 ? inst_p<1>(a, st) : inst_p<2>(a, st);

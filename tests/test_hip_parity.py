@@ -2022,6 +2022,39 @@ def test_total_weighting_increments_fused(fr, monkeypatch, semiring, T):
     np.testing.assert_allclose(a[:, ~counts], b[:, ~counts], rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("semiring", ["Reals", "Arctic"])
+@pytest.mark.parametrize("T", [900, 2100])
+def test_total_weighting_high_orders_fused(fr, monkeypatch, semiring, T):
+    """Both rare variants of the fused epilogue at once: differencing orders above 2 and cumulated
+    rows of TOTALLY weighted sums, on one and on several time chunks (the instantiations that are
+    TOTALINC and HIGHORD) - same counts as the materialising sieve kernels on the stored rows."""
+    rng = np.random.default_rng(T + len(semiring))
+    X = rng.standard_normal((17, 2, T)).cumsum(axis=2) / np.sqrt(T)
+
+    def build():
+        fruit = fr.Fruit()
+        fruit.add(fr.ISS([fr.words.SimpleWord(s) for s in ["[1]", "[1][2]", "[12][1]", "[2][2][1]"]],
+                         mode=fr.ISSMode.EXTENDED, semiring=getattr(fr.iss.semiring, semiring)(),
+                         weighting=fr.iss.weighting.Indices(scale=2.0, total=True)))
+        fruit.add(fr.sieving.NPI(q=(0.5, 1.0), inc=3), fr.sieving.NPI(q=(0.4, 1.0), inc=4, cut=[T // 3, -1]))
+        fruit.add(fr.sieving.NPI(q=(0.5, 1.0), inc=1), fr.sieving.NPI(q=(0.3, 1.0), inc=-1), fr.sieving.END)
+        for slc in fruit:
+            slc.fit_sample_size = 1.0
+        return fruit
+    fused = build()
+    np.random.seed(1)
+    fused.fit(X)
+    assert fused.get_slice()._fused(T) is not None
+    a = fused.transform(X)
+    monkeypatch.setenv("FRUITS_AMD_FUSED", "0")
+    plain = build()
+    np.random.seed(1)
+    plain.fit(X)
+    b = plain.transform(X)
+    labels = [fused.label(i) for i in range(fused.nfeatures())]
+    compare_features(a, b, labels, count_frac=0.02)
+
+
 @pytest.mark.parametrize("T", [200, 700, 1024, 1500, 2100, 4200])
 def test_high_order_increments_fused(fr, monkeypatch, T):
     """NPI / MPI with inc = 3 ... 8 (IncrementSieve._pre_transform applies the increments inc
