@@ -1830,6 +1830,16 @@ def test_float_cuts_run_fused(fr, monkeypatch):
     np.testing.assert_allclose(a[:, ~counts], c[:, ~counts], rtol=1e-9, atol=1e-12)
 
 
+def _require_hiprtc(plan):
+    """Skips a test of run-time compiled programs when hipRTC is not installed."""
+    try:
+        plan.jit(1, compile_only=True)
+    except ValueError as e:
+        if "not available" in str(e):
+            pytest.skip("hipRTC is not installed")
+        raise
+
+
 def test_jit_static_program(fr, monkeypatch, tmp_path):
     """A plan outside the standard word sets: fr_plan_prepare compiles its static program at
     run time (hipRTC); results bit-identical to the interpreter's, equal to the oracle's;
@@ -1852,6 +1862,7 @@ def test_jit_static_program(fr, monkeypatch, tmp_path):
         interp = nat.to_host(iss.transform_device(Xd))
         monkeypatch.setenv("FRUITS_HIP_JIT", "1")
         iss, plan = fresh()
+        _require_hiprtc(plan)
         plan.prepare(N, T)
         assert plan.jit_loaded() >= 1
         got = nat.to_host(iss.transform_device(Xd))
@@ -1881,6 +1892,7 @@ def test_jit_repeated_words(fr, monkeypatch, tmp_path):
     monkeypatch.setenv("FRUITS_HIP_JIT", "1")
     iss = fr.ISS(w48)
     plan = iss._plan(0, 48)
+    _require_hiprtc(plan)
     plan.prepare(1032, 1024)
     assert plan.jit_loaded() == 2
     got = nat.to_host(iss.transform_device(Xd))
@@ -1920,6 +1932,8 @@ def test_random_jit_differential(fr, seed, monkeypatch, tmp_path):
     interp, _ = run("0")
     got, plan = run("2")
     qualifies = plan.static_schedule(1) is not None and plan.static_program_index(1) == 0
+    if qualifies and plan.jit_loaded() == 0:
+        _require_hiprtc(plan)
     assert plan.jit_loaded() == (0 if not qualifies else min(2, 1 + (plan.info(nat.FR_INFO_GROUPS) > 1)))
     np.testing.assert_array_equal(got, interp)
     ref = corc.iss_transform(X, words, mode)
