@@ -324,7 +324,7 @@ def test_random_fruit_differential(fr, seed, monkeypatch):
             q = [[0.0, 1.0], [-1.0, 1.0], [0.5, 1.0], [0.25, 0.5, 1.0], [-1.0, 0.3, 0.7, 1.0]][
                 int(rng.integers(0, 5))]
             sieves.append({"kind": kind, "cut": cut, "q": q,
-                           "inc": int(rng.integers(0, 6))})   # 3..5: fused on one-chunk series
+                           "inc": int(rng.integers(0, 6))})   # 3..5 at T = 1030: the HIGHORD instances
     spec = {"slices": [{"preps": preps,
                         "iss": [{"words": words, "mode": str(rng.choice(["EXTENDED", "SINGLE"])),
                                  "semiring": semiring, "weighting": weighting}],
