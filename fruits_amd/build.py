@@ -22,6 +22,10 @@ HEADERS = ["kernels.h", "plan.h", "jit.h", "walk.h", "walk_device.h", "walk_fuse
            os.path.join("..", "..", "include", "fruits_hip.h")]
 
 
+# headers that only some units include: {header: unit names}
+LOCAL_HEADERS = {"pairwise.h": ("kernels_misc",)}
+
+
 def units():
     """(object name, source, extra flags)"""
     out = [("kernels_misc", "kernels_misc.hip", []), ("plan", "plan.cpp", []),
@@ -76,9 +80,11 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
-def _newest_header() -> float:
+def _newest_header(unit: str = None) -> float:
     # (this file holds the units' compile flags: a change of it rebuilds like a header's)
-    return max([os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS] + [os.path.getmtime(__file__)])
+    local = [h for h, us in LOCAL_HEADERS.items() if unit is None or unit in us]
+    return max([os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS + local]
+               + [os.path.getmtime(__file__)])
 
 
 STAMP = LIB + ".flags"
@@ -162,10 +168,9 @@ def _build(lib_path: str, tag: str, defines, force: bool, verbose: bool, jobs: i
              "-Wno-unused-function"] + [f"-D{d}" for d in defines]
     if os.environ.get("FRUITS_HIP_TIMING_BUILD"):
         flags.append("-DFRUITS_HIP_TIMING_BUILD")
-    hdr_t = _newest_header()
-
     def compile_one(unit):
         name, src, extra = unit
+        hdr_t = _newest_header(name)
         srcp = os.path.join(CSRC, src)
         if only and name not in only:
             return os.path.join(OBJ, f"{name}.p.o")      # the product's object

@@ -6,6 +6,7 @@
 
 #include "kernels.h"
 #include "walk_scan.h"
+#include "pairwise.h"
 
 namespace fr {
 
@@ -275,35 +276,28 @@ __global__ void pre_transform_kernel(const double *__restrict__ A, int64_t N, in
 
 // STD preparateur, separately=True (fruits/preparation/transform.py:141-147):
 // per (series, dimension) row: (x - mean) / (std + eps), std = population std
-// (np.std), or 1 when var=False.
-__device__ __forceinline__ double block_reduce_sum(double v, double *sm) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  __syncthreads();
-  if (lane == 0) sm[wave] = v;
-  __syncthreads();
-  double r = 0.0;
-  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += sm[w];
-  return r;
-}
-
+// (np.std), or 1 when var=False.  mean = np.add.reduce(x) / T and
+// std = sqrt(np.add.reduce((x - mean)^2) / T) in NUMPY'S summation order (pairwise.h):
+// the statistics, and with them every standardised value, are bit-identical to the
+// reference's - a last-bit difference here flips the plateau ties of the max-plus
+// semirings behind it.
 __global__ __launch_bounds__(256) void standardize_kernel(const double *__restrict__ X, int64_t T,
                                                            int div_std, double eps,
                                                            double *__restrict__ out) {
-  __shared__ double sm[4];
+#pragma clang fp contract(off)
+  __shared__ PairwiseShared sh;
   const double *x = X + (int64_t)blockIdx.x * T;
   double *o = out + (int64_t)blockIdx.x * T;
-  double acc = 0.0;
-  for (int64_t t = threadIdx.x; t < T; t += blockDim.x) acc += x[t];
-  const double mean = block_reduce_sum(acc, sm) / (double)T;
+  const double mean = np_sum_row([&](int64_t t) { return x[t]; }, T, sh) / (double)T;
   double sd = 1.0;
   if (div_std) {
-    double v = 0.0;
-    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
-      const double d = x[t] - mean;
-      v += d * d;
-    }
-    sd = sqrt(block_reduce_sum(v, sm) / (double)T);
+    const double v = np_sum_row(
+        [&](int64_t t) {
+          const double d = x[t] - mean;
+          return d * d;
+        },
+        T, sh);
+    sd = sqrt(v / (double)T);
   }
   const double den = sd + eps;
   for (int64_t t = threadIdx.x; t < T; t += blockDim.x) o[t] = (x[t] - mean) / den;
@@ -311,14 +305,15 @@ __global__ __launch_bounds__(256) void standardize_kernel(const double *__restri
 
 // Statistics of the PREPARED rows for the fused preparation of the walk kernel (walk.h):
 // prepared dimension d' = prep[4 d'] (raw dimension), prep[4 d' + 1] (increment lag, 0 none).
-// Same passes and the same summation order as standardize_kernel over the materialised
-// rows, so the fused pipeline reproduces the unfused one bit for bit.
+// The same sums in the same order as standardize_kernel over the materialised rows (numpy's),
+// so the fused pipeline reproduces the unfused one, and both the reference, bit for bit.
 // stats[(n * n_prep + d') * 2] = mean, [.. + 1] = std + eps (1 + eps when div_std == 0).
 __global__ __launch_bounds__(256) void row_stats_kernel(const double *__restrict__ X, int64_t D,
                                                          int64_t T, const int32_t *__restrict__ prep,
                                                          int n_prep, int div_std, double eps,
                                                          double *__restrict__ stats) {
-  __shared__ double sm[4];
+#pragma clang fp contract(off)
+  __shared__ PairwiseShared sh;
   const int64_t n = blockIdx.x / n_prep;
   const int dp = (int)(blockIdx.x % n_prep);
   const int raw = prep[4 * dp], lag = prep[4 * dp + 1];
@@ -327,17 +322,16 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const double *__restrict
     if (lag <= 0) return x[t];
     return t >= lag ? x[t] - x[t - lag] : 0.0;
   };
-  double acc = 0.0;
-  for (int64_t t = threadIdx.x; t < T; t += blockDim.x) acc += value(t);
-  const double mean = block_reduce_sum(acc, sm) / (double)T;
+  const double mean = np_sum_row(value, T, sh) / (double)T;
   double sd = 1.0;
   if (div_std) {
-    double v = 0.0;
-    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
-      const double d = value(t) - mean;
-      v += d * d;
-    }
-    sd = sqrt(block_reduce_sum(v, sm) / (double)T);
+    const double v = np_sum_row(
+        [&](int64_t t) {
+          const double d = value(t) - mean;
+          return d * d;
+        },
+        T, sh);
+    sd = sqrt(v / (double)T);
   }
   if (threadIdx.x == 0) {
     stats[(n * n_prep + dp) * 2] = mean;

@@ -107,7 +107,7 @@ def pytest_terminal_summary(terminalreporter):
         big = max((r["max_d"] for r in part), default=0)
         tr.write_line(f"  SURVEY 7 bar: differing {100.0 * tot['differ'] / max(tot['entries'], 1):.4f} % "
                       f"(bar 0.1 %), largest |d| {big:.0f} (bar 1)"
-                      + ("" if cls == "sum" else " - not asserted for this class"))
+                      + ("" if cls == "sum" else f" - this class must be EQUAL: {cls}: differing {tot['differ']}"))
     if FIT_REPORT:
         tr.write_sep("-", "fit parity report (thresholds fitted on the GPU vs the oracle's)")
         n = sum(r["thresholds"] for r in FIT_REPORT)

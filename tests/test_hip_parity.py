@@ -1088,6 +1088,12 @@ def compare_strict(got, ref, labels, expo, means, rtol=RTOL, what="", max_plus=N
         if cls == "sum":
             # sums: a tie is ONE data point sitting on a threshold that was fitted from it
             assert rec["max_d"] <= 1, rec
+        else:
+            # max-plus rows are formed by max / + / rounded products only, in the reference's
+            # order, from inputs that are bit-equal to the reference's (INC, and since round 4
+            # STD in numpy's summation order, csrc/pairwise.h): plateau ties fall the same
+            # way on both sides - the counts are EQUAL
+            assert rec["differ"] == 0, rec
     if is_mean.any():
         cols = np.nonzero(is_mean)[0]
         g, r, em = got[:, is_mean], ref[:, is_mean], expo[:, is_mean]
@@ -1320,6 +1326,51 @@ def test_fused_preparation(fr, monkeypatch, chain, T):
     compare_features(got, ref, labels, expo, what=f"fused preparation {chain} T={T}")
     monkeypatch.delenv("FRUITS_AMD_FUSED_PREP")
     strict_transform_parity(fruit, spec, X, X, labels, np_seed=1, what=f"fused preparation {chain} T={T}")
+
+
+@pytest.mark.parametrize("T", [1, 5, 7, 8, 9, 127, 128, 129, 1000, 1024, 1025, 4096, 8192, 8193, 20000])
+def test_std_bit_identical_to_numpy(fr, T):
+    """STD is np.mean / np.std along the contiguous axis (fruits/preparation/transform.py:141-147):
+    numpy's pairwise summation in buffers of 8192 elements is a deterministic order and the device
+    kernel follows it (csrc/pairwise.h) - the standardised rows are EQUAL, not close; rows of
+    very different magnitude, constant rows, var=False, INC in front (the fused statistics
+    pre-pass sees x[t] - x[t-1] formed on the fly)."""
+    rng = np.random.default_rng(100 + T)
+    N = 60 if T <= 4096 else 6
+    X = rng.standard_normal((N, 2, T)) * np.exp(rng.uniform(-8, 8, size=(N, 2, 1)))
+    X[::7] = X[::7].cumsum(axis=2)
+    if N > 3:
+        X[3, 0] = 2.5                       # a constant row: std 0, eps decides
+        X[2, 1] = 0.0
+    for var in (True, False):
+        got = fr.preparation.STD(var=var).transform(X)
+        np.testing.assert_array_equal(got, orc.std_transform(X, var=var))
+    if T > 1:
+        inc = orc.inc_transform(X)
+        got = fr.preparation.STD().transform(fr.preparation.INC().transform(X))
+        np.testing.assert_array_equal(got, orc.std_transform(inc))
+
+
+@pytest.mark.parametrize("T", [65, 1024, 2100])
+def test_std_fused_staging_is_exact(fr, T):
+    """The same through the fused launch (statistics pre-pass + standardisation in the staging):
+    an Arctic slice behind NEW(INC) -> STD ends in max / + only, so its END features must EQUAL
+    the oracle's, and so must its counting features (plateau ties included)."""
+    rng = np.random.default_rng(T)
+    X = rng.standard_normal((16, 2, T)).cumsum(axis=2) * 3.0
+    spec = {"slices": [
+        {"preps": [{"kind": "NEW", "inner": {"kind": "INC"}}, {"kind": "STD"}],
+         "iss": [{"words": ["[1]", "[1][2]", "[3][1][4]", "[2][-1]"], "mode": "EXTENDED", "semiring": "Arctic"}],
+         "sieves": [{"kind": "END", "cut": [T // 3, -1]}, {"kind": "NPI", "q": [0.0, 1.0], "inc": 2},
+                    {"kind": "NPI", "q": [0.0, 1.0], "inc": 1}, {"kind": "NPI", "q": [0.0, 1.0], "inc": 3}]}]}
+    fruit = build_fruit(fr, spec)
+    np.random.seed(0)
+    fruit.fit(X)
+    assert fruit.get_slice()._fused(T) is not None
+    got = fruit.transform(X)
+    np.random.seed(0)
+    ref = orc.fruit_transform(spec, orc.fruit_fit(spec, X), X)
+    np.testing.assert_array_equal(got, ref)
 
 
 @pytest.mark.parametrize("T", [300, 700, 1300])
@@ -2149,8 +2200,9 @@ def test_zz_parity_bars():
     (observed 4.0 %: increments of a few ulp of the running sum next to the threshold 0 - the
     nearly absorbed summands of fruit_twi's L1-weighted 9-letter words and of fruit_general's
     deep Indices-weighted words; none of them differs).
-    Max-plus columns (Arctic / Bayesian) tie by construction (plateaus): bounded by the
-    exposure, reported, no percentage bar."""
+    Max-plus columns (Arctic / Bayesian) tie by construction (plateaus of a running maximum,
+    two thirds of the entries are exposed) - and are formed exactly like the reference's, from
+    bit-equal inputs: no entry may differ at all."""
     from conftest import STRICT_REPORT
     sums = [r for r in STRICT_REPORT if r["cls"] == "sum"]
     if len(sums) < 20:
@@ -2162,3 +2214,5 @@ def test_zz_parity_bars():
     big = [r for r in sums if r["series"] >= 64]
     if big:
         assert sum(r["exposed"] for r in big) <= 5e-2 * sum(r["entries"] for r in big), big
+    maxplus = [r for r in STRICT_REPORT if r["cls"] == "max-plus"]
+    assert maxplus and sum(r["differ"] for r in maxplus) == 0, maxplus

@@ -403,6 +403,35 @@ def test_plan_compiler_sanitized(tmp_path):
     assert "K=18 nodes=18" in r.stdout.splitlines()[0]
 
 
+def test_numpy_sum_model(tmp_path):
+    """STD's statistics follow numpy's summation order (csrc/pairwise.h): the order logic of the
+    device routine, compiled for the host (tests/native/pairwise_host.cpp, the lanes' shuffles
+    emulated), equals np.add.reduce bit for bit - lengths around every boundary of the
+    recursion (8, 128, the halving to multiples of 8) and of the 8192-element buffers."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("g++ not available")
+    so = str(tmp_path / "pairwise_host.so")
+    subprocess.check_call([gxx, "-std=c++17", "-O2", "-ffp-contract=off", "-shared", "-fPIC",
+                           os.path.join(ROOT, "tests", "native", "pairwise_host.cpp"), "-o", so])
+    L = C.CDLL(so)
+    L.pw_host_sum.restype = C.c_double
+    L.pw_host_sum.argtypes = [C.c_void_p, C.c_int64]
+    rng = np.random.default_rng(5)
+    lengths = (list(range(1, 300)) + [511, 512, 1000, 1023, 1024, 1025, 2047, 4096, 4097, 5000,
+               8191, 8192, 8193, 8199, 8200, 12345, 16384, 16385, 20000, 70001, 200000])
+    for T in lengths:
+        a = np.ascontiguousarray(rng.standard_normal(T) * np.exp(rng.uniform(-5, 5, T)))
+        got = L.pw_host_sum(a.ctypes.data, T)
+        assert got == np.add.reduce(a), (T, got, np.add.reduce(a))
+        X = a.reshape(1, 1, T)
+        assert got / T == np.mean(X, axis=2)[0, 0]
+    z = np.full(9, -0.0)
+    assert np.signbit(L.pw_host_sum(z.ctypes.data, 9)) == np.signbit(np.add.reduce(z))
+
+
 def test_static_schedules_are_valid_walks():
     """plan.cpp static_schedule: every node once, letters only on completed rows, children
     behind their parents - for the standard word sets and 1-3 groups per series."""
