@@ -713,20 +713,22 @@ class FruitSlice:
             feats[:, r * width:(r + 1) * width] = pipe.run(Xin, last.lookup_device(Xin))
         return feats
 
-    def _transform_ffn_fused(self, Pd, cache):
+    def _transform_ffn_fused(self, Pd, cache, words=None):
         """CosWISS with the randomised ffn (fruits/iss/cos.py:93-137): every (word, frequency)
         reads its own transformed copy of the input, so the slice runs word by word - the F copies
         of a word (coswiss_ffn) go through ONE fused launch of that word's units and the sieves
         (pipeline over the word alone, its rows' thresholds): W launches, and neither the
-        (W x F, N, T) iterated sums nor a sieve pass over them."""
+        (W x F, N, T) iterated sums nor a sieve pass over them.  ``words``: only these (a rank's
+        share of a word-sharded slice), their column blocks in that order."""
         t = nat.torch()
         iss = self._iss[0]
         N, D, T = (int(v) for v in Pd.shape)
         F = len(iss._freqs)
         width = F * sum(sv.nfeatures() for sv in self._sieves)
-        feats = t.empty((N, self.nfeatures()), dtype=t.float64, device=Pd.device)
+        words = list(range(len(iss.words))) if words is None else list(words)
+        feats = t.empty((N, len(words) * width), dtype=t.float64, device=Pd.device)
         Z = t.empty((F, N, D, T), dtype=t.float64, device=Pd.device)
-        for w in range(len(iss.words)):
+        for slot, w in enumerate(words):
             pipe = self._fused(T, indices=(w,))
             if pipe.plan.max_dim > D:
                 raise IndexError(f"a word references dimension {pipe.plan.max_dim} but "
@@ -735,7 +737,7 @@ class FruitSlice:
                 nat.coswiss_ffn(Pd, iss._A[w, f], iss._b[w, f], iss._C[w, f], Z[f])
             nat.check(nat.lib().fr_coswiss_set_input_stride(pipe.plan._h, N * D * T))
             self._arm_series_cuts(pipe, N, T, cache)
-            feats[:, w * width:(w + 1) * width] = pipe.run(Z[0], None)
+            feats[:, slot * width:(slot + 1) * width] = pipe.run(Z[0], None)
         return feats
 
     def fit_transform(self, X: np.ndarray) -> np.ndarray:

@@ -41,7 +41,10 @@ class CosWISS(ISS):
         self._exponent = exponent
         self._ffn_size = ffn_size
         self._dropout = dropout
-        self._programs: dict = {}
+
+    def _fresh_transients(self) -> None:
+        super()._fresh_transients()
+        self._programs: dict = {}    # term programs (device handles) of the non-factorised path
 
     def n_iterated_sums(self) -> int:
         return len(self._freqs) * len(self.words)

@@ -180,7 +180,11 @@ def _device_block(slc, iss, X, cache, indices, depths, per_sum):
     # the rank's share in ONE launch on the RAW batch where the slice's preparation fuses into
     # the staging (INC / NEW(INC) / STD): as in FruitSlice.transform_device
     T = int(Xd.shape[2])
-    chain = slc._fusable_preparation(T)
+    # (a CosWISS with the randomised ffn reads a transformed copy of the input per (word,
+    # frequency) - fruits/iss/cos.py:93-137: its pipelines must not be run on the plain batch;
+    # the rank's words go through FruitSlice._transform_ffn_fused's word-by-word launches)
+    ffn = getattr(iss, "_ffn_size", None) is not None
+    chain = None if ffn else slc._fusable_preparation(T)
     fused = slc._fused(T, indices=indices) if chain is not None else None
     if fused is not None and fused.set_preparation(int(Xd.shape[1]), *chain):
         slc._attach(cache)
@@ -189,7 +193,9 @@ def _device_block(slc, iss, X, cache, indices, depths, per_sum):
     Pd = slc._prepare_device(Xd, cache)
     slc._attach(cache)
     feats = t.zeros((X.shape[0], n_rows * per_sum), dtype=t.float64, device=Pd.device)
-    fused = slc._fused(int(Pd.shape[2]), indices=indices)
+    if ffn and slc._fusable():
+        return slc._transform_ffn_fused(Pd, cache, words=indices)
+    fused = None if ffn else slc._fused(int(Pd.shape[2]), indices=indices)
     if fused is not None:      # the rank's share in ONE launch, no (K_r, N, T) tensor
         fused.set_preparation(int(Pd.shape[1]))     # (prepared input: nothing to fuse)
         slc._arm_series_cuts(fused, int(Pd.shape[0]), int(Pd.shape[2]), cache)

@@ -23,7 +23,7 @@ class Seed(ABC):
     # What a seed holds for the running process only - the cache it is attached to, device
     # programs - and what therefore is no part of its pickled state (a fitted fruit is handed
     # from the rank that fitted it to the others: fruits_amd.parallel.fit_on_root).
-    _TRANSIENT = ("_cache", "_plans")
+    _TRANSIENT = ("_cache", "_plans", "_programs")
 
     def __getstate__(self):
         return {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}

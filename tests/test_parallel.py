@@ -191,3 +191,31 @@ def test_fit_state_round_trip():
     np.testing.assert_array_equal(got._sieves_extended[3][0]._quantiles, [0.1 * 3, np.inf])
     with pytest.raises(ValueError):
         fr.Fruit("other").load_fit_state(a.fit_state())
+
+
+@pytest.mark.parametrize("variant", ["terms", "ffn", "dropout"])
+def test_fit_state_round_trip_coswiss(variant):
+    """A CosWISS keeps device programs of two kinds (factorised plans, and the term programs of
+    the non-factorised path: ctypes handles + device tensors); neither is part of the pickled
+    state, and the receiving side starts with empty tables of both."""
+    import pickle
+    import fruits_amd as fr
+    from fruits_amd import _native as nat
+    words = [fr.words.SimpleWord(s) for s in ["[1]", "[1][2]"]]
+    kw = {"terms": dict(exponent=nat.CosPlan.MAX_EXPONENT + 1), "ffn": dict(ffn_size=3),
+          "dropout": dict(dropout=0.5)}[variant]
+    cos = fr.CosWISS(words, freqs=[0.2, 0.7], **kw)
+    cos._programs[(0, 2, 2)] = (C_handle := object(), "device tensors")
+    cos._plans[("cos", (0, 1))] = C_handle
+    if variant == "ffn":
+        np.random.seed(0)
+        cos._A = np.random.rand(2, 2, 3, 2)           # (the fitted weights DO travel)
+    back = pickle.loads(pickle.dumps(cos))
+    assert back._programs == {} and back._plans == {}
+    assert back._exponent == cos._exponent and list(back._freqs) == [0.2, 0.7]
+    if variant == "ffn":
+        np.testing.assert_array_equal(back._A, cos._A)
+    fruit = fr.Fruit("cos")
+    fruit.add(cos, fr.sieving.END)
+    fruit._fitted = fruit.get_slice()._fitted = True
+    pickle.loads(pickle.dumps(fruit.fit_state()))
