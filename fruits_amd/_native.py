@@ -29,7 +29,7 @@ FR_E_ARG, FR_E_DIM, FR_E_HIP, FR_E_NOMEM, FR_E_LIMIT, FR_E_INDEX = -1, -2, -3, -
 EXPORTS = [
     "fr_last_error", "fr_version", "fr_device_count", "fr_malloc", "fr_free",
     "fr_memcpy_h2d", "fr_memcpy_d2h", "fr_stream_sync", "fr_plan_create",
-    "fr_plan_destroy", "fr_plan_info", "fr_plan_dump", "fr_plan_records", "fr_plan_static_schedule", "fr_plan_jit", "fr_plan_workspace_bytes",
+    "fr_plan_destroy", "fr_plan_info", "fr_plan_dump", "fr_plan_records", "fr_plan_static_schedule", "fr_plan_pieces", "fr_plan_jit", "fr_plan_workspace_bytes",
     "fr_iss_run", "fr_iterated_sum_fast_host", "fr_increments",
     "fr_pathlen_lookup", "fr_sieve", "fr_pre_transform", "fr_standardize",
     "fr_pipeline_create", "fr_pipeline_destroy", "fr_pipeline_info",
@@ -81,6 +81,7 @@ def lib():
     L.fr_plan_jit.restype = C.c_int32
     L.fr_plan_jit.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int64]
     L.fr_plan_static_schedule.restype = C.c_int32
+    L.fr_plan_pieces.restype = C.c_int64
     L.fr_plan_static_schedule.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
     L.fr_plan_records.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
     L.fr_plan_workspace_bytes.restype = C.c_int64
@@ -288,6 +289,39 @@ class Plan:
     def jit_loaded(self) -> int:
         """Number of run-time compiled static programs this plan holds on the device."""
         return int(lib().fr_plan_info(self._h, FR_INFO_JIT_PROGRAMS))
+
+    def pieces(self, max_piece: int = 0):
+        """The plan in pieces (fr_plan_pieces; csrc/plan.h, PiecedProgram) as a dict, or None when
+        the plan has no such cover: ``types`` - per piece type its body / chain records
+        ((records, 16) int32), items ((items, 4): chain byte offset, walk position of the body's
+        first row, nodes of the unit in front), ``unit_begin``, ``unit_row0`` - and
+        ``row_of_walk``, the output row at every walk position."""
+        L = lib()
+        n = int(L.fr_plan_pieces(self._h, C.c_int32(max_piece), None, C.c_int64(0)))
+        if n <= 0:
+            return None
+        buf = np.zeros(n, dtype=np.int32)
+        L.fr_plan_pieces(self._h, C.c_int32(max_piece), buf.ctypes.data_as(C.POINTER(C.c_int32)),
+                         C.c_int64(n))
+        n_types, K, chain_nodes, nodes = (int(v) for v in buf[:4])
+        at, types = 4, []
+        for _ in range(n_types):
+            (body_nodes, body_rows, levels, units, n_items, max_unit_nodes, n_recs,
+             max_unit_rows) = (int(v) for v in buf[at:at + 8])
+            at += 8
+            recs = buf[at:at + 16 * n_recs].reshape(n_recs, 16).copy()
+            at += 16 * n_recs
+            items = buf[at:at + 4 * n_items].reshape(n_items, 4).copy()
+            at += 4 * n_items
+            unit_begin = buf[at:at + units + 1].copy()
+            at += units + 1
+            unit_row0 = buf[at:at + units].copy()
+            at += units
+            types.append(dict(body_nodes=body_nodes, body_rows=body_rows, levels=levels, units=units,
+                              max_unit_nodes=max_unit_nodes, max_unit_rows=max_unit_rows, recs=recs,
+                              items=items, unit_begin=unit_begin, unit_row0=unit_row0))
+        return dict(types=types, K=K, chain_nodes=chain_nodes, nodes=nodes,
+                    row_of_walk=buf[at:at + K].copy())
 
     def static_schedule(self, groups: int = 1):
         """(header dict, (entries, 16) int32) of the plan's static schedule, or None."""
@@ -518,6 +552,10 @@ class Pipeline:
         """Run-time compiled kernels this pipeline holds (``static_only``: those with the plan
         as straight-line code)."""
         return int(lib().fr_pipeline_info(self._h, 4 if static_only else 3))
+
+    def pieces_loaded(self) -> int:
+        """Kernels of piece types this pipeline holds (a large plan in pieces)."""
+        return int(lib().fr_pipeline_info(self._h, 5))
 
     def run(self, Xd, lookup_d, feats=None, groups: int = 0, work=None):
         t = torch()

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -10,6 +11,7 @@
 #include <set>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -254,6 +256,7 @@ bool carries_fit_lds(const fr::Plan &p, int64_t T, int G) {
 // as fit next to the rows and carries while four workgroups still share a CU's 160 KiB, at
 // least what the widest node needs (output rows x feature ops).  `fits`: every group's
 // features fit, so a unit flushes once.  0: the widest node does not fit the LDS at all.
+int feat_window_sized(int widest, int largest_group, size_t other_lds_bytes, bool mpi, bool &fits);
 int feat_window_for(const fr::GroupedProgram &gp, size_t other_lds_bytes, int n_ops, bool mpi,
                     bool &fits) {
   int widest = 0, largest_group = 0;
@@ -267,6 +270,10 @@ int feat_window_for(const fr::GroupedProgram &gp, size_t other_lds_bytes, int n_
     }
     largest_group = std::max(largest_group, total);
   }
+  return feat_window_sized(widest, largest_group, other_lds_bytes, mpi, fits);
+}
+// (widest: the slots one node needs; largest_group: the slots of the largest unit)
+int feat_window_sized(int widest, int largest_group, size_t other_lds_bytes, bool mpi, bool &fits) {
   const size_t budget = 38 * 1024;
   int W = 64;
   while (W < 1024 && W < largest_group &&
@@ -446,7 +453,7 @@ extern "C" {
 
 const char *fr_last_error(void) { return g_err.c_str(); }
 
-int fr_version(void) { return 132; }
+int fr_version(void) { return 133; }
 
 int fr_device_count(void) {
   int n = 0;
@@ -534,6 +541,9 @@ void fr_plan_destroy(fr_plan_t *plan) {
     }
     for (auto &kv : plan->p->programs)
       if (kv.second.d_blob) (void)hipFree(kv.second.d_blob);
+    for (auto &kv : plan->p->pieced)
+      for (fr::PieceType &t : kv.second.types)
+        if (t.d_blob) (void)hipFree(t.d_blob);
     if (plan->p->jit) {
       JitState *js = static_cast<JitState *>(plan->p->jit);
       for (auto &kv : js->progs) fr::jit_unload(kv.second);
@@ -599,6 +609,28 @@ int32_t fr_plan_records(fr_plan_t *plan, int32_t groups, int32_t *buf, int64_t c
   if (buf != nullptr && cap_words >= n * 16)
     std::memcpy(buf, gp.recs.data(), (size_t)n * 64);
   return (int32_t)n;
+}
+
+int64_t fr_plan_pieces(fr_plan_t *plan, int32_t max_piece, int32_t *buf, int64_t cap_words) {
+  if (!plan || !plan->p) return fail(FR_E_ARG, "fr_plan_pieces: null plan");
+  fr::Plan &p = *plan->p;
+  std::lock_guard<std::mutex> lock(p.mu);
+  const fr::PiecedProgram &pp = fr::pieced(p, max_piece > 0 ? max_piece : fr::kFusedPieceNodes);
+  if (!pp.ok) return 0;
+  // header: types, K, node executions in chains, nodes of the plan; per type 8 words + its
+  // records, items and unit tables; then the output row at every walk position
+  std::vector<int32_t> out{(int32_t)pp.types.size(), p.K, pp.chain_nodes, (int32_t)p.nodes.size()};
+  for (const fr::PieceType &t : pp.types) {
+    out.insert(out.end(), {t.body_nodes, t.body_rows, t.levels, t.units(), (int32_t)t.items.size() / 4,
+                           t.max_unit_nodes, (int32_t)t.recs.size(), t.max_unit_rows});
+    for (const fr::NodeRec &r : t.recs) out.insert(out.end(), r.w, r.w + 16);
+    out.insert(out.end(), t.items.begin(), t.items.end());
+    out.insert(out.end(), t.unit_begin.begin(), t.unit_begin.end());
+    out.insert(out.end(), t.unit_row0.begin(), t.unit_row0.end());
+  }
+  out.insert(out.end(), pp.row_of_walk.begin(), pp.row_of_walk.end());
+  if (buf != nullptr && cap_words >= (int64_t)out.size()) std::memcpy(buf, out.data(), out.size() * 4);
+  return (int64_t)out.size();
 }
 
 int32_t fr_plan_static_schedule(fr_plan_t *plan, int32_t groups, int32_t *buf, int64_t cap_words) {
@@ -738,6 +770,28 @@ struct fr_pipeline {
   // instantiation and groups per series: id | groups << 32
   std::map<uint64_t, fr::JitProgram> jit_static;
   std::set<uint64_t> jit_static_tried;
+  // ... or, for a large plan, the plan in PIECES (plan.h, PiecedProgram; walk_fused.h,
+  // fwalk_pieces): one kernel per piece type, by instantiation; the op table in walk order and
+  // the walk position of every output row (uploaded by fr_pipeline_prepare on the caller's
+  // thread; the kernels may come from a helper thread)
+  std::vector<fr::FeatOp> h_ops;   // host copy of the op table
+  struct Pieces {
+    int max_piece = 0, device = -1;
+    std::vector<fr::JitProgram> progs;   // one per piece type; empty: not compiled (yet)
+    void *d_tables = nullptr;
+    const fr::FeatOp *d_ops_walk = nullptr;
+    const int32_t *d_walk_of_row = nullptr;
+  };
+  std::map<uint32_t, Pieces> jit_pieces;
+  std::set<uint32_t> jit_pieces_tried;
+  void drop_pieces() {               // (caller holds jit_mu)
+    for (auto &kv : jit_pieces) {
+      for (fr::JitProgram &pr : kv.second.progs) fr::jit_unload(pr);
+      if (kv.second.d_tables) (void)hipFree(kv.second.d_tables);
+    }
+    jit_pieces.clear();
+    jit_pieces_tried.clear();
+  }
 };
 
 
@@ -758,6 +812,9 @@ struct FusedArgs {          // non-null feats selects the fused sieve kernels
   const int32_t *prep = nullptr;   // device (n_prep, 4) table
   const double *stats = nullptr;   // device (N, n_prep, 2) or nullptr (no STD)
   int32_t n_prep = 0;
+  // a plan in pieces writes its features in walk order: (N, K * per_sum) scratch, and says so
+  double *walk_feats = nullptr;
+  const int32_t **walk_of_row = nullptr;   // set by the launch: the walk position of every output row
 };
 
 // The instantiation of the fused walk a (plan, series length, sieves) selects - what
@@ -830,6 +887,172 @@ void ensure_fused_static(fr_pipeline &pl, const fr::FusedKey &key, const fr::Fus
     return;
   }
   if (ok) pl.jit_static[id] = prog;
+}
+
+// ---- a large plan in pieces (plan.h, PiecedProgram) ----------------------------------------
+// Plans of more than kFusedStaticMaxNodes nodes (developer knobs: pieces=0 - never;
+// piece_min=M - from M nodes on; piece_nodes=P - pieces of at most P nodes).
+int piece_nodes_knob() { return debug_knob("piece_nodes", fr::kFusedPieceNodes); }
+bool pieces_eligible(const fr::Plan &p) {
+  return !p.cos && !p.letter_sum && debug_knob("pieces", 1) != 0 && env_int("FRUITS_HIP_JIT", 1) != 0 &&
+         (int)p.nodes.size() >= debug_knob("piece_min", fr::kFusedStaticMaxNodes + 1);
+}
+
+// Uploads the tables of every piece type once per plan.  Caller holds p.mu; never inside a capture.
+int ensure_piece_tables(fr::Plan &p, fr::PiecedProgram &pp, const char *who) {
+  int rc = claim_device(p, who);
+  if (rc != FR_OK) return rc;
+  for (fr::PieceType &t : pp.types) {
+    if (t.d_blob) continue;
+    size_t off = 0;
+    const size_t o_recs = off;   off = align_up(off + t.recs.size() * sizeof(fr::NodeRec), 64);
+    const size_t o_emit = off;   off = align_up(off + t.emit_rows.size() * 4, 64);
+    const size_t o_items = off;  off = align_up(off + t.items.size() * 4, 64);
+    const size_t o_ub = off;     off = align_up(off + t.unit_begin.size() * 4, 64);
+    const size_t o_ur = off;     off = align_up(off + t.unit_row0.size() * 4, 64);
+    std::vector<char> host(off + 64, 0);
+    std::memcpy(host.data() + o_recs, t.recs.data(), t.recs.size() * sizeof(fr::NodeRec));
+    std::memcpy(host.data() + o_emit, t.emit_rows.data(), t.emit_rows.size() * 4);
+    std::memcpy(host.data() + o_items, t.items.data(), t.items.size() * 4);
+    std::memcpy(host.data() + o_ub, t.unit_begin.data(), t.unit_begin.size() * 4);
+    std::memcpy(host.data() + o_ur, t.unit_row0.data(), t.unit_row0.size() * 4);
+    void *d = nullptr;
+    HIP_TRY(hipMalloc(&d, host.size()));
+    hipError_t e = hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void)hipFree(d);
+      return hip_fail(e, "hipMemcpy(piece tables)");
+    }
+    char *b = static_cast<char *>(d);
+    t.d_blob = d;
+    t.d_recs = reinterpret_cast<const fr::NodeRec *>(b + o_recs);
+    t.d_emit_rows = reinterpret_cast<const int32_t *>(b + o_emit);
+    t.d_items = reinterpret_cast<const int32_t *>(b + o_items);
+    t.d_unit_begin = reinterpret_cast<const int32_t *>(b + o_ub);
+    t.d_unit_row0 = reinterpret_cast<const int32_t *>(b + o_ur);
+  }
+  return FR_OK;
+}
+
+// The pipeline's side of a plan in pieces: the op table in walk order (an op's column = its
+// row's walk position x features per sum + its place in the block) and the walk position of
+// every output row, for the instantiation `key`.  Synchronous uploads: the caller's thread,
+// never inside a capture.  FR_OK also when the plan has no cover.
+int ensure_pieces_tables(fr_pipeline &pl, const fr::FusedKey &key, const char *who) {
+  fr::Plan &p = *pl.plan->p;
+  const int max_piece = piece_nodes_knob();
+  fr::PiecedProgram *pp;
+  {
+    std::lock_guard<std::mutex> lock(p.mu);
+    pp = &fr::pieced(p, max_piece);
+    if (!pp->ok) return FR_OK;
+    int rc = ensure_piece_tables(p, *pp, who);
+    if (rc != FR_OK) return rc;
+  }
+  std::lock_guard<std::mutex> lock(pl.jit_mu);
+  if (!pl.jit_uniform) return FR_OK;
+  fr_pipeline::Pieces &pcs = pl.jit_pieces[key.packed()];
+  if (pcs.d_tables) return FR_OK;
+  const int K = p.K, npad = pl.n_ops_padded;
+  std::vector<fr::FeatOp> walk((size_t)K * npad);
+  std::vector<int32_t> walk_of_row(K, 0);
+  for (int q = 0; q < K; ++q) {
+    const int k = pp->row_of_walk[q];
+    walk_of_row[k] = q;
+    for (int i = 0; i < npad; ++i) {
+      fr::FeatOp o = pl.h_ops[(size_t)k * npad + i];
+      if (i < pl.n_ops_eff) o.col = q * pl.per_sum + (o.col - k * pl.per_sum);
+      walk[(size_t)q * npad + i] = o;
+    }
+  }
+  const size_t ops_bytes = align_up(walk.size() * sizeof(fr::FeatOp), 256);
+  void *d = nullptr;
+  HIP_TRY(hipMalloc(&d, ops_bytes + (size_t)K * 4));
+  hipError_t e = hipMemcpy(d, walk.data(), walk.size() * sizeof(fr::FeatOp), hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = hipMemcpy(static_cast<char *>(d) + ops_bytes, walk_of_row.data(), (size_t)K * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    return hip_fail(e, "hipMemcpy(ops in walk order)");
+  }
+  pcs.max_piece = max_piece;
+  pcs.device = current_device_id();
+  pcs.d_tables = d;
+  pcs.d_ops_walk = static_cast<const fr::FeatOp *>(d);
+  pcs.d_walk_of_row = reinterpret_cast<const int32_t *>(static_cast<char *>(d) + ops_bytes);
+  return FR_OK;
+}
+
+int piece_level_variant(int levels) { return levels <= 2 ? 2 : (levels <= 4 ? 4 : (levels <= 6 ? 6 : 8)); }
+
+// Compiles (hipRTC, one helper thread per piece type; disk cache) and loads the kernels of the
+// plan's piece types for the instantiation `key`; all of them or none.
+void ensure_fused_pieces(fr_pipeline &pl, const fr::FusedKey &key, bool cache_only) {
+  fr::Plan &p = *pl.plan->p;
+  const uint32_t id = key.packed();
+  fr::FusedOps ops;
+  uint64_t gen;
+  int max_piece;
+  {
+    std::lock_guard<std::mutex> lock(pl.jit_mu);
+    auto it = pl.jit_pieces.find(id);
+    if (!pl.jit_uniform || it == pl.jit_pieces.end() || !it->second.d_tables || !it->second.progs.empty() ||
+        pl.jit_pieces_tried.count(id))
+      return;
+    pl.jit_pieces_tried.insert(id);
+    ops = pl.jit_ops;
+    gen = pl.jit_gen;
+    max_piece = it->second.max_piece;
+  }
+  const fr::PiecedProgram *pp;
+  {
+    std::lock_guard<std::mutex> lock(p.mu);
+    pp = &fr::pieced(p, max_piece);   // (map nodes are stable; built and uploaded by ensure_pieces_tables)
+  }
+  const int n_types = (int)pp->types.size();
+  std::vector<fr::JitProgram> progs(n_types);
+  std::vector<std::string> errs(n_types);
+  std::vector<char> good(n_types, 0);
+  const int dev = current_device_id();
+  std::atomic<int> next{0};
+  auto worker = [&] {
+    (void)hipSetDevice(dev);   // (the current device is per thread)
+    for (int t = next++; t < n_types; t = next++) {
+      fr::FusedPlan fp;
+      fp.w = pp->types[t].body_w;
+      fp.piece = true;
+      fr::FusedKey k = key;
+      k.LV = piece_level_variant(pp->types[t].levels);
+      good[t] = fr::jit_fused(ops, k, progs[t], errs[t], &fp, cache_only) ? 1 : 0;
+    }
+  };
+  const int hw = (int)std::thread::hardware_concurrency();
+  const int n_threads = cache_only ? 1 : std::max(1, std::min({n_types, hw > 0 ? hw : 4, 16}));
+  std::vector<std::thread> pool;
+  for (int i = 1; i < n_threads; ++i) pool.emplace_back(worker);
+  worker();
+  for (std::thread &th : pool) th.join();
+  bool all = true, missing = false;
+  for (int t = 0; t < n_types; ++t) {
+    if (!good[t]) all = false;
+    if (!good[t] && cache_only && fr::jit_not_cached(errs[t])) missing = true;
+  }
+  std::lock_guard<std::mutex> lock(pl.jit_mu);
+  auto it = pl.jit_pieces.find(id);
+  if (!all || gen != pl.jit_gen || it == pl.jit_pieces.end()) {
+    for (int t = 0; t < n_types; ++t)
+      if (good[t]) fr::jit_unload(progs[t]);
+    // (a miss of the cache-only look leaves no trace: a later call compiles)
+    if (!all && missing && gen == pl.jit_gen) pl.jit_pieces_tried.erase(id);
+    else if (!all)
+      for (int t = 0; t < n_types; ++t)
+        if (!good[t]) {
+          pl.jit_failed[id | 0x80000000u] = errs[t];
+          break;
+        }
+    return;
+  }
+  it->second.progs = std::move(progs);
 }
 
 // Shared body of fr_iss_run and fr_pipeline_run: validates, lays out the
@@ -1147,6 +1370,63 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
   // static programs of several groups run one short-lived workgroup per unit: the hardware
   // dispatcher balances them and keeps the write front compact
   if (static_prog) a.persistent = 0;
+  if (fu && fu->pl && !packed && fu->walk_feats != nullptr && fu->walk_of_row != nullptr) {
+    // a large plan in pieces (plan.h, PiecedProgram): one launch per piece type, each over
+    // (series x the type's units); the features leave in walk order
+    const fr::FusedKey key = fused_key_for(p, T, fu->total_inc, fu->carry_per_node > 3);
+    fr_pipeline::Pieces pcs;
+    {
+      std::lock_guard<std::mutex> lock(fu->pl->jit_mu);
+      auto it = fu->pl->jit_pieces.find(key.packed());
+      if (it != fu->pl->jit_pieces.end() && !it->second.progs.empty() &&
+          it->second.device == fr::current_device())
+        pcs = it->second;
+    }
+    if (!pcs.progs.empty()) {
+      const fr::PiecedProgram *pp;
+      {
+        std::lock_guard<std::mutex> lock(p.mu);
+        pp = &p.pieced.at(pcs.max_piece);
+      }
+      const int64_t chunk = fr::walk_chunk_elems(T);
+      const int64_t F = (int64_t)p.K * fu->pl->per_sum;
+      for (size_t t = 0; t < pp->types.size(); ++t) {
+        const fr::PieceType &pt = pp->types[t];
+        fr::IssArgs b = a;
+        b.recs = pt.d_recs;
+        b.emit_rows = pt.d_emit_rows;
+        b.piece_items = pt.d_items;
+        b.piece_unit_begin = pt.d_unit_begin;
+        b.piece_unit_row0 = pt.d_unit_row0;
+        b.group_begin = nullptr;
+        b.slot_rows = nullptr;
+        b.group_row_begin = nullptr;
+        b.shape_ids = nullptr;
+        b.G = pt.units();
+        b.xcd_map = (b.G > 1 && N % 8 == 0) ? 1 : 0;
+        b.ops = pcs.d_ops_walk;
+        b.feats = fu->walk_feats;
+        b.feat_stride = F;
+        b.carry_per_node = fu->carry_per_node;
+        b.carry_slots = b.carry_per_node * pt.max_unit_nodes;
+        b.carry_in_lds = 1;
+        b.persistent = 0;
+        b.nchunks = (int32_t)((T + chunk - 1) / chunk);
+        const size_t other = ((size_t)b.R * chunk + 24 + (b.nchunks > 1 ? b.carry_slots : 0)) * 8;
+        bool fits = false;
+        b.feat_window = feat_window_sized(pt.widest_node * fu->n_ops, pt.max_unit_rows * fu->n_ops, other,
+                                          fu->has_mpi, fits);
+        b.feat_fits = fits ? 1 : 0;
+        if (b.feat_window == 0)
+          return fail(FR_E_LIMIT, w + ": the chunk carries and the features of one node do not fit the LDS");
+        const size_t lds = other + fr::feat_window_bytes(b.feat_window, b.has_mpi != 0, false);
+        hipError_t je = fr::jit_launch_fused(pcs.progs[t], b, lds, st);
+        if (je != hipSuccess) return hip_fail(je, "fused walk (a piece type) launch");
+      }
+      *fu->walk_of_row = pcs.d_walk_of_row;
+      return FR_OK;
+    }
+  }
   if (fu && fu->pl && !packed) {
     // the pipeline's run-time compiled kernel for this instantiation (fr_pipeline_prepare)
     const fr::FusedKey key = fused_key_for(p, T, fu->total_inc, fu->carry_per_node > 3);
@@ -1271,6 +1551,7 @@ void fr_pipeline_destroy(fr_pipeline_t *pl) {
   if (pl->d_prep) (void)hipFree(pl->d_prep);
   for (auto &kv : pl->jit) fr::jit_unload(kv.second);
   for (auto &kv : pl->jit_static) fr::jit_unload(kv.second);
+  pl->drop_pieces();
   delete pl;
 }
 
@@ -1289,6 +1570,13 @@ int64_t fr_pipeline_info(const fr_pipeline_t *pl, int32_t what) {
       fr_pipeline *m = const_cast<fr_pipeline *>(pl);
       std::lock_guard<std::mutex> lock(m->jit_mu);
       return (int64_t)m->jit_static.size();
+    }
+    case 5: {                                    // kernels of piece types loaded (a plan in pieces)
+      fr_pipeline *m = const_cast<fr_pipeline *>(pl);
+      std::lock_guard<std::mutex> lock(m->jit_mu);
+      int64_t n = 0;
+      for (const auto &kv : m->jit_pieces) n += (int64_t)kv.second.progs.size();
+      return n;
     }
     default: return fail(FR_E_ARG, "fr_pipeline_info: unknown selector");
   }
@@ -1396,6 +1684,7 @@ int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
   pl->jit_static.clear();
   pl->jit_static_tried.clear();
   pl->jit_failed.clear();
+  pl->drop_pieces();
   pl->jit_ops = fr::FusedOps{};
   pl->jit_ops.n_padded = pl->n_ops_padded;
   for (const PipeSieve &sv : pl->sieves) {   // (a slot pair per differencing order >= 3 and per
@@ -1419,6 +1708,7 @@ int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
     pl->jit_ops.hi.push_back(ops[i].hi);
   }
   const size_t bytes = ops.size() * sizeof(fr::FeatOp);
+  pl->h_ops = ops;
   if (!pl->d_ops && bytes) HIP_TRY(hipMalloc(&pl->d_ops, bytes));
   if (bytes) HIP_TRY(hipMemcpy(pl->d_ops, ops.data(), bytes, hipMemcpyHostToDevice));
   if (!pl->mpi_cols.empty() && !pl->d_mpi_cols) {
@@ -1436,6 +1726,8 @@ int64_t fr_pipeline_workspace_bytes(const fr_pipeline_t *pl, int64_t N, int64_t 
   size_t b = align_up(work_layout(p, N, pl->T, p.weighting ? lookup_rows : 0).total(), 256);
   if (!pl->mpi_cols.empty()) b += align_up((size_t)N * pl->per_sum * p.K * 8, 256);
   if (pl->prep_n > 0 && pl->prep_std != 0) b += align_up((size_t)N * pl->prep_n * 16, 256);
+  // (a plan in pieces leaves its features in walk order first)
+  if (pieces_eligible(p)) b += align_up((size_t)N * pl->per_sum * p.K * 8, 256);
   return (int64_t)b;
 }
 
@@ -1505,7 +1797,14 @@ static int pipeline_prepare(fr_pipeline_t *pl, int64_t N, int32_t groups, bool c
   // kernel runs the pipeline.  Not for the wave-per-series kernels (T <= 384) and CosWISS.
   fr::FusedKey key;
   LaunchShape shape;
-  if (fused_instance_of(pl, N, groups, key, shape)) ensure_fused_jit(*pl, key, cache_only);
+  if (fused_instance_of(pl, N, groups, key, shape)) {
+    // (a large plan runs in pieces: their tables go up here, on the caller's thread)
+    if (pieces_eligible(p)) {
+      rc = ensure_pieces_tables(*pl, key, "fr_pipeline_prepare");
+      if (rc != FR_OK) return rc;
+    }
+    ensure_fused_jit(*pl, key, cache_only);
+  }
   return FR_OK;
 }
 
@@ -1531,6 +1830,19 @@ static int pipeline_compile_plan(fr_pipeline_t *pl, int64_t N, int32_t groups, b
   fr::FusedKey key;
   LaunchShape shape;
   if (!fused_instance_of(pl, N, groups, key, shape) || debug_knob("fused_static", 1) == 0) return FR_OK;
+  // a large plan: in pieces, every piece type straight-line code in a kernel of its own; the
+  // node shapes below only where the plan has no such cover
+  if (pieces_eligible(p)) {
+    if (!cache_only) {
+      int rc = ensure_pieces_tables(*pl, key, "fr_pipeline_compile_plan");
+      if (rc != FR_OK) return rc;
+    }
+    ensure_fused_pieces(*pl, key, cache_only);
+    std::lock_guard<std::mutex> lock(pl->jit_mu);
+    auto it = pl->jit_pieces.find(key.packed());
+    if (it != pl->jit_pieces.end() && !it->second.progs.empty()) return FR_OK;
+    if (cache_only) return FR_OK;   // (not in the cache: the loop kernels' cached variants are not looked up either)
+  }
   // for the group program a launch over N series will pick (another group count at run time
   // simply takes the kernel of fr_pipeline_prepare)
   const int asked = groups > 0 ? groups : debug_knob("groups", 0);
@@ -1643,9 +1955,33 @@ int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, 
       fu.stats = stats;
     }
   }
+  const int32_t *walk_of_row = nullptr;
+  if (pieces_eligible(p)) {
+    size_t off = plan_ws;
+    if (!pl->mpi_cols.empty()) off += align_up((size_t)N * F * 8, 256);
+    if (pl->prep_n > 0 && pl->prep_std != 0) off += align_up((size_t)N * pl->prep_n * 16, 256);
+    fu.walk_feats = reinterpret_cast<double *>(static_cast<char *>(d_work) + off);
+    fu.walk_of_row = &walk_of_row;
+  }
   int rc = run_walk("fr_pipeline_run", p, d_X, N, D, T, d_lookup, lookup_rows, nullptr, 0, 0,
                     d_work, (int64_t)plan_ws, groups, st, &fu);
   if (rc != FR_OK) return rc;
+  if (walk_of_row != nullptr) {
+    // the features are in walk order (plan.h, PiecedProgram): band means there, then the blocks
+    // of every iterated sum to their columns
+    if (!pl->mpi_cols.empty()) {
+      hipError_t e = fr::launch_mpi_finalize(fu.walk_feats, fu.cnt, N, F,
+                                             static_cast<const int32_t *>(pl->d_mpi_cols),
+                                             (int)pl->mpi_cols.size(),
+                                             static_cast<const int32_t *>(pl->d_npi_pairs),
+                                             (int)pl->npi_pairs.size() / 2, pl->per_sum, p.K, st);
+      if (e != hipSuccess) return hip_fail(e, "mpi_finalize launch");
+    }
+    hipError_t e = fr::launch_gather_row_blocks(fu.walk_feats, d_feats, N, F, feat_stride, p.K,
+                                                pl->per_sum, walk_of_row, st);
+    if (e != hipSuccess) return hip_fail(e, "gather_row_blocks launch");
+    return FR_OK;
+  }
   if (!pl->mpi_cols.empty()) {
     hipError_t e = fr::launch_mpi_finalize(d_feats, fu.cnt, N, feat_stride,
                                            static_cast<const int32_t *>(pl->d_mpi_cols),

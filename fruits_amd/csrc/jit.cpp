@@ -361,14 +361,19 @@ std::string jit_fused_source(const FusedOps &ops, const FusedPlan *plan) {
   list("lo", ops.lo);
   list("hi", ops.hi);
   o << "};\n";
-  if (plan != nullptr && !plan->shapes.empty()) {
-    o << "struct JitPlan {\n  static constexpr bool is_static = false, is_shaped = true;\n"
+  if (plan != nullptr && plan->piece) {
+    o << "struct JitPlan {\n  static constexpr bool is_static = false, is_shaped = false, is_piece = true;\n"
+      << "  static constexpr int32_t w[" << plan->w.size() << "] = {";
+    for (size_t i = 0; i < plan->w.size(); ++i) o << (i ? (i % 16 ? ", " : ",\n    ") : "\n    ") << plan->w[i];
+    o << "};\n};\n";
+  } else if (plan != nullptr && !plan->shapes.empty()) {
+    o << "struct JitPlan {\n  static constexpr bool is_static = false, is_shaped = true, is_piece = false;\n"
       << "  static constexpr int n = " << plan->shapes.size() << ";\n  static constexpr int32_t desc["
       << plan->shapes.size() << "] = {";
     for (size_t i = 0; i < plan->shapes.size(); ++i) o << (i ? ", " : "") << plan->shapes[i];
     o << "};\n};\n";
   } else if (plan != nullptr) {
-    o << "struct JitPlan {\n  static constexpr bool is_static = true, is_shaped = false;\n  static constexpr int groups = "
+    o << "struct JitPlan {\n  static constexpr bool is_static = true, is_shaped = false, is_piece = false;\n  static constexpr int groups = "
       << plan->groups() << ";\n  static constexpr int32_t group_begin[" << plan->groups() << "] = {";
     for (int g = 0; g < plan->groups(); ++g) o << (g ? ", " : "") << plan->group_begin[g];
     o << "};\n  static constexpr int32_t w[" << plan->w.size() << "] = {";

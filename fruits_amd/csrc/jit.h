@@ -48,7 +48,10 @@ struct FusedPlan {
   // GroupedProgram::shapes): `w` empty, `n_groups` = the group program they were counted on
   std::vector<int32_t> shapes;
   int n_groups = 0;
-  int groups() const { return shapes.empty() ? (int)group_begin.size() : n_groups; }
+  // ... or ONE piece type of a plan in pieces (plan.h, PiecedProgram; walk_fused.h, fwalk_pieces):
+  // the records of its body (`w`), `piece` set
+  bool piece = false;
+  int groups() const { return piece ? 0 : (shapes.empty() ? (int)group_begin.size() : n_groups); }
 };
 struct FusedKey {        // the WalkCfg instantiation a (plan, series length, sieves) selects
   int E, LV, MULTI, W, SEMI, TI, TOTAL, HO;

@@ -17,6 +17,9 @@ hipError_t launch_iss_walk(IssArgs &a, int levels, hipStream_t st);
 hipError_t launch_mpi_finalize(double *feats, const double *cnt, int64_t N, int64_t stride,
                                const int32_t *cols, int n_cols, const int32_t *pairs, int n_pairs,
                                int per_sum, int K, hipStream_t st);
+hipError_t launch_gather_row_blocks(const double *src, double *dst, int64_t N, int64_t src_stride,
+                                    int64_t dst_stride, int K, int per_sum, const int32_t *walk_of_row,
+                                    hipStream_t st);
 hipError_t launch_exp_tables(const double *g, int64_t count, const float *alphas, int n_alpha,
                              double *aux, bool linear, hipStream_t st);
 hipError_t launch_increments(const double *X, int64_t rows, int64_t T, int64_t shift, double *out,

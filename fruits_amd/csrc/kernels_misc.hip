@@ -1192,6 +1192,38 @@ hipError_t launch_mpi_finalize(double *feats, const double *cnt, int64_t N, int6
   return hipGetLastError();
 }
 
+// A plan in pieces leaves its features in WALK order (plan.h, PiecedProgram): the blocks of
+// `per_sum` columns of one iterated sum back into the reference's row order,
+// dst[n, k * per_sum + j] = src[n, walk_of_row[k] * per_sum + j].  Writes are coalesced, reads
+// gather 8 * per_sum byte runs inside the series' row (a few KB: cache hits).
+__global__ __launch_bounds__(256) void gather_row_blocks_kernel(const double *__restrict__ src,
+                                                                 double *__restrict__ dst, int64_t N,
+                                                                 int64_t src_stride, int64_t dst_stride,
+                                                                 int K, int per_sum,
+                                                                 const int32_t *__restrict__ walk_of_row) {
+  const int64_t F = (int64_t)K * per_sum;
+  const int64_t total = N * F;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / F;
+    const int c = (int)(i - n * F);
+    const int k = c / per_sum, j = c - k * per_sum;
+    dst[n * dst_stride + c] = src[n * src_stride + (int64_t)walk_of_row[k] * per_sum + j];
+  }
+}
+
+hipError_t launch_gather_row_blocks(const double *src, double *dst, int64_t N, int64_t src_stride,
+                                    int64_t dst_stride, int K, int per_sum, const int32_t *walk_of_row,
+                                    hipStream_t st) {
+  const int64_t total = N * (int64_t)K * per_sum;
+  if (total <= 0) return hipSuccess;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(gather_row_blocks_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, N,
+                     src_stride, dst_stride, K, per_sum, walk_of_row);
+  return hipGetLastError();
+}
+
 hipError_t launch_exp_tables(const double *g, int64_t count, const float *alphas, int n_alpha,
                              double *aux, bool linear, hipStream_t st) {
   if (count <= 0 || n_alpha <= 0) return hipSuccess;

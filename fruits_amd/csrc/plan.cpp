@@ -308,6 +308,37 @@ Plan *build_plan(int W, const int32_t *exps, const int32_t *L, const int32_t *Dw
   return nullptr;
 }
 
+// The device record of plan node i (see NodeRec).
+static NodeRec node_record(const Plan &p, int i) {
+  const NodeDesc &nd = p.nodes[i];
+  NodeRec r{};
+  // (a letter whose exponents cancel, [2-2], has no factor at all: the factor-table path
+  // multiplies by none, the inline one always by its first)
+  bool slow = nd.fac_count > kRecInlineFactors || nd.fac_count == 0 || p.letter_sum;
+  for (int j = 0; j < nd.fac_count; ++j)
+    if (p.multiplicative() && (p.factors[nd.fac_begin + j] & FAC_DIV)) slow = true;
+  const bool kids = (nd.flags & F_CHILDREN) != 0;
+  const bool need2 = kids && nd.z_mul >= 0;
+  const bool need1 = nd.emit_count > 0 || (kids && !need2);
+  const int fl = nd.flags | (slow ? F_SLOW : 0) | (need1 ? F_NEED1 : 0) | (need2 ? F_NEED2 : 0) |
+                 (nd.emit_count > 0 ? F_EMIT : 0);
+  r.w[0] = (nd.level & 0xff) | ((fl & 0xff) << 8);
+  // (the first half of a record serves a multiply-only node alone: walk_fused.h)
+  r.w[1] = (nd.fac_count & 0xffff) | ((nd.z_mul + 1) << 16) | ((nd.emit_mul + 1) << 24);
+  for (int j = 0; j < kRecInlineFactors && j < nd.fac_count; ++j)
+    r.w[2 + j] = p.multiplicative() ? (p.factors[nd.fac_begin + j] & FAC_ROW_MASK)
+                                    : p.factors[nd.fac_begin + j];
+  r.w[6] = nd.emit_count;
+  for (int j = 0; j < kRecInlineEmits && j < nd.emit_count; ++j)
+    r.w[7 + j] = p.emit_rows[nd.emit_begin + j];
+  r.w[9] = i;
+  r.w[10] = nd.emit_mul;
+  r.w[11] = nd.z_mul;
+  r.w[12] = nd.fac_begin;
+  r.w[13] = nd.emit_begin;
+  return r;
+}
+
 GroupedProgram &grouped(Plan &p, int G) {
   G = std::max(1, std::min(G, std::max(1, p.units())));
   auto it = p.programs.find(G);
@@ -335,31 +366,7 @@ GroupedProgram &grouped(Plan &p, int G) {
     for (int u : members[g])
       for (int i = p.unit_begin[u]; i < p.unit_begin[u + 1]; ++i) {
         const NodeDesc &nd = p.nodes[i];
-        NodeRec r{};
-        // (a letter whose exponents cancel, [2-2], has no factor at all: the factor-table path
-        // multiplies by none, the inline one always by its first)
-        bool slow = nd.fac_count > kRecInlineFactors || nd.fac_count == 0 || p.letter_sum;
-        for (int j = 0; j < nd.fac_count; ++j)
-          if (p.multiplicative() && (p.factors[nd.fac_begin + j] & FAC_DIV)) slow = true;
-        const bool kids = (nd.flags & F_CHILDREN) != 0;
-        const bool need2 = kids && nd.z_mul >= 0;
-        const bool need1 = nd.emit_count > 0 || (kids && !need2);
-        const int fl = nd.flags | (slow ? F_SLOW : 0) | (need1 ? F_NEED1 : 0) | (need2 ? F_NEED2 : 0) |
-                       (nd.emit_count > 0 ? F_EMIT : 0);
-        r.w[0] = (nd.level & 0xff) | ((fl & 0xff) << 8);
-        // (the first half of a record serves a multiply-only node alone: walk_fused.h)
-        r.w[1] = (nd.fac_count & 0xffff) | ((nd.z_mul + 1) << 16) | ((nd.emit_mul + 1) << 24);
-        for (int j = 0; j < kRecInlineFactors && j < nd.fac_count; ++j)
-          r.w[2 + j] = p.multiplicative() ? (p.factors[nd.fac_begin + j] & FAC_ROW_MASK)
-                                                : p.factors[nd.fac_begin + j];
-        r.w[6] = nd.emit_count;
-        for (int j = 0; j < kRecInlineEmits && j < nd.emit_count; ++j)
-          r.w[7 + j] = p.emit_rows[nd.emit_begin + j];
-        r.w[9] = i;
-        r.w[10] = nd.emit_mul;
-        r.w[11] = nd.z_mul;
-        r.w[12] = nd.fac_begin;
-        r.w[13] = nd.emit_begin;
+        const NodeRec r = node_record(p, i);
         gp.recs.push_back(r);
         for (int j = 0; j < nd.emit_count; ++j) gp.slot_rows.push_back(p.emit_rows[nd.emit_begin + j]);
       }
@@ -394,6 +401,249 @@ GroupedProgram &grouped(Plan &p, int G) {
     for (size_t i = 0; i < gp.recs.size(); ++i) gp.shape_ids[i] = of[i] < 0 ? -1 : id[of[i]];
   }
   return p.programs.emplace(G, std::move(gp)).first->second;
+}
+
+// The plan in pieces (plan.h, PiecedProgram).
+PiecedProgram &pieced(Plan &p, int max_piece) {
+  max_piece = std::max(2, std::min(max_piece, 4096));
+  auto hit = p.pieced.find(max_piece);
+  if (hit != p.pieced.end()) return hit->second;
+  PiecedProgram pp;
+  pp.max_piece = max_piece;
+  const int n = (int)p.nodes.size();
+  if (p.cos || p.letter_sum || n == 0) return p.pieced.emplace(max_piece, std::move(pp)).first->second;
+  // the trie behind the DFS order: an only child continues its parent's frame (F_CHAIN), the
+  // other nodes hang below the last node of the level above
+  std::vector<int> parent(n, -1), below(n, 0);
+  std::vector<std::vector<int>> kids(n + 1);   // kids[i + 1]; kids[0]: the root's
+  for (int u = 0; u < p.units(); ++u) {
+    int last_at[kMaxLevels + 1];
+    for (int &v : last_at) v = -1;
+    for (int i = p.unit_begin[u]; i < p.unit_begin[u + 1]; ++i) {
+      const int lv = p.nodes[i].level;
+      parent[i] = (p.nodes[i].flags & F_CHAIN) ? last_at[lv] : (lv > 0 ? last_at[lv - 1] : -1);
+      last_at[lv] = i;
+      kids[parent[i] + 1].push_back(i);
+    }
+  }
+  for (int i = n - 1; i >= 0; --i)
+    if (parent[i] >= 0) below[parent[i]] += 1 + below[i];
+  // Equal sub-tries get equal numbers - what a node computes (flags, weight rows, output rows,
+  // the factors themselves) and the numbers of its children, SORTED: the order of the children
+  // is the plan's word order, which differs from parent to parent, and since the walk order of
+  // the output rows is ours to choose (row_of_walk) the children are walked in sorted order so
+  // that equal sub-tries are equal record for record.
+  std::vector<int> canon(n, 0);
+  {
+    std::map<std::vector<int32_t>, int> intern;
+    for (int i = n - 1; i >= 0; --i) {
+      const NodeDesc &nd = p.nodes[i];
+      const NodeRec r = node_record(p, i);
+      std::vector<int> &ks = kids[i + 1];
+      std::stable_sort(ks.begin(), ks.end(), [&](int x, int y) { return canon[x] < canon[y]; });
+      std::vector<int32_t> key{r.w[0] >> 8, r.w[1], nd.emit_count, nd.fac_count};
+      for (int j = 0; j < nd.fac_count; ++j) key.push_back(p.factors[nd.fac_begin + j]);
+      for (int c : ks) key.push_back(canon[c]);
+      canon[i] = intern.emplace(key, (int)intern.size()).first->second;
+    }
+    std::stable_sort(kids[0].begin(), kids[0].end(), [&](int x, int y) { return canon[x] < canon[y]; });
+  }
+  // the nodes of the sub-trie below (and with) C in the sorted walk order
+  auto subtrie = [&](int C, std::vector<int> &out) {
+    std::vector<int> stack{C};
+    while (!stack.empty()) {
+      const int x = stack.back();
+      stack.pop_back();
+      out.push_back(x);
+      const std::vector<int> &ks = kids[x + 1];
+      for (auto it = ks.rbegin(); it != ks.rend(); ++it) stack.push_back(*it);
+    }
+  };
+  // sub-tries of at least this many nodes below a node get an item of their own (the node goes
+  // into the chain): such bodies repeat; smaller siblings share a body
+  const int smin = std::max(1, std::min(24, max_piece / 2));
+  struct Item {
+    std::vector<int> chain, roots;
+    int type = -1;
+    std::vector<char> emits;   // per chain node: this item outputs its rows
+  };
+  std::vector<Item> items;
+  auto chain_of = [&](int P) {
+    std::vector<int> c;
+    for (int x = P; x >= 0; x = parent[x]) c.push_back(x);
+    std::reverse(c.begin(), c.end());
+    return c;
+  };
+  auto add_item = [&](int P, const std::vector<int> &roots) {
+    Item it;
+    it.chain = chain_of(P);
+    it.roots = roots;
+    items.push_back(std::move(it));
+  };
+  std::vector<int> todo{-1};
+  while (!todo.empty()) {
+    const int P = todo.back();
+    todo.pop_back();
+    const std::vector<int> &ks = kids[P + 1];
+    if ((P < 0 ? n : below[P]) <= max_piece) {
+      add_item(P, ks);
+      continue;
+    }
+    std::vector<int> small, deeper;
+    int small_nodes = 0;
+    for (int C : ks) {
+      if (below[C] > max_piece) {
+        deeper.push_back(C);
+      } else if (below[C] >= smin) {
+        add_item(C, kids[C + 1]);
+      } else {
+        if (small_nodes + 1 + below[C] > max_piece) {
+          add_item(P, small);
+          small.clear();
+          small_nodes = 0;
+        }
+        small.push_back(C);
+        small_nodes += 1 + below[C];
+      }
+    }
+    if (!small.empty()) add_item(P, small);
+    for (auto it = deeper.rbegin(); it != deeper.rend(); ++it) todo.push_back(*it);
+  }
+  // types: bodies with equal records (levels counted from the chain's end, rows from the body's
+  // first) are one
+  std::map<std::vector<int32_t>, int> type_of;
+  std::vector<std::vector<int>> members;   // items of a type, in order
+  for (size_t ii = 0; ii < items.size(); ++ii) {
+    Item &it = items[ii];
+    const int P = it.chain.empty() ? -1 : it.chain.back();
+    const int shift = P < 0 ? 1 : -p.nodes[P].level;
+    std::vector<int32_t> key, w;
+    std::vector<int32_t> rel_emits;
+    int rows = 0, nodes = 0, levels = 1, widest = 0;
+    bool ok = true;
+    std::vector<int> order;
+    for (int C : it.roots) subtrie(C, order);
+    for (int i : order) {
+        NodeRec r = node_record(p, i);
+        const NodeDesc &nd = p.nodes[i];
+        const int lv = nd.level + shift;
+        if (lv < 0 || lv >= kMaxLevels) ok = false;
+        levels = std::max(levels, lv + 1);
+        r.w[0] = (lv & 0xff) | (r.w[0] & ~0xff);
+        r.w[7] = r.w[8] = 0;
+        if (nd.emit_count > 0) r.w[7] = rows;
+        if (nd.emit_count > 1) r.w[8] = rows + 1;
+        r.w[9] = nodes;
+        r.w[13] = (int32_t)rel_emits.size();
+        for (int j = 0; j < nd.emit_count; ++j) rel_emits.push_back(rows + j);
+        rows += nd.emit_count;
+        widest = std::max(widest, nd.emit_count);
+        ++nodes;
+        key.push_back(r.w[0]);
+        key.push_back(r.w[1]);
+        key.push_back(nd.emit_count);
+        for (int j = 0; j < nd.fac_count; ++j) key.push_back(p.factors[nd.fac_begin + j]);
+        w.insert(w.end(), r.w, r.w + 16);
+      }
+    if (!ok) return p.pieced.emplace(max_piece, std::move(pp)).first->second;
+    auto f = type_of.find(key);
+    if (f == type_of.end()) {
+      PieceType t;
+      NodeRec end{};
+      end.w[0] = kRecSentinelLevel;
+      w.insert(w.end(), end.w, end.w + 16);
+      t.body_w = w;
+      t.body_nodes = nodes;
+      t.body_rows = rows;
+      t.levels = levels;
+      t.widest_node = widest;
+      t.emit_rows = rel_emits;
+      t.recs.resize(w.size() / 16);
+      std::memcpy(t.recs.data(), w.data(), w.size() * 4);
+      f = type_of.emplace(key, (int)pp.types.size()).first;
+      pp.types.push_back(std::move(t));
+      members.emplace_back();
+    }
+    it.type = f->second;
+    members[it.type].push_back((int)ii);
+  }
+  // every chain node is output by the first item whose chain holds it
+  {
+    std::vector<char> out(n, 0);
+    int covered = 0;
+    for (Item &it : items) {
+      for (int x : it.chain) {
+        it.emits.push_back(out[x] ? 0 : 1);
+        if (!out[x]) ++covered;
+        out[x] = 1;
+      }
+      for (int C : it.roots) covered += 1 + below[C];
+    }
+    if (covered != n) return p.pieced.emplace(max_piece, std::move(pp)).first->second;
+  }
+  // units (a few items of one type on one series) and the walk order of the output rows
+  pp.row_of_walk.assign(p.K, -1);
+  int q = 0;
+  for (size_t ti = 0; ti < pp.types.size(); ++ti) {
+    PieceType &t = pp.types[ti];
+    const int limit = max_piece + max_piece / 2;
+    int unit_nodes = 0;
+    t.unit_begin.push_back(0);
+    auto close_unit = [&](int row_end) {
+      t.unit_begin.push_back((int32_t)t.items.size() / 4);
+      t.max_unit_nodes = std::max(t.max_unit_nodes, unit_nodes);
+      t.max_unit_rows = std::max(t.max_unit_rows, row_end - t.unit_row0.back());
+      unit_nodes = 0;
+    };
+    for (int ii : members[ti]) {
+      const Item &it = items[ii];
+      const int size = (int)it.chain.size() + t.body_nodes;
+      if (unit_nodes > 0 && unit_nodes + size > limit) close_unit(q);
+      if (unit_nodes == 0) t.unit_row0.push_back(q);
+      const int32_t chain_off = (int32_t)t.recs.size() * 64;
+      for (size_t c = 0; c < it.chain.size(); ++c) {
+        const int x = it.chain[c];
+        const NodeDesc &nd = p.nodes[x];
+        NodeRec r = node_record(p, x);
+        const int ne = it.emits[c] ? nd.emit_count : 0;
+        const bool need2 = nd.z_mul >= 0, need1 = ne > 0 || !need2;
+        const int fl = ((r.w[0] >> 8) & F_SLOW) | F_CHAIN | F_CHILDREN | (need1 ? F_NEED1 : 0) |
+                       (need2 ? F_NEED2 : 0) | (ne > 0 ? F_EMIT : 0);
+        r.w[0] = fl << 8;   // level 0
+        r.w[6] = ne;
+        r.w[7] = r.w[8] = 0;
+        if (ne > 0) r.w[7] = q;
+        if (ne > 1) r.w[8] = q + 1;
+        r.w[13] = (int32_t)t.emit_rows.size();
+        for (int j = 0; j < ne; ++j) {
+          t.emit_rows.push_back(q + j);
+          pp.row_of_walk[q + j] = p.emit_rows[nd.emit_begin + j];
+        }
+        q += ne;
+        t.widest_node = std::max(t.widest_node, ne);
+        t.recs.push_back(r);
+      }
+      NodeRec end{};
+      end.w[0] = kRecSentinelLevel;
+      t.recs.push_back(end);
+      t.items.push_back(chain_off);
+      t.items.push_back(q);
+      t.items.push_back(unit_nodes);
+      t.items.push_back(0);
+      std::vector<int> order;
+      for (int C : it.roots) subtrie(C, order);
+      for (int i : order)
+        for (int j = 0; j < p.nodes[i].emit_count; ++j)
+          pp.row_of_walk[q++] = p.emit_rows[p.nodes[i].emit_begin + j];
+      unit_nodes += size;
+      pp.chain_nodes += (int)it.chain.size();
+    }
+    if (unit_nodes > 0) close_unit(q);
+  }
+  pp.ok = q == p.K;
+  for (int32_t r : pp.row_of_walk)
+    if (r < 0) pp.ok = false;
+  return p.pieced.emplace(max_piece, std::move(pp)).first->second;
 }
 
 // Static schedule: see plan.h / walk.h.  Greedy list scheduling per group - among the nodes

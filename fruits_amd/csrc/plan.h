@@ -72,6 +72,43 @@ struct CosProgram {
   int64_t x_unit_stride = 0;
 };
 
+// A large plan cut into PIECES for the fused walk (walk_fused.h, fwalk_pieces): straight-line
+// code is what makes the fused walk fast (no record decode, no level dispatch), but one
+// function over a whole plan of a thousand nodes does not compile in useful time.  So the trie
+// is covered by items: a CHAIN - the path from the root to a node P, walked by the record loop,
+// leaving P's prefix in frame 0 - and a BODY, a forest of whole sub-tries below P as
+// straight-line code with its levels counted from P.  Bodies that are equal (same letters, same
+// shape: in of_weight(w, d) every sub-trie below a prefix of the same weight) are ONE type,
+// compiled once (one kernel per type; a unit = a few items of one type on one series).  The
+// output rows are numbered in WALK order (type by type, unit by unit, a chain's rows, then the
+// body's in record order), so a body addresses its thresholds relative to its first row and a
+// unit's feature columns are contiguous; `row_of_walk` maps back.
+struct PieceType {
+  std::vector<int32_t> body_w;      // 16 words per record (rebased levels, body-relative output
+                                    // rows), sentinel included - the immediates of the type's kernel
+  int body_nodes = 0, body_rows = 0, levels = 0;
+  std::vector<NodeRec> recs;        // device records: the body's (record p at byte 64 p), then the
+                                    // chains of the items, each closed by a sentinel
+  std::vector<int32_t> emit_rows;   // output rows beyond the two a record holds (body: relative)
+  std::vector<int32_t> items;       // 4 words per item: chain byte offset in recs, walk position of
+                                    // the body's first row, nodes of the unit in front of the item, 0
+  std::vector<int32_t> unit_begin;  // U + 1 offsets into the items
+  std::vector<int32_t> unit_row0;   // walk position of a unit's first output row
+  int max_unit_nodes = 0, max_unit_rows = 0, widest_node = 0;   // (carry slots, feature window)
+  void *d_blob = nullptr;
+  const NodeRec *d_recs = nullptr;
+  const int32_t *d_emit_rows = nullptr, *d_items = nullptr, *d_unit_begin = nullptr,
+                *d_unit_row0 = nullptr;
+  int units() const { return (int)unit_begin.size() - 1; }
+};
+struct PiecedProgram {
+  bool ok = false;
+  int max_piece = 0;
+  std::vector<PieceType> types;
+  std::vector<int32_t> row_of_walk;   // K entries: the output row at walk position q
+  int chain_nodes = 0;                // node executions spent in chains (all types, per series)
+};
+
 struct Plan {
   CosProgram *cos = nullptr;  // non-null: a CosWISS program (no trie, K = W*F)
   int W = 0;
@@ -100,6 +137,7 @@ struct Plan {
   bool multiplicative() const { return semiring != kSemiArctic; }
   int dims_used = 0;
   std::map<int, GroupedProgram> programs;  // per G
+  std::map<int, PiecedProgram> pieced;     // per largest piece (nodes)
   // pre-compiled static programs for 1 / 2 / 3 groups per series (1 + index; 0: none;
   // -1: not looked up yet)
   int static_prog[4] = {-1, -1, -1, -1};
@@ -131,5 +169,8 @@ struct StaticSchedule {
 StaticSchedule static_schedule(Plan &p, int G);
 // Node order for G groups (LPT assignment of units to groups), cached in the plan.
 GroupedProgram &grouped(Plan &p, int G);
+// The plan in pieces of at most `max_piece` nodes (see PiecedProgram), cached in the plan;
+// !ok: the plan has no such cover (CosWISS, letter sums, nothing to walk).
+PiecedProgram &pieced(Plan &p, int max_piece);
 
 }  // namespace fr

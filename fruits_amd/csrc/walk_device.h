@@ -674,7 +674,8 @@ __device__ __forceinline__ void feat_flush(WalkCtx &cx, bool add) {
     int col;
     if constexpr (TABLE) {
       const int r = sl / n_ops, i = sl - r * n_ops;
-      const int64_t k = as_const(ap->slot_rows)[cx.frow0 + r];
+      // (a plan in pieces numbers its output rows in walk order: no table)
+      const int64_t k = ap->slot_rows != nullptr ? as_const(ap->slot_rows)[cx.frow0 + r] : cx.frow0 + r;
       col = as_const(ap->ops)[k * ap->n_ops_padded + i].col;
     } else {
       col = cx.fl_col[sl];

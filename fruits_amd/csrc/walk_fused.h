@@ -456,6 +456,10 @@ struct Hot {
   int n_ops;
   uint32_t op_row_bytes;   // bytes of one output row's ops (the host checks the table < 4 GiB)
   int cps;                 // carry slots per node (kCarrySlots; more with differencing orders >= 3)
+  // a body of a plan in pieces (fwalk_pieces): its output rows and carry slots count from these
+  // (0 everywhere else)
+  uint32_t op_base;        // byte offset of the body's first output row in the op table
+  int slot_base;           // carry slot of the body's first node
   // MODE 2 (the tensor is written): row 0 of this series' chunk, bytes between two output rows
   // (0: beyond 32 bits - the general product), whole aligned chunk (no per-lane checks)
   char *out;
@@ -517,7 +521,7 @@ __device__ __forceinline__ void fops_all(WalkCtx &cx, const Hot &a, int ne, uint
     slot += n;
     const int k = j == 1 ? rec_field(a.recs, rec_off, 8)
                          : as_const(cold_args()->emit_rows)[rec_field(a.recs, rec_off, 13) + j];
-    op_off = (uint32_t)k * a.op_row_bytes;
+    op_off = a.op_base + (uint32_t)k * a.op_row_bytes;
   }
 }
 
@@ -701,6 +705,8 @@ __device__ __forceinline__ Hot hot_args(const WalkCtx &cx) {
   a.n_ops = __builtin_amdgcn_readfirstlane(ka.n_ops);
   a.op_row_bytes = __builtin_amdgcn_readfirstlane(ka.n_ops_padded * 32);
   a.cps = C::MULTI != 0 ? __builtin_amdgcn_readfirstlane(ka.carry_per_node) : kCarrySlots;
+  a.op_base = 0;
+  a.slot_base = 0;
   if constexpr (C::MODE == 2) {
     a.out = static_cast<char *>(const_cast<void *>(uniform_ptr(cx.out_base)));
     a.k_stride = __builtin_amdgcn_readfirstlane(ka.k_stride_bytes32);
@@ -872,7 +878,7 @@ __device__ __forceinline__ void fwalk_shaped(WalkCtx &cx, int node_begin, int &s
 // decoded - and what is left per node is the arithmetic, the thresholds of its ops and the feature
 // window's bookkeeping.  Same sums in the same order as fwalk (same functions).
 struct NoProg {
-  static constexpr bool is_static = false, is_shaped = false;
+  static constexpr bool is_static = false, is_shaped = false, is_piece = false;
 };
 template <class PG, int PC>
 struct SRec {
@@ -890,9 +896,9 @@ __device__ __forceinline__ void fwalk_static(WalkCtx &cx, const Hot &a, double (
   constexpr int EP = C::EP;
   if constexpr (R::level != kRecSentinelLevel) {
     static_assert(R::level < C::MAXLV, "a record deeper than the kernel's register frames");
-    constexpr int slot = (C::MULTI != 0 ? OPS::cps : kCarrySlots) * (PC - GB);
+    const int slot = a.slot_base + (C::MULTI != 0 ? OPS::cps : kCarrySlots) * (PC - GB);
     constexpr uint32_t me = (uint32_t)PC * 64u;
-    constexpr uint32_t op_off = (uint32_t)R::w(7) * (uint32_t)(OPS::n_padded * 32);
+    const uint32_t op_off = a.op_base + (uint32_t)R::w(7) * (uint32_t)(OPS::n_padded * 32);
     feat_reserve<C, true>(cx, R::ne * OPS::n);
     cx.slot = slot;
     double s[EP];
@@ -967,6 +973,8 @@ __device__ __forceinline__ void fwalk_static_group(WalkCtx &cx, int g0) {
       a.n_ops = OPS::n;
       a.op_row_bytes = (uint32_t)(OPS::n_padded * 32);
       a.cps = OPS::cps;
+      a.op_base = 0;
+      a.slot_base = 0;
       double f[C::MAXLV][C::EP];
 #pragma unroll
       for (int k = 0; k < C::MAXLV; ++k)
@@ -976,6 +984,49 @@ __device__ __forceinline__ void fwalk_static_group(WalkCtx &cx, int g0) {
     } else {
       fwalk_static_group<C, TOTAL, OPS, PG, G + 1>(cx, g0);
     }
+  }
+}
+
+// ---------------------------------------------------------------- a large plan in pieces
+// plan.h, PiecedProgram: a kernel of this kind walks the items of ONE piece type - PG::w holds the
+// records of the type's body, a forest of whole sub-tries as straight-line code (fwalk_static
+// above, its output rows and carry slots counted from the item's) - behind a CHAIN, the path
+// from the trie's root to the node the forest hangs below, walked by the record loop in frame 0.
+// A unit = the items [unit_begin[u], unit_begin[u + 1]) on one series, one staging of its rows.
+template <class C, bool TOTAL, class OPS, class PG>
+__device__ __forceinline__ void fwalk_pieces(WalkCtx &cx, int unit, int &sink) {
+  constexpr int EP = C::EP;
+  Hot a = hot_args<C>(cx);
+  a.n_ops = OPS::n;
+  a.op_row_bytes = (uint32_t)(OPS::n_padded * 32);
+  a.cps = C::MULTI != 0 ? OPS::cps : kCarrySlots;
+  const void *items = uniform_ptr(cx.a->piece_items);
+  const void *unit_begin = uniform_ptr(cx.a->piece_unit_begin);
+  uint32_t it = (uint32_t)at_offset(unit_begin, (uint32_t)unit * 4u)[0] * 16u;
+  const uint32_t it_end = (uint32_t)at_offset(unit_begin, (uint32_t)unit * 4u)[1] * 16u;
+  double f[C::MAXLV][EP];
+#pragma unroll
+  for (int k = 1; k < C::MAXLV; ++k)
+#pragma unroll
+    for (int i = 0; i < EP; ++i) f[k][i] = 0.0;
+  for (; it < it_end; it += 16u) {
+    cptr<int32_t> iw = at_offset(items, it);
+    uint32_t rec_off = (uint32_t)iw[0];
+    const int row_base = iw[1], node_base = iw[2];
+    // the chain: every node continues frame 0 (the semiring's one in front of the first)
+#pragma unroll
+    for (int i = 0; i < EP; ++i) f[0][i] = C::SEMI != 1 ? 1.0 : 0.0;
+    a.op_base = 0;
+    int slot = a.cps * node_base;
+    Rec8 nd = load_rec8(a.recs, rec_off);
+    while (nd.level() != kRecSentinelLevel) {
+      fnode<C, TOTAL, OPS>(cx, a, f, nd, rec_off, slot, sink);
+      rec_off += 64u;
+      slot += a.cps;
+    }
+    a.op_base = (uint32_t)row_base * a.op_row_bytes;
+    a.slot_base = slot;
+    fwalk_static<C, TOTAL, OPS, PG, 0, 0>(cx, a, f);
   }
 }
 
@@ -1108,7 +1159,8 @@ __global__ __launch_bounds__(kWalkThreads) void iss_fused_kernel(const IssArgs a
     n = ni;
     g0 = u - ni * a.G;
   }
-  const int node_begin = as_const(a.group_begin)[g0];
+  int node_begin = 0;
+  if constexpr (!PG::is_piece) node_begin = as_const(a.group_begin)[g0];
   int sink = 0;
   cx.pc_begin = node_begin;
   cx.series = n;   // (feature rows, cut rows: addressed from it where they are needed)
@@ -1126,6 +1178,11 @@ __global__ __launch_bounds__(kWalkThreads) void iss_fused_kernel(const IssArgs a
       fwalk<C, TOTAL, OPS>(cx, node_begin, sink);
     } else {
       cx.fused_used = 0;  // same slots in every chunk
+      if constexpr (PG::is_piece) {
+        static_assert(OPS::is_static && C::MODE == 1, "a piece comes with static ops");
+        cx.frow0 = as_const(a.piece_unit_row0)[g0];
+        fwalk_pieces<C, TOTAL, OPS, PG>(cx, g0, sink);
+      } else {
       cx.frow0 = as_const(a.group_row_begin)[g0];
       if constexpr (PG::is_static) {
         static_assert(OPS::is_static && C::MODE == 1, "a static plan comes with static ops");
@@ -1135,6 +1192,7 @@ __global__ __launch_bounds__(kWalkThreads) void iss_fused_kernel(const IssArgs a
         fwalk_shaped<C, TOTAL, OPS, PG>(cx, node_begin, sink);
       } else {
         fwalk<C, TOTAL, OPS>(cx, node_begin, sink);
+      }
       }
       // a unit whose features fit the window keeps them there over its time chunks; else every
       // chunk leaves its share (added onto the earlier chunks' in global memory)

@@ -71,6 +71,9 @@ constexpr int kFusedStaticMaxNodes = 128;
 // larger plans: this many of their most frequent node shapes get a body of their own in the
 // pipeline's kernel (fwalk_shaped); the others take the generic body
 constexpr int kFusedShapes = 24;
+// ... or, the default since round 4, the plan in PIECES of at most this many nodes, each piece
+// type straight-line code in a kernel of its own (plan.h, PiecedProgram)
+constexpr int kFusedPieceNodes = 128;
 
 constexpr int kWalkThreads = 256;
 
@@ -170,6 +173,12 @@ struct IssArgs {
   const int32_t *prep;
   const double *stats;
   int32_t n_prep;
+  // a plan in pieces (plan.h, PiecedProgram; walk_fused.h, fwalk_pieces): the launch of ONE piece
+  // type - G = its units per series, recs / emit_rows its own tables, ops / feats in walk order
+  // (slot_rows == nullptr: a window slot's output row is its walk position)
+  const int32_t *piece_items;       // 4 words per item: chain byte offset, first body row, nodes in front, 0
+  const int32_t *piece_unit_begin;  // G + 1 offsets into the items
+  const int32_t *piece_unit_row0;   // walk position of a unit's first output row
   unsigned long long *dbg;  // diagnostic stamps (timing build only)
   int32_t debug;            // timing experiments (FRUITS_HIP_DEBUG), 0 in production
 };

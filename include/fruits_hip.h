@@ -135,6 +135,19 @@ int32_t fr_plan_dump(const fr_plan_t *plan, int32_t *buf, int32_t cap);
  * 64-byte node records (16 int32 words each, sentinel records included) in walk
  * order.  Returns the number of records; copies them when `cap_words` holds them. */
 int32_t fr_plan_records(fr_plan_t *plan, int32_t groups, int32_t *buf, int64_t cap_words);
+/* Debug / test view of the plan IN PIECES (csrc/plan.h, PiecedProgram): what the fused walk of a
+ * large plan runs - the trie covered by items (a chain from the root, walked by the record loop,
+ * and a body, a forest of whole sub-tries compiled as straight-line code), equal bodies one
+ * piece TYPE with a kernel of its own, the output rows renumbered in walk order.  `max_piece`:
+ * nodes of the largest body (0: the default).  Words: {types, K, node executions in chains,
+ * nodes}; per type {body nodes, body rows, frames, units, items, nodes of the largest unit,
+ * records, rows of the largest unit}, its records (16 words each: the body's - levels counted
+ * from the chain's end, output rows from the body's first - then the chains, each closed by a
+ * sentinel), its items (4 words: chain byte offset, walk position of the body's first row, nodes
+ * of the unit in front, 0), units + 1 item offsets, a walk position per unit; then the output
+ * row at every walk position.  Returns the number of words (copied when `cap_words` holds
+ * them), 0 when the plan has no such cover. */
+int64_t fr_plan_pieces(fr_plan_t *plan, int32_t max_piece, int32_t *buf, int64_t cap_words);
 /* Debug / test view of the plan's STATIC schedule for `groups` groups per series (small
  * unweighted plans whose walk is compiled as straight-line code): 32 header words {entries,
  * staged rows, frames, groups, row sources [4..8), first entry of each group [8..16), rows
@@ -266,7 +279,8 @@ int fr_sieve(int32_t kind, const double *d_A, int64_t N, int64_t T, int64_t a_st
  * Returns FR_E_LIMIT from create when a sieve is outside the fused set (the caller
  * then uses fr_iss_run + fr_sieve).  fr_pipeline_info: 0 features per iterated sum,
  * 1 q_stride, 2 total features, 3 run-time compiled kernels the pipeline holds
- * (fr_pipeline_prepare), 4 those of them with the plan as straight-line code. */
+ * (fr_pipeline_prepare), 4 those of them with the plan as straight-line code, 5 the kernels
+ * of piece types loaded (a large plan in pieces, fr_pipeline_compile_plan). */
 fr_pipeline_t *fr_pipeline_create(fr_plan_t *plan, int32_t n_sieves, const int32_t *kinds,
                                   const int32_t *incs, const int32_t *C1, const int32_t *Q1,
                                   const int64_t *cuts, int64_t T);

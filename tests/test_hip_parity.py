@@ -1512,6 +1512,8 @@ def test_fused_kernel_compiled_for_its_pipeline(fr, which, plan_too, monkeypatch
         monkeypatch.setenv("FRUITS_HIP_DEBUG", ",".join(
             v for v in (os.environ.get("FRUITS_HIP_DEBUG", ""), "fused_static=0") if v))
     T = {"multi_chunk": 1500, "large_plan_chunks": 2100}.get(which, 700)
+    if which.startswith("large_plan"):
+        _debug_knobs(monkeypatch, piece_nodes=40)          # (pieces that compile in seconds)
     rng = np.random.default_rng(len(which))
     X = rng.standard_normal((40, 2, T)).cumsum(axis=2) / 5.0
     fruit = fr.Fruit(which)
@@ -1542,7 +1544,10 @@ def test_fused_kernel_compiled_for_its_pipeline(fr, which, plan_too, monkeypatch
     pipe.prepare(X.shape[0])
     if pipe.jit_loaded() == 0:
         pytest.skip("hipRTC is not installed")
-    assert pipe.jit_loaded(static_only=True) == (1 if plan_too else 0)
+    if which.startswith("large_plan") and plan_too:
+        assert pipe.pieces_loaded() >= 2      # (more than 128 nodes: in pieces, a kernel per piece type)
+    else:
+        assert pipe.jit_loaded(static_only=True) == (1 if plan_too else 0)
     own = fruit.transform(X)
     labels = [fruit.label(i) for i in range(fruit.nfeatures())]
     exact = np.array(["MPI" not in lb for lb in labels])
@@ -1550,6 +1555,84 @@ def test_fused_kernel_compiled_for_its_pipeline(fr, which, plan_too, monkeypatch
     np.testing.assert_allclose(own, generic, rtol=1e-12, atol=1e-300)
     fruit.fit(X)                                   # new thresholds: the compiled kernel is dropped
     assert slc._fused(T).jit_loaded() == 0
+
+
+def _debug_knobs(monkeypatch, **knobs):
+    keep = [v for v in os.environ.get("FRUITS_HIP_DEBUG", "").split(",")
+            if v and v.split("=")[0] not in knobs]
+    monkeypatch.setenv("FRUITS_HIP_DEBUG", ",".join(keep + [f"{k}={v}" for k, v in knobs.items()]))
+
+
+@pytest.mark.parametrize("which", ["indices", "total_inc", "arctic", "chunks", "bands_means", "repeats",
+                                   "high_orders", "bayesian_l1", "wide_root"])
+def test_large_plan_in_pieces(fr, which, monkeypatch):
+    """A plan of more than 128 nodes runs IN PIECES (csrc/plan.h PiecedProgram, walk_fused.h
+    fwalk_pieces): chains walked by the record loop, bodies - whole sub-tries, equal ones one
+    type - as straight-line code, one kernel per type, the features in walk order and gathered
+    back.  Here with small pieces on plans of 60-120 nodes (the knobs piece_min / piece_nodes;
+    seconds of compiler): the same features as the record loop, bit for bit (band means: wave
+    sums meet in LDS in arrival order) - weightings, semirings, several time chunks (carries
+    counted per unit), repeated words (more than two output rows per node), high differencing
+    orders, a root with many small sub-tries."""
+    monkeypatch.setenv("FRUITS_AMD_AUTO_PREPARE", "0")
+    T = {"chunks": 2100, "high_orders": 1500}.get(which, 600)
+    rng = np.random.default_rng(len(which))
+    D = 3 if which == "wide_root" else 2
+    X = rng.standard_normal((24, D, T)).cumsum(axis=2) / 5.0
+    W = fr.iss.weighting
+    mode = fr.ISSMode.EXTENDED
+    if which == "repeats":
+        words, mode = list(fr.words.of_weight(3, dim=2)) * 3 + list(fr.words.of_weight(4, dim=2)), fr.ISSMode.SINGLE
+        kw = dict(weighting=W.Indices())
+    elif which == "wide_root":
+        words = list(fr.words.of_weight(2, dim=3)) + list(fr.words.of_weight(3, dim=3))
+        kw = {}
+    else:
+        words = list(fr.words.of_weight(4, dim=2)) + [fr.words.SimpleWord("[1][-2][11][2]")]
+        kw = {"indices": dict(weighting=W.Indices()),
+              "total_inc": dict(weighting=W.Indices(total=True)),
+              "arctic": dict(semiring=fr.iss.semiring.Arctic(), weighting=W.Indices(total=True)),
+              "chunks": dict(weighting=W.Indices()),
+              "bands_means": dict(weighting=W.Indices()),
+              "high_orders": dict(weighting=W.Indices()),
+              "bayesian_l1": dict(semiring=fr.iss.semiring.Bayesian(), weighting=W.L1())}[which]
+        if which in ("arctic", "bayesian_l1"):
+            words = words[:-1]
+    fruit = fr.Fruit(which)
+    fruit.add(fr.preparation.INC)
+    fruit.add(fr.ISS(words, mode=mode, **kw))
+    if which in ("bands_means", "arctic"):
+        fruit.add(fr.sieving.NPI(q=(0.3, 0.7, 1.0), inc=0), fr.sieving.MPI(q=(0.3, 0.7, 1.0), inc=0),
+                  fr.sieving.NPI(inc=2), fr.sieving.MPI(inc=1), fr.sieving.END)
+    elif which == "high_orders":
+        fruit.add(fr.sieving.NPI(inc=3), fr.sieving.NPI(q=(0.4, 1.0), inc=-1), fr.sieving.END(cut=[T // 2, -1]))
+    else:
+        fruit.add(fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.NPI, fr.sieving.END)
+    fruit.get_slice().fit_sample_size = 1.0
+    np.random.seed(4)
+    fruit.fit(X)
+    slc = fruit.get_slice()
+    pipe = slc._fused(T)
+    assert pipe is not None and pipe.plan.nodes >= 60
+    _debug_knobs(monkeypatch, pieces=0)
+    pipe.prepare(X.shape[0])
+    if pipe.jit_loaded() == 0:
+        pytest.skip("hipRTC is not installed")
+    loop = fruit.transform(X)
+    assert pipe.pieces_loaded() == 0
+    _debug_knobs(monkeypatch, pieces=1, piece_min=50, piece_nodes=20)
+    cover = pipe.plan.pieces(20)
+    assert cover is not None and len(cover["types"]) >= 2
+    pipe.prepare(X.shape[0])
+    assert pipe.pieces_loaded() == len(cover["types"])
+    pieces = fruit.transform(X)
+    labels = [fruit.label(i) for i in range(fruit.nfeatures())]
+    exact = np.array(["MPI" not in lb for lb in labels])
+    np.testing.assert_array_equal(pieces[:, exact], loop[:, exact])
+    np.testing.assert_allclose(pieces, loop, rtol=1e-12, atol=1e-300)
+    np.random.seed(4)
+    fruit.fit(X)                                   # new thresholds: kernels and tables are dropped
+    assert slc._fused(T).pieces_loaded() == 0
 
 
 def test_own_kernel_compiled_in_the_background(fr, tmp_path, monkeypatch):
