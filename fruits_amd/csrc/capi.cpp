@@ -944,7 +944,7 @@ int ensure_pieces_tables(fr_pipeline &pl, const fr::FusedKey &key, const char *w
   fr::PiecedProgram *pp;
   {
     std::lock_guard<std::mutex> lock(p.mu);
-    pp = &fr::pieced(p, max_piece);
+    pp = &fr::pieced(p, max_piece, debug_knob("piece_unit", 0));
     if (!pp->ok) return FR_OK;
     int rc = ensure_piece_tables(p, *pp, who);
     if (rc != FR_OK) return rc;
@@ -1390,7 +1390,13 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
       }
       const int64_t chunk = fr::walk_chunk_elems(T);
       const int64_t F = (int64_t)p.K * fu->pl->per_sum;
-      for (size_t t = 0; t < pp->types.size(); ++t) {
+      // (one launch per type, back to back on the caller's stream.  Forked onto side streams -
+      // normal or low priority - behind an event and joined again the launches were 0.5-2 %
+      // SLOWER on configs 4 / 5: kernels of different code on one CU share its instruction cache)
+      std::vector<size_t> order(pp->types.size());
+      for (size_t t = 0; t < order.size(); ++t) order[t] = t;
+      for (size_t oi = 0; oi < order.size(); ++oi) {
+        const size_t t = order[oi];
         const fr::PieceType &pt = pp->types[t];
         fr::IssArgs b = a;
         b.recs = pt.d_recs;

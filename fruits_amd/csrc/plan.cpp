@@ -404,7 +404,7 @@ GroupedProgram &grouped(Plan &p, int G) {
 }
 
 // The plan in pieces (plan.h, PiecedProgram).
-PiecedProgram &pieced(Plan &p, int max_piece) {
+PiecedProgram &pieced(Plan &p, int max_piece, int unit_nodes_limit) {
   max_piece = std::max(2, std::min(max_piece, 4096));
   auto hit = p.pieced.find(max_piece);
   if (hit != p.pieced.end()) return hit->second;
@@ -586,7 +586,8 @@ PiecedProgram &pieced(Plan &p, int max_piece) {
   int q = 0;
   for (size_t ti = 0; ti < pp.types.size(); ++ti) {
     PieceType &t = pp.types[ti];
-    const int limit = max_piece + max_piece / 2;
+    // (a unit = several items behind one staging of the series' rows: kPieceUnitNodes)
+    const int limit = unit_nodes_limit > 0 ? unit_nodes_limit : std::max(kPieceUnitNodes, max_piece + max_piece / 2);
     int unit_nodes = 0;
     t.unit_begin.push_back(0);
     auto close_unit = [&](int row_end) {

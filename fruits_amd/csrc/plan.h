@@ -171,6 +171,8 @@ StaticSchedule static_schedule(Plan &p, int G);
 GroupedProgram &grouped(Plan &p, int G);
 // The plan in pieces of at most `max_piece` nodes (see PiecedProgram), cached in the plan;
 // !ok: the plan has no such cover (CosWISS, letter sums, nothing to walk).
-PiecedProgram &pieced(Plan &p, int max_piece);
+// (`unit_nodes`: nodes of a unit - a few items of one type on one series; 0: the default.  The
+// first call for a `max_piece` decides.)
+PiecedProgram &pieced(Plan &p, int max_piece, int unit_nodes = 0);
 
 }  // namespace fr

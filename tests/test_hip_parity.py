@@ -1620,7 +1620,9 @@ def test_large_plan_in_pieces(fr, which, monkeypatch):
         pytest.skip("hipRTC is not installed")
     loop = fruit.transform(X)
     assert pipe.pieces_loaded() == 0
-    _debug_knobs(monkeypatch, pieces=1, piece_min=50, piece_nodes=20)
+    # (units of several items behind one staging by default; of one item each on two of the cases)
+    _debug_knobs(monkeypatch, pieces=1, piece_min=50, piece_nodes=20,
+                 piece_unit=1 if which in ("chunks", "repeats") else 0)
     cover = pipe.plan.pieces(20)
     assert cover is not None and len(cover["types"]) >= 2
     pipe.prepare(X.shape[0])

@@ -10,12 +10,18 @@ def stats(sub):
     return list(csv.DictReader(open(f[0]))) if f else []
 
 def pmc(sub):
+    """Counter means per LAUNCH: a plan in pieces is several dispatches per launch (one per piece
+    type, then gather_row_blocks - whose dispatches count the launches); else one."""
     acc = collections.defaultdict(list)
+    launches = collections.Counter()
     for f in glob.glob(f"{root}/{sub}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if any(k in r["Kernel_Name"] for k in KERNELS):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+            if "gather_row_blocks" in r["Kernel_Name"]:
+                launches[r["Counter_Name"]] += 1
+    per = {k: (launches[k] if launches[k] else len(v)) for k, v in acc.items()}
+    return {k: sum(v) / per[k] for k, v in acc.items()}, per
 
 # headline: the driver's command
 rows = stats("bench_trace")
@@ -62,8 +68,17 @@ for t in ("cfg2", "cfg3", "cfg4", "cfg5", "cos1", "cos2"):
     lines.append("# PMC means per dispatch of the walk / coswiss kernels")
     for k in sorted(c):
         lines.append(f"{k:28s} {c[k]:18.1f}")
+    pieces = [r for r in rows if "gather_row_blocks" in r["Name"]]
+    if pieces:
+        n_launch = int(pieces[0]["Calls"])
+        fused = [r for r in rows if any(k in r["Name"] for k in KERNELS)]
+        # (the fit's materialising launch is of another instantiation: MODE 2)
+        fused = [r for r in fused if ", 4, 1, " in r["Name"]]
+        launch_ns = sum(float(r["TotalDurationNs"]) for r in fused) / n_launch
+        lines.append(f"# a plan in pieces: {sum(int(r['Calls']) for r in fused) // n_launch} dispatches per launch, "
+                     f"{launch_ns / 1e3:.1f} us of kernels per launch ({n_launch} launches)")
     if main is not None and "SQ_INSTS_VALU" in c:
-        dur = float(main["AverageNs"]) * 1e-9
+        dur = launch_ns * 1e-9 if pieces else float(main["AverageNs"]) * 1e-9
         # issue roofline: one VALU instruction per SIMD per 4-cycle issue turn; 256 CUs x 4 SIMDs
         clk = 2.4e9
         valu_rate = c["SQ_INSTS_VALU"] / dur
@@ -78,6 +93,9 @@ for t in ("cfg2", "cfg3", "cfg4", "cfg5", "cos1", "cos2"):
             for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA"):
                 if k in c:
                     lines.append(f"# {k} / SQ_WAVE_CYCLES = {c[k] / c['SQ_WAVE_CYCLES']:.3f}")
+        if "GRBM_GUI_ACTIVE" in c:
+            lines.append(f"# clock: GRBM_GUI_ACTIVE {c['GRBM_GUI_ACTIVE']:.3e} / 8 XCDs / {dur*1e6:.1f} us = "
+                         f"{c['GRBM_GUI_ACTIVE'] / 8 / dur / 1e9:.2f} GHz while the kernels run")
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             lines.append(f"# HBM traffic per launch: read {2 * c['FETCH_SIZE'] * 1024 / 1e6:.1f} MB (FETCH_SIZE x2), "
                          f"write {c['WRITE_SIZE'] * 1024 / 1e6:.1f} MB")
