@@ -15,14 +15,19 @@ Two things are then measured:
 * the headline ``value``: every rank processes its own batch of the workload above
   (the path is independent per series: weak scaling, no data-path collective), the
   timed region is bracketed by barrier + synchronize, the slowest rank counts;
-* ``word_sharded_config4``: north_star's multi-GPU split - BASELINE configs[3], the
-  ``fruit_general`` word set ``of_weight(6, 2)`` + ``Indices`` on ``(8192, 3, 1024)``
-  with the WORD LIST sharded over the ranks (``fruits_amd.parallel``): every rank
-  holds the whole batch, computes the feature columns of its sub-tries in one fused
-  launch, and one RCCL all-gather (+ a column permutation) assembles the reference's
-  ``(N, F)`` feature matrix on every rank.  Reported: slowest rank's launch, the
-  all-gather, bytes gathered, end to end, and a check against the unsharded
+* ``word_sharded_config4``: north_star's multi-GPU split through the PRODUCT entry
+  ``fruits_amd.parallel.transform_sharded`` - BASELINE configs[3], the ``fruit_general``
+  word set ``of_weight(6, 2)`` + ``Indices`` on ``(8192, 3, 1024)``: the batch exists on rank 0
+  only and is broadcast device to device, the fruit is fitted on rank 0, every rank computes
+  the feature columns of its sub-tries in one fused launch, one RCCL all-gather and one column
+  gather assemble the reference's ``(N, F)`` on every rank; checked against the unsharded
   transform on rank 0.
+
+N = 1 adds, INSIDE the ``roofline`` object (the driver's record keeps it verbatim):
+``secondary`` - the metric's 48-word reading, of_weight(4,2) materialised (K = 115), what the box
+copies, and the fused pipelines of configs[2..4] on one GPU (us, fraction; for the fused ones the
+VALU issue fraction of the last committed profile) - and ``sweep_N_T_static_interp``; ``extras``
+holds ``cold_start`` (an empty user cache of run-time compiled kernels).
 
 ``FRUITS_BENCH_BACKEND=gloo`` rehearses the N > 1 path on a box with fewer GPUs than
 ranks (ranks share devices, the collective is staged through the host).
@@ -214,37 +219,17 @@ def _config4(torch, fr, nat, Xd=None, fit_on_root=None):
                      n_fit=128, Xd=Xd, fit_on_root=fit_on_root)
 
 
-def _broadcast_batch(torch, dist, shape, rank, backend):
-    """The batch generated ONCE, on rank 0, and broadcast device to device (RCCL; a gloo
-    rehearsal stages it through the host) - instead of every rank generating / uploading it."""
-    t0 = time.perf_counter()
-    Xd = (_device_batch(torch, shape, 0) if rank == 0
-          else torch.empty(shape, dtype=torch.float64, device="cuda"))
-    if backend == "nccl":
-        dist.broadcast(Xd, src=0)
-    else:
-        host = Xd.cpu()
-        dist.broadcast(host, src=0)
-        Xd.copy_(host)
-    torch.cuda.synchronize()
-    return Xd, (time.perf_counter() - t0) * 1e3
-
-
-def sweep(torch, fr, nat, dev, copy_GBs, budget_s=25.0):
+def sweep(torch, fr, nat, dev, budget_s=25.0):
     """The materialising walk of of_weight(2,3) EXTENDED (K = 18) over N x T, once with the
-    pre-compiled static program and once through the record interpreter (FRUITS_HIP_STATIC=0),
-    and of_weight(4,2) EXTENDED (K = 115, no static program) at the headline shape; every cell
-    with its fraction of the 8 TB/s spec and of the copy rate measured on this box.  Cells are
-    dropped when the time budget is spent (largest first kept: the order below)."""
+    pre-compiled static program and once without (FRUITS_HIP_STATIC=0: the record interpreter /
+    the lean materialising walk): rows [N, T, fraction of 8 TB/s with, without].  Cells are
+    dropped when the time budget is spent."""
     t_start = time.perf_counter()
-    cells = []
     w2 = fr.words.of_weight(2, dim=N_DIMS)
+    plan = fr.ISS(w2, mode=fr.ISSMode.EXTENDED)._plan(0, len(w2))
+    K = plan.rows
 
-    def cell(words, N, T, static):
-        plan = fr.ISS(words, mode=fr.ISSMode.EXTENDED)._plan(0, len(words))
-        K = plan.rows
-        if 8.0 * N * T * (plan.dims_used + K) > 40e9:
-            return None
+    def frac(N, T, static):
         prev = os.environ.get("FRUITS_HIP_STATIC")
         os.environ["FRUITS_HIP_STATIC"] = "1" if static else "0"
         try:
@@ -258,55 +243,122 @@ def sweep(torch, fr, nat, dev, copy_GBs, budget_s=25.0):
                 os.environ.pop("FRUITS_HIP_STATIC", None)
             else:
                 os.environ["FRUITS_HIP_STATIC"] = prev
-        b_alg = 8.0 * N * T * (plan.dims_used + K)
-        gbs = b_alg / (t * 1e-6) / 1e9
         del Xs, buf
-        return {"words": f"of_weight({len(words)} words)", "K": K, "N": N, "T": T,
-                "path": "static program" if static else "interpreter", "kernel_us": t,
-                "GBs": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS, "frac_of_on_box_copy": gbs / copy_GBs}
-    order = [(w2, 2048, 1024), (w2, 8192, 1024), (w2, 512, 1024), (w2, 1024, 1024), (w2, 3072, 1024),
-             (w2, 4096, 1024), (w2, 16384, 1024), (w2, 2048, 4096), (w2, 8192, 256), (w2, 2048, 256),
-             (w2, 512, 4096), (w2, 8192, 4096), (w2, 512, 256), (w2, 16384, 256)]
-    for words, N, T in order:
-        for static in (True, False):
-            if time.perf_counter() - t_start > budget_s:
-                break
-            c = cell(words, N, T, static)
-            if c is not None:
-                cells.append(c)
+        return round(8.0 * N * T * (plan.dims_used + K) / (t * 1e-6) / 1e9 / HBM_PEAK_GBS, 3)
+    rows = []
+    order = [(2048, 1024), (8192, 1024), (512, 1024), (1024, 1024), (3072, 1024), (4096, 1024),
+             (16384, 1024), (2048, 4096), (8192, 256), (2048, 256), (512, 4096), (8192, 4096),
+             (512, 256), (16384, 256)]
+    for N, T in order:
+        if time.perf_counter() - t_start > budget_s:
+            break
+        rows.append([N, T, frac(N, T, True), frac(N, T, False)])
         torch.cuda.empty_cache()
-    if time.perf_counter() - t_start <= budget_s + 5.0:
-        c = cell(fr.words.of_weight(4, dim=2), N_SERIES, N_STEPS_T, True)
-        if c is not None:
-            c["path"] = "lean materialising walk (115 nodes: no static program; DESIGN.md 4.1c)"
-            cells.append(c)
-    return {"cells": cells, "on_box_copy_GBs": copy_GBs,
-            "note": "static programs cover T in (512, 1024]; other lengths run the interpreter "
-                    "(or the wave-per-series kernels for T <= 384) on both lines; 'interpreter' = "
-                    "no static program: the record interpreter, and from two resident rounds of "
-                    "workgroups on the lean materialising walk (DESIGN.md 4.1c)"}
+    return rows
+
+
+def _issue_fractions():
+    """VALU issue fractions of the fused launches from the last committed profile run
+    (profiles/fused_issue.json, written from rocprofv3 SQ counters: not measured in this run)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "fused_issue.json")) as f:
+            return json.load(f)
+    except Exception:
+        return {}
+
+
+def _fused_entry(p, pipe, t_us, issue, key):
+    """A fused pipeline's launch for roofline.secondary: these launches write (N, F) only, so the
+    bound that applies is vector issue (profiles/), not HBM; `equiv_frac` = what a materialising
+    launch of the same sums would have to stream, as a fraction of 8 TB/s (labelled: above 1 by
+    construction - avoided traffic, not bandwidth)."""
+    K, d_used = pipe.plan.rows, pipe.plan.dims_used
+    equiv = 8.0 * p.N * p.T * (d_used + K) / (t_us * 1e-6) / 1e9
+    e = {"us": round(t_us, 1), "K": K, "nodes": pipe.plan.nodes,
+         "elements_per_s": float(f"{p.N * K * p.T / (t_us * 1e-6):.4g}"),
+         "equiv_frac": round(equiv / HBM_PEAK_GBS, 3),
+         "kernel": ("pieces" if pipe.pieces_loaded() else
+                    "straight-line plan" if pipe.jit_loaded(static_only=True) else
+                    "own sieves" if pipe.jit_loaded() else "generic")}
+    if key in issue:
+        e["valu_issue_frac"] = issue[key]
+    return e
+
+
+def _bench_fruit(fr, words, weighting, sieves):
+    fruit = fr.Fruit("bench")
+    fruit.add(fr.preparation.INC)
+    fruit.add(fr.ISS(words, mode=fr.ISSMode.EXTENDED, weighting=weighting))
+    fruit.add(*sieves)
+    fruit.get_slice().fit_sample_size = 1.0
+    return fruit
+
+
+def cold_start(torch, fr, nat, which):
+    """What a one-shot user sees on a machine that has never run this fruit: an EMPTY user
+    cache of run-time compiled kernels (FRUITS_HIP_JIT_CACHE = a fresh directory; the kernels
+    shipped with the build, fruits_amd/jit_bundle, are still there).  ms of the first
+    Fruit.transform, of the transforms while a compilation runs in the background, seconds until
+    the compiled kernels take over, ms after."""
+    import tempfile
+    prev = {k: os.environ.get(k) for k in ("FRUITS_HIP_JIT_CACHE", "FRUITS_AMD_AUTO_PREPARE")}
+    os.environ["FRUITS_HIP_JIT_CACHE"] = tempfile.mkdtemp(prefix="fruits_cold_")
+    os.environ["FRUITS_AMD_AUTO_PREPARE"] = "1"
+    try:
+        shape, words = {"cfg3": ((2048, 3, 1024), fr.words.of_weight(4, dim=2)),
+                        "cfg4": ((8192, 3, 1024), fr.words.of_weight(6, dim=2))}[which]
+        X = np.random.default_rng(0).standard_normal(shape)
+        fruit = _bench_fruit(fr, words, fr.iss.weighting.Indices(),
+                             [fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END])
+        np.random.seed(0)
+        fruit.fit(X[:128])
+
+        def once():
+            t0 = time.perf_counter()
+            fruit.transform(X)
+            return (time.perf_counter() - t0) * 1e3
+        first = once()
+        pipe = fruit.get_slice()._fused(shape[2])
+
+        def compiled():
+            return pipe.pieces_loaded() > 0 or pipe.jit_loaded(static_only=True) > 0
+        on_first = compiled()
+        during, t_start = [], time.perf_counter()
+        while not compiled() and time.perf_counter() - t_start < 90.0:
+            during.append(once())
+        takeover = time.perf_counter() - t_start
+        pending = getattr(pipe, "_pending", None)
+        if pending is not None:
+            pending.result(timeout=120)
+        after = sorted(once() for _ in range(3))[1]
+        return {"first_transform_ms": round(first, 1), "compiled_kernels_on_first_launch": bool(on_first),
+                "transform_ms_while_compiling": round(float(np.median(during)), 1) if during else None,
+                "seconds_until_compiled": round(takeover, 1) if not on_first else 0.0,
+                "transform_ms_after": round(after, 1), "took_over": bool(compiled()),
+                "note": "Fruit.transform end to end (upload of X, launch, download of the features)"}
+    finally:
+        for k, v in prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def extras(torch, fr, nat, dev, quick=False):
-    """Secondary measurements on the same GPU (not the headline value): the metric's
-    "48 words" reading, what the box streams, and the fused pipelines of BASELINE
-    configs[2], [3] and [4] on ONE GPU."""
-    out = {}
+    """Secondary measurements on the same GPU (not the headline value).  Returns (secondary,
+    sweep, details): `secondary` and `sweep` go INTO the roofline object (the driver's record
+    keeps that verbatim), the details into `extras`."""
+    sec, det = {}, {}
+    issue = _issue_fractions()
     rng = np.random.default_rng(0)
     X = rng.standard_normal((N_SERIES, N_DIMS, N_STEPS_T))
     Xd = nat.to_device(X)
-    # (a) words[i % 15] tiled to 48, SINGLE mode: K = 48 rows, 855.6 MB algorithmic
+    # (a) the metric's "48 words": words[i % 15] tiled to 48, SINGLE mode, K = 48, 855.6 MB
     w15 = fr.words.of_weight(2, dim=N_DIMS)
-    w48 = [w15[i % 15] for i in range(48)]
-    plan = fr.ISS(w48)._plan(0, 48)
-    # (not one of the pre-compiled word sets: fr_plan_prepare compiles its static program with
-    # hipRTC - once, cached on disk - as a caller that launches a plan repeatedly would)
-    plan.prepare(N_SERIES, N_STEPS_T)
-    # (the time of this launch depends on where the driver places its 805 MB output: the same
-    # kernel in the same process reads 150 us on one allocation and 166 us on the next, stable
-    # within an allocation - three placements, the median is the figure)
+    plan = fr.ISS([w15[i % 15] for i in range(48)])._plan(0, 48)
+    plan.prepare(N_SERIES, N_STEPS_T)     # (its static program: hipRTC, cached on disk)
     placements, shift = [], []
-    for trial in range(3):
+    for trial in range(3):                # (the time depends on where the 805 MB output lies)
         buf = torch.empty((48, N_SERIES, N_STEPS_T), dtype=torch.float64, device=dev)
         placements.append(_event_time_us(torch, lambda: plan.run(Xd, None, out=buf)))
         del buf
@@ -316,211 +368,137 @@ def extras(torch, fr, nat, dev, quick=False):
     torch.cuda.empty_cache()
     t = float(np.median(placements))
     b_alg = 8.0 * N_SERIES * N_STEPS_T * (3 + 48)
-    out["words48_single"] = {"kernel_us": t, "elements_per_s": N_SERIES * 48 * N_STEPS_T / (t * 1e-6),
-                             "GBs": b_alg / (t * 1e-6) / 1e9, "frac": b_alg / (t * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                             "placements_us": placements,
-                             "best_placement_frac": b_alg / (min(placements) * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                             "static_programs_compiled_at_run_time": plan.jit_loaded()}
-    # (a') what this box sustains (SURVEY.md 8d asks for an on-box peak next to the 8 TB/s
-    # spec): a device fill and a device-to-device copy of the size of the output tensor
+    sec["words48"] = {"us": round(t, 1), "frac": round(b_alg / (t * 1e-6) / 1e9 / HBM_PEAK_GBS, 3),
+                      "placements_us": [round(v, 1) for v in placements]}
+    # (a') of_weight(4,2) EXTENDED, K = 115, materialised (1.9 GB): three placements too
+    w42 = fr.words.of_weight(4, dim=2)
+    plan = fr.ISS(w42, mode=fr.ISSMode.EXTENDED)._plan(0, len(w42))
+    plan.prepare(N_SERIES, N_STEPS_T)
+    placements = []
+    for trial in range(3):
+        buf = torch.empty((plan.rows, N_SERIES, N_STEPS_T), dtype=torch.float64, device=dev)
+        placements.append(_event_time_us(torch, lambda: plan.run(Xd, None, out=buf), reps=5))
+        del buf
+        torch.cuda.empty_cache()
+    t = float(np.median(placements))
+    b_alg = 8.0 * N_SERIES * N_STEPS_T * (plan.dims_used + plan.rows)
+    sec["K115"] = {"us": round(t, 1), "frac": round(b_alg / (t * 1e-6) / 1e9 / HBM_PEAK_GBS, 3),
+                   "placements_us": [round(v, 1) for v in placements]}
+    # (a'') what this box streams: fill / copy of a buffer of the headline tensor's size
     big = torch.empty((18, N_SERIES, N_STEPS_T), dtype=torch.float64, device=dev)
     big2 = torch.empty_like(big)
     t_fill = _event_time_us(torch, lambda: big.fill_(1.0))
     t_copy = _event_time_us(torch, lambda: big2.copy_(big))
     nbytes = big.numel() * 8
-    out["on_box_stream"] = {"fill_GBs": nbytes / (t_fill * 1e-6) / 1e9,
-                            "copy_read_plus_write_GBs": 2 * nbytes / (t_copy * 1e-6) / 1e9,
-                            "bytes": nbytes,
-                            "note": "torch fill_ / copy_ of a buffer of the (K,N,T) tensor's size"}
+    copy_GBs = 2 * nbytes / (t_copy * 1e-6) / 1e9
+    sec["on_box_copy"] = {"GBs": round(copy_GBs), "frac": round(copy_GBs / HBM_PEAK_GBS, 3),
+                          "fill_GBs": round(nbytes / (t_fill * 1e-6) / 1e9)}
     del big, big2
-    # (b) config 3 shape: INC -> ISS(of_weight(4,2) EXTENDED, Indices) -> NPI(q=(.5,1)), END: one
-    # fused launch on the raw batch
+    # (b) config 3: INC -> ISS(of_weight(4,2) EXTENDED, Indices) -> NPI(q=(.5,1)), END, one launch
     p3 = _Pipeline(torch, fr, nat, (N_SERIES, N_DIMS, N_STEPS_T), fr.words.of_weight(4, dim=2),
                    fr.iss.weighting.Indices(), [fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END],
                    n_fit=128, Xd=Xd)
     fn, _, pipe3 = p3.launch()
-    t = _event_time_us(torch, fn)
-    p3.fruit.transform(X)   # first call builds plans / uploads tables
-    t0 = time.perf_counter()
-    p3.fruit.transform(X)
-    e2e = time.perf_counter() - t0
-    out["config3_fused_pipeline"] = dict(
-        p3.figures(pipe3, t), fruit_transform_end_to_end_ms=e2e * 1e3,
-        workload="BASELINE configs[2] shape: of_weight(4,2) EXTENDED + Indices, (2048,3,1024), "
-                 "INC -> ISS -> NPI(q=(0.5,1)), END, one fused launch")
+    sec["cfg3"] = _fused_entry(p3, pipe3, _event_time_us(torch, fn), issue, "cfg3")
     del p3, fn, pipe3
-    # (b') the shape sweep: what the materialising walk reaches away from the headline shape
-    out["sweep"] = sweep(torch, fr, nat, dev, out["on_box_stream"]["copy_read_plus_write_GBs"],
-                         budget_s=4.0 if quick else 25.0)
+    sweep_rows = sweep(torch, fr, nat, dev, budget_s=4.0 if quick else 25.0)
     del Xd
     if quick:
-        return out
-    # (c) config 4 on ONE GPU: fruit_general's of_weight(6,2) + Indices, (8192,3,1024),
-    # INC -> ISS -> NPI(q=(.5,1)), END; K = 1351 (the reference's tensor would be 90 GB)
+        return sec, sweep_rows, det
+    # (c) config 4 on ONE GPU: of_weight(6,2) + Indices, (8192,3,1024); K = 1351
     p4 = _config4(torch, fr, nat)
     fn, _, pipe4 = p4.launch()
-    out["config4_single_gpu"] = dict(
-        p4.figures(pipe4, _event_time_us(torch, fn, reps=5)),
-        workload="BASELINE configs[3] on one GPU: of_weight(6,2) EXTENDED + Indices, raw "
-                 "(8192,3,1024) in, INC -> ISS -> NPI(q=(0.5,1)), END, one fused launch")
+    sec["cfg4"] = _fused_entry(p4, pipe4, _event_time_us(torch, fn, reps=5), issue, "cfg4")
     del p4, fn, pipe4
     torch.cuda.empty_cache()
-    # (d) config 5 on ONE GPU: fruit_twi slice 1, of_weight(9,1) + L1, (8192,6,4096)
+    # (d) config 5 on ONE GPU: of_weight(9,1) + L1, (8192,6,4096), four time chunks
     p5 = _Pipeline(torch, fr, nat, (8192, 6, 4096), fr.words.of_weight(9, dim=1),
                    fr.iss.weighting.L1(), [fr.sieving.NPI, fr.sieving.END], n_fit=32)
     fn, _, pipe5 = p5.launch()
-    out["config5_single_gpu"] = dict(
-        p5.figures(pipe5, _event_time_us(torch, fn, reps=3)),
-        workload="BASELINE configs[4] on one GPU: of_weight(9,1) EXTENDED + L1, (8192,6,4096) "
-                 "(N chosen: SURVEY.md 0.3), INC -> ISS -> NPI, END, one fused launch over 4 "
-                 "time chunks")
+    sec["cfg5"] = _fused_entry(p5, pipe5, _event_time_us(torch, fn, reps=3), issue, "cfg5")
     del p5, fn, pipe5
     torch.cuda.empty_cache()
-    return out
+    # (e) a cold machine
+    det["cold_start"] = {w: cold_start(torch, fr, nat, w) for w in ("cfg3", "cfg4")}
+    torch.cuda.empty_cache()
+    return sec, sweep_rows, det
 
 
 # --------------------------------------------------------------------------- word-sharded config 4
 def word_sharded_config4(torch, fr, nat, dist, rank, world, backend):
-    """BASELINE configs[3]: the word list of fruit_general's first slice sharded over the
-    ranks, features all-gathered (fruits_amd.parallel).  Every rank holds the same batch."""
+    """BASELINE configs[3] through the PRODUCT entry, fruits_amd.parallel.transform_sharded: the
+    batch exists on rank 0 only (the others pass None: uploaded once, broadcast device to
+    device), the fruit is fitted on rank 0 (state broadcast), the word list of the slice is
+    sharded over the ranks by sub-trie, every rank one fused launch on the raw batch, one padded
+    all-gather of the (N, F_r) blocks + ONE column gather."""
     from fruits_amd import parallel as par
-    Xd, bcast_ms = _broadcast_batch(torch, dist, (8192, 3, 1024), rank, backend)
+    shape = (8192, 3, 1024)
+    Xd = _device_batch(torch, shape, 0) if rank == 0 else None
+    fruit = _bench_fruit(fr, fr.words.of_weight(6, dim=2), fr.iss.weighting.Indices(),
+                         [fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END])
+    np.random.seed(0)
     t0 = time.perf_counter()
-    p = _config4(torch, fr, nat, Xd=Xd, fit_on_root=(rank, world))
+    par.fit_on_root(fruit, Xd[:128].cpu().numpy() if rank == 0 else None, rank, world)
     fit_ms = (time.perf_counter() - t0) * 1e3
-    N, T = p.N, p.T
-    parts = par.shard_words(p.strings, p.depths, world)
-    maps = par.column_map(parts, p.depths, p.per_sum)
-    n_features = p.slc.nfeatures()
-    fn, local, pipe = p.launch(indices=parts[rank])
-    # (1) the rank's fused launch alone
-    fn()
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(5):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        fn()
-        b.record()
-        b.synchronize()
-        ts.append(a.elapsed_time(b))
-    my_ms = float(np.median(ts))
-    # (2) the all-gather alone and (3) launch + gather + permutation, device resident
-    par.gather_features(local, maps, n_features, rank, world)   # warm-up (RCCL channel set-up)
-    gather_ms, e2e_ms = [], []
-    full = None
+    par.transform_sharded(fruit, Xd, rank, world, on_device=True)      # (plans, tables, kernels, RCCL set-up)
+    par.transform_sharded(fruit, Xd, rank, world, on_device=True)
+    runs, full = [], None
     for _ in range(5):
         dist.barrier()
         torch.cuda.synchronize()
         tm = {}
-        par.gather_features(local, maps, n_features, rank, world, timings=tm)
-        gather_ms.append(tm.get("allgather_s", 0.0) * 1e3)
-        dist.barrier()
-        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        fn()
-        full = par.gather_features(local, maps, n_features, rank, world)
+        full = par.transform_sharded(fruit, Xd, rank, world, on_device=True, timings=tm)
         torch.cuda.synchronize()
-        e2e_ms.append((time.perf_counter() - t0) * 1e3)
-    mine = {"rank": rank, "launch_ms": my_ms, "allgather_ms": float(np.median(gather_ms)),
-            "end_to_end_ms": float(np.median(e2e_ms)), "K": pipe.plan.rows,
-            "features": pipe.n_features, "nodes": pipe.plan.nodes}
+        tm["end_to_end_s"] = time.perf_counter() - t0
+        runs.append(tm)
+    med = {k: float(np.median([r[k] for r in runs])) for k in ("broadcast_s", "compute_s", "gather_s", "end_to_end_s")}
+    slc = fruit.get_slice()
+    iss = slc.get_iss()[0]
+    strings = [str(w) for w in iss.words]
+    depths = [iss._depth(i) for i in range(len(strings))]
+    mine_words = par.shard_words(strings, depths, world)[rank]
+    pipe = slc._fused(shape[2], indices=mine_words)
+    mine = {"rank": rank, "launch_ms": med["compute_s"] * 1e3, "gather_ms": med["gather_s"] * 1e3,
+            "broadcast_ms": med["broadcast_s"] * 1e3, "end_to_end_ms": med["end_to_end_s"] * 1e3,
+            "K": pipe.plan.rows, "nodes": pipe.plan.nodes,
+            "gathered_bytes_per_rank": runs[-1].get("gathered_bytes_per_rank", 0),
+            "kernel": "pieces" if pipe.pieces_loaded() else ("own" if pipe.jit_loaded() else "generic")}
     everyone = [None] * world
     dist.all_gather_object(everyone, mine)
-    series_leg = series_sharded_config4(torch, dist, rank, world, backend, p)
     if rank != 0:
         return None
-    # (4) rank 0: the unsharded transform of the same batch, every column compared
-    fn1, feats1, pipe1 = p.launch()
+    # rank 0: the unsharded transform of the same batch, every column compared
+    cache = fr.cache.SharedSeedCache(None)
+    cache.adopt_device_input(Xd)
+    slc._attach(cache)
+    whole = slc._fused(shape[2])
+    chain = slc._fusable_preparation(shape[2])
+    assert whole.set_preparation(shape[1], *chain)
+    whole.prepare(shape[0])
+    lk = iss.lookup_device(Xd)
+    ref = torch.empty((shape[0], whole.n_features), dtype=torch.float64, device="cuda")
+    fn1 = lambda: whole.run(Xd, lk, feats=ref)
     t_one = _event_time_us(torch, fn1, reps=3) / 1e3
-    fn1()
     torch.cuda.synchronize()
-    diff = (full - feats1).abs()
-    cols_ok = int((diff.max(dim=0).values == 0).sum().item())
+    cols_ok = int(((full - ref).abs().max(dim=0).values == 0).sum().item())
     launches = [e["launch_ms"] for e in everyone]
     e2e = max(e["end_to_end_ms"] for e in everyone)
-    width = max(len(m) for m in maps)
-    K_total = pipe1.plan.rows
+    K_total = whole.plan.rows
     return {
-        "workload": "BASELINE configs[3]: fruit_general slice-1 word set of_weight(6,2) EXTENDED + "
-                    "Indices, (8192,3,1024) float64 on EVERY rank, INC -> ISS -> NPI(q=(0.5,1)), END; "
-                    "word list sharded over the ranks by sub-trie, one fused launch per rank, one "
-                    "padded all_gather_into_tensor of the (N, F_r) blocks + column permutation",
-        "backend": backend + (" (RCCL over xGMI)" if backend == "nccl" else " (host-staged rehearsal)"),
-        "world_size": dist.get_world_size(), "N": N, "D": p.D, "T": T, "words": len(p.strings),
-        "K": K_total, "features": n_features,
-        "rank_launch_ms": launches, "slowest_launch_ms": max(launches),
-        "balance": float(np.mean(launches) / max(launches)),
-        "K_per_rank": [e["K"] for e in everyone], "nodes_per_rank": [e["nodes"] for e in everyone],
-        "allgather_ms": max(e["allgather_ms"] for e in everyone),
-        "gathered_bytes_per_rank": int(N * width * 8),
-        "gathered_bytes_total": int(world * N * width * 8),
-        "end_to_end_ms": e2e,
-        "elements_per_s": N * K_total * T / (e2e * 1e-3),
-        "single_rank_unsharded_launch_ms": t_one,
-        "speedup_vs_single_rank_launch": t_one / e2e,
-        "equals_unsharded_transform": bool(cols_ok == n_features),
-        "columns_checked": n_features, "columns_bit_identical": cols_ok,
-        "max_abs_diff": float(diff.max().item()),
-        "batch": f"generated on rank 0, broadcast to the ranks ({bcast_ms:.1f} ms incl. generation)",
-        "fit": f"on rank 0 only, fitted state broadcast (pipeline set-up {fit_ms:.1f} ms on rank 0)",
-        "series_sharded_config4": None if series_leg is None else dict(
-            series_leg, single_rank_unsharded_launch_ms=t_one,
-            equals_unsharded_transform=bool((series_leg.pop("_full") == feats1).all().item())),
-    }
-
-
-def series_sharded_config4(torch, dist, rank, world, backend, p):
-    """The same workload with the SERIES sharded instead: every rank runs the whole word list
-    (one fused launch) on its N / world rows of the batch - no collective on the data path."""
-    from fruits_amd import parallel as par
-    nat = p.nat
-    rows = par.shard_series(p.N, rank, world)
-    Xr = p.Xd[rows].contiguous()
-    n_r = int(Xr.shape[0])
-    pipe = p.slc._fused(p.T)
-    assert pipe.set_preparation(p.D, *p.chain) and p.lk.shape[0] == 1
-    feats = torch.empty((n_r, pipe.n_features), dtype=torch.float64, device="cuda")
-    wb = int(nat.lib().fr_pipeline_workspace_bytes(pipe._h, n_r, 1))
-    work = torch.empty(max(wb, 1), dtype=torch.uint8, device="cuda")
-    pipe.prepare(n_r)
-    fn = lambda: pipe.run(Xr, p.lk, feats=feats, work=work)
-    fn()
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(5):
-        dist.barrier()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        fn()
-        b.record()
-        b.synchronize()
-        ts.append(a.elapsed_time(b))
-    everyone = [None] * world
-    dist.all_gather_object(everyone, {"rank": rank, "rows": n_r, "launch_ms": float(np.median(ts))})
-    # for the check only (not part of the path): the row blocks assembled on rank 0
-    tallest = max(e["rows"] for e in everyone)
-    padded = torch.zeros((tallest, pipe.n_features), dtype=torch.float64, device="cuda")
-    padded[:n_r] = feats
-    if backend == "nccl":
-        flat = torch.empty((world * tallest, pipe.n_features), dtype=torch.float64, device="cuda")
-        dist.all_gather_into_tensor(flat, padded)
-    else:
-        flat_h = torch.empty((world * tallest, pipe.n_features), dtype=torch.float64)
-        dist.all_gather_into_tensor(flat_h, padded.cpu())
-        flat = flat_h.cuda()
-    if rank != 0:
-        return None
-    blocks = flat.view(world, tallest, pipe.n_features)
-    full = torch.cat([blocks[r, :everyone[r]["rows"]] for r in range(world)], dim=0)
-    launches = [e["launch_ms"] for e in everyone]
-    return {
-        "workload": "BASELINE configs[3] with the series sharded: every rank the whole word list "
-                    "(K = 1351) on N / world rows, one fused launch, no data-path collective",
-        "rows_per_rank": [e["rows"] for e in everyone], "rank_launch_ms": launches,
-        "slowest_launch_ms": max(launches), "balance": float(np.mean(launches) / max(launches)),
-        "elements_per_s": p.N * pipe.plan.rows * p.T / (max(launches) * 1e-3),
-        "_full": full,
+        "workload": "BASELINE configs[3]: of_weight(6,2) EXTENDED + Indices, (8192,3,1024) f64, INC -> ISS -> "
+                    "NPI(q=(0.5,1)), END through fruits_amd.parallel.transform_sharded (batch on rank 0 only)",
+        "backend": backend, "world_size": dist.get_world_size(), "K": K_total, "features": int(full.shape[1]),
+        "rank_launch_ms": [round(v, 3) for v in launches], "slowest_launch_ms": round(max(launches), 3),
+        "balance": round(float(np.mean(launches) / max(launches)), 3),
+        "nodes_per_rank": [e["nodes"] for e in everyone], "kernels": sorted({e["kernel"] for e in everyone}),
+        "broadcast_ms": round(max(e["broadcast_ms"] for e in everyone), 3),
+        "allgather_and_column_gather_ms": round(max(e["gather_ms"] for e in everyone), 3),
+        "gathered_bytes_per_rank": everyone[0]["gathered_bytes_per_rank"],
+        "end_to_end_ms": round(e2e, 3), "elements_per_s": shape[0] * K_total * shape[2] / (e2e * 1e-3),
+        "single_rank_unsharded_launch_ms": round(t_one, 3),
+        "equals_unsharded_transform": bool(cols_ok == full.shape[1]), "columns_bit_identical": cols_ok,
+        "fit_on_root_ms": round(fit_ms, 1),
     }
 
 
@@ -668,7 +646,11 @@ def main() -> None:
         if rank == 0:
             res["word_sharded_config4"] = ws
     if rank == 0 and world == 1 and not args.no_extras:
-        res["extras"] = extras(torch, fr, nat, dev, quick=args.quick_extras)
+        sec, sweep_rows, det = extras(torch, fr, nat, dev, quick=args.quick_extras)
+        # (inside the roofline object: the driver's record keeps that verbatim)
+        res["roofline"]["secondary"] = sec
+        res["roofline"]["sweep_N_T_static_interp"] = sweep_rows
+        res["extras"] = det
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(words)
     if distributed:

@@ -546,12 +546,25 @@ class Pipeline:
             nodes = self.plan.nodes
             self.prepare(N, groups, plan_too=nodes <= self.QUICK_PLAN_NODES or nodes > 128)
         self._pending = _prepare_pool().submit(work)
+
+        def report(fut):     # (nobody may ever call result(): a failure is said once, not swallowed)
+            err = fut.exception()
+            if err is not None:
+                import warnings
+                warnings.warn(f"fruits_amd: compiling a pipeline's own kernels failed ({err}); "
+                              "the generic kernel keeps running it", RuntimeWarning)
+        self._pending.add_done_callback(report)
         return self._pending
 
     def jit_loaded(self, static_only: bool = False) -> int:
         """Run-time compiled kernels this pipeline holds (``static_only``: those with the plan
         as straight-line code)."""
         return int(lib().fr_pipeline_info(self._h, 4 if static_only else 3))
+
+    def fully_compiled(self) -> bool:
+        """Whether the pipeline already holds the kernels a ``prepare`` would give it: the plan's
+        own (in pieces, or as straight-line code) - nothing left for a compiler to do."""
+        return self.pieces_loaded() > 0 or self.jit_loaded(static_only=True) > 0
 
     def pieces_loaded(self) -> int:
         """Kernels of piece types this pipeline holds (a large plan in pieces)."""

@@ -778,6 +778,7 @@ struct fr_pipeline {
   struct Pieces {
     int max_piece = 0, device = -1;
     std::vector<fr::JitProgram> progs;   // one per piece type; empty: not compiled (yet)
+    std::vector<char> fits;              // per type: compiled for units whose features fit the window
     void *d_tables = nullptr;
     const fr::FeatOp *d_ops_walk = nullptr;
     const int32_t *d_walk_of_row = nullptr;
@@ -983,6 +984,17 @@ int ensure_pieces_tables(fr_pipeline &pl, const fr::FusedKey &key, const char *w
   return FR_OK;
 }
 
+// LDS of a launch of piece type `pt` next to the feature window, and the window (0: none fits)
+size_t piece_other_lds(const fr::Plan &p, const fr::PieceType &pt, int64_t T, int carry_per_node) {
+  const int64_t chunk = fr::walk_chunk_elems(T);
+  return ((size_t)p.rows_staged() * chunk + 24 + (T > chunk ? (size_t)carry_per_node * pt.max_unit_nodes : 0)) * 8;
+}
+int piece_window(const fr::Plan &p, const fr::PieceType &pt, int64_t T, int carry_per_node, int n_ops,
+                 bool mpi, bool &fits) {
+  return feat_window_sized(pt.widest_node * n_ops, pt.max_unit_rows * n_ops,
+                           piece_other_lds(p, pt, T, carry_per_node), mpi, fits);
+}
+
 int piece_level_variant(int levels) { return levels <= 2 ? 2 : (levels <= 4 ? 4 : (levels <= 6 ? 6 : 8)); }
 
 // Compiles (hipRTC, one helper thread per piece type; disk cache) and loads the kernels of the
@@ -993,6 +1005,8 @@ void ensure_fused_pieces(fr_pipeline &pl, const fr::FusedKey &key, bool cache_on
   fr::FusedOps ops;
   uint64_t gen;
   int max_piece;
+  const int n_ops_eff = pl.n_ops_eff;
+  const bool has_mpi = !pl.mpi_cols.empty();
   {
     std::lock_guard<std::mutex> lock(pl.jit_mu);
     auto it = pl.jit_pieces.find(id);
@@ -1012,7 +1026,7 @@ void ensure_fused_pieces(fr_pipeline &pl, const fr::FusedKey &key, bool cache_on
   const int n_types = (int)pp->types.size();
   std::vector<fr::JitProgram> progs(n_types);
   std::vector<std::string> errs(n_types);
-  std::vector<char> good(n_types, 0);
+  std::vector<char> good(n_types, 0), type_fits(n_types, 0);
   const int dev = current_device_id();
   std::atomic<int> next{0};
   auto worker = [&] {
@@ -1023,7 +1037,13 @@ void ensure_fused_pieces(fr_pipeline &pl, const fr::FusedKey &key, bool cache_on
       fp.piece = true;
       fr::FusedKey k = key;
       k.LV = piece_level_variant(pp->types[t].levels);
-      good[t] = fr::jit_fused(ops, k, progs[t], errs[t], &fp, cache_only) ? 1 : 0;
+      // (whether the largest unit's features fit the window is known here: no flush test then)
+      fr::FusedOps type_ops = ops;
+      bool fits = false;
+      (void)piece_window(p, pp->types[t], pl.T, ops.cps, n_ops_eff, has_mpi, fits);
+      type_ops.window_fits = fits;
+      type_fits[t] = fits ? 1 : 0;
+      good[t] = fr::jit_fused(type_ops, k, progs[t], errs[t], &fp, cache_only) ? 1 : 0;
     }
   };
   const int hw = (int)std::thread::hardware_concurrency();
@@ -1053,6 +1073,7 @@ void ensure_fused_pieces(fr_pipeline &pl, const fr::FusedKey &key, bool cache_on
     return;
   }
   it->second.progs = std::move(progs);
+  it->second.fits = std::move(type_fits);
 }
 
 // Shared body of fr_iss_run and fr_pipeline_run: validates, lays out the
@@ -1418,11 +1439,12 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
         b.carry_in_lds = 1;
         b.persistent = 0;
         b.nchunks = (int32_t)((T + chunk - 1) / chunk);
-        const size_t other = ((size_t)b.R * chunk + 24 + (b.nchunks > 1 ? b.carry_slots : 0)) * 8;
+        const size_t other = piece_other_lds(p, pt, T, b.carry_per_node);
         bool fits = false;
-        b.feat_window = feat_window_sized(pt.widest_node * fu->n_ops, pt.max_unit_rows * fu->n_ops, other,
-                                          fu->has_mpi, fits);
+        b.feat_window = piece_window(p, pt, T, b.carry_per_node, fu->n_ops, fu->has_mpi, fits);
         b.feat_fits = fits ? 1 : 0;
+        if ((pcs.fits[t] != 0) != fits)   // (the kernel was compiled for exactly this: ensure_fused_pieces)
+          return fail(FR_E_LIMIT, w + ": a piece kernel was compiled for another feature window");
         if (b.feat_window == 0)
           return fail(FR_E_LIMIT, w + ": the chunk carries and the features of one node do not fit the LDS");
         const size_t lds = other + fr::feat_window_bytes(b.feat_window, b.has_mpi != 0, false);
@@ -1693,6 +1715,7 @@ int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
   pl->drop_pieces();
   pl->jit_ops = fr::FusedOps{};
   pl->jit_ops.n_padded = pl->n_ops_padded;
+  pl->jit_ops.full_chunks = pl->T % fr::walk_chunk_elems(pl->T) == 0;
   for (const PipeSieve &sv : pl->sieves) {   // (a slot pair per differencing order >= 3 and per
     if (sv.kind == FR_SIEVE_END) continue;    // cumulation of a row: walk_fused.h, fop)
     if (sv.inc > 2) pl->jit_ops.cps = std::max(pl->jit_ops.cps, 3 + 2 * (sv.inc - 2));

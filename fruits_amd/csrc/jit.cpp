@@ -350,7 +350,8 @@ std::string jit_fused_source(const FusedOps &ops, const FusedPlan *plan) {
   o << kJitDeviceSource << "\nnamespace fr {\nstruct JitOps {\n  static constexpr bool is_static = true;\n";
   const size_t n = ops.w0.size();
   o << "  static constexpr int n = " << n << ", n_padded = " << ops.n_padded << ", cps = " << ops.cps
-    << ";\n";
+    << ";\n  static constexpr bool window_fits = " << (ops.window_fits ? "true" : "false")
+    << ", full_chunks = " << (ops.full_chunks ? "true" : "false") << ";\n";
   auto list = [&](const char *name, const std::vector<int32_t> &v) {
     o << "  static constexpr int32_t " << name << "[" << (n ? n : 1) << "] = {";
     for (size_t i = 0; i < n; ++i) o << (i ? ", " : "") << v[i];

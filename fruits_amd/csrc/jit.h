@@ -38,6 +38,8 @@ struct FusedOps {        // per op of an output row, the same for every row
   std::vector<int32_t> w0, lo, hi;   // FeatOp::kind_inc (kind, differencing order, shape), cuts
   int n_padded = 0;                  // ops per row of the device table (row stride / 32 bytes)
   int cps = 3;                       // carry slots per node (IssArgs::carry_per_node)
+  bool window_fits = false;          // a piece type whose largest unit fits the feature window
+  bool full_chunks = false;          // the series length is a multiple of the time chunk
 };
 // The plan as an immediate too (walk_fused.h, fwalk_static): the records of the group program
 // the launch will use (16 words each, sentinels included) and the groups' first records.

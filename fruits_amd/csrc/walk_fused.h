@@ -483,9 +483,22 @@ __device__ __forceinline__ Op1 load_op1(const Hot &a, uint32_t op_off) {
 // column differ - so kind_inc / lo / hi are immediates: the op loop is unrolled and the decode of
 // fop folds away (an END at a fixed index of a one-chunk series becomes one predicated LDS store).
 struct DynOps {
-  static constexpr bool is_static = false;
+  static constexpr bool is_static = false, window_fits = false, full_chunks = false;
   static constexpr int n = 0;
 };
+
+// Window slots of the next node.  OPS::window_fits (a kernel of a piece type whose largest unit
+// fits the feature window: the host knows when it compiles the kernel): no test, and no copy of
+// the flush behind every node of straight-line code.
+template <class C, class OPS>
+__device__ __forceinline__ void freserve(WalkCtx &cx, int need) {
+  if constexpr (OPS::window_fits) {
+    cx.fslot = cx.fused_used;
+    cx.fused_used += need;
+  } else {
+    feat_reserve<C, true>(cx, need);
+  }
+}
 
 template <class C, class OPS, bool SEQ, int I>
 __device__ __forceinline__ void fops_static(WalkCtx &cx, const Hot &a, uint32_t op_off, int slot,
@@ -628,7 +641,7 @@ __device__ __forceinline__ void fnode(WalkCtx &cx, const Hot &a, double (&f)[C::
   int t_ops = 0;
   if constexpr (C::MODE == 1) {
     t_ops = touch(a.ops, op_off);
-    feat_reserve<C, true>(cx, ne * (OPS::is_static ? OPS::n : a.n_ops));
+    freserve<C, OPS>(cx, ne * (OPS::is_static ? OPS::n : a.n_ops));
   }
   cx.slot = slot;
   const int nf = nd.fac_count(), flags = nd.flags(), lv = nd.level();
@@ -761,7 +774,7 @@ __device__ __forceinline__ void fnode_shaped(WalkCtx &cx, const Hot &a, double (
   int t_ops = 0;
   if constexpr ((S::flags & F_EMIT) != 0) {
     t_ops = touch(a.ops, op_off);
-    feat_reserve<C, true>(cx, ne * OPS::n);
+    freserve<C, OPS>(cx, ne * OPS::n);
   }
   cx.slot = slot;
   double s[EP];
@@ -899,7 +912,7 @@ __device__ __forceinline__ void fwalk_static(WalkCtx &cx, const Hot &a, double (
     const int slot = a.slot_base + (C::MULTI != 0 ? OPS::cps : kCarrySlots) * (PC - GB);
     constexpr uint32_t me = (uint32_t)PC * 64u;
     const uint32_t op_off = a.op_base + (uint32_t)R::w(7) * (uint32_t)(OPS::n_padded * 32);
-    feat_reserve<C, true>(cx, R::ne * OPS::n);
+    freserve<C, OPS>(cx, R::ne * OPS::n);
     cx.slot = slot;
     double s[EP];
     if constexpr ((R::flags & F_SLOW) != 0) {
@@ -1169,7 +1182,9 @@ __global__ __launch_bounds__(kWalkThreads) void iss_fused_kernel(const IssArgs a
     cx.t0 = t0;
     cx.parity = chunk & 1;
     cx.first_chunk = chunk == 0;
-    cx.full_chunk = t0 + C::CHUNK <= a.T;
+    // (OPS::full_chunks - a run-time compiled kernel for a series length that is a multiple of the
+    // chunk: the ops' paths for ragged chunks are not even compiled)
+    cx.full_chunk = OPS::full_chunks || t0 + C::CHUNK <= a.T;
     if (chunk > 0) lds_barrier();  // all reads of the old rows are done
     stage_chunk<C>(cx, a, n, t0, lds);
     __syncthreads();

@@ -519,8 +519,16 @@ class FruitSlice:
         if mode == "all":
             pipe.prepare(N)
         elif size >= (16 << 20):
+            # (a stream capture must not see the uploads, module loads and the helper thread's
+            # work: a captured launch takes what is there - fr_pipeline_prepare before the capture
+            # is the documented way)
+            if nat.torch().cuda.is_current_stream_capturing():
+                return
+            # the uploads (plan tables, the tables of a plan in pieces) and whatever the disk cache
+            # or the kernels shipped with the build hold: here, on the caller's thread ...
             pipe.prepare_cached(N)
-            if size >= (256 << 20):
+            # ... the helper thread only compiles and loads what is still missing
+            if size >= (256 << 20) and not pipe.fully_compiled():
                 pipe.prepare_in_background(N)
         else:
             return

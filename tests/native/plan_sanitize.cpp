@@ -56,6 +56,16 @@ int main() {
         checksum += sc.ok ? (long)sc.entries.size() + sc.frames + sc.rows : -1;
         for (const fr::NodeRec &r : sc.entries) checksum += r.w[0] & 0xff;
       }
+      // the plan in pieces (several piece sizes, units of one item and of many)
+      for (int piece : {2, 7, 16, 64, 128}) {
+        fr::PiecedProgram &pp = fr::pieced(*p, piece, piece == 7 ? 1 : 0);
+        checksum += pp.ok ? (long)pp.types.size() + pp.chain_nodes : -1;
+        for (const fr::PieceType &t : pp.types) {
+          checksum += (long)t.recs.size() + t.units() + t.max_unit_nodes + t.body_rows;
+          for (int32_t v : t.items) checksum += v & 0xff;
+        }
+        for (int32_t r : pp.row_of_walk) checksum += r;
+      }
     } else {
       checksum += p->cos->factors.size() + p->cos->letter_begin.back();
       delete p->cos;

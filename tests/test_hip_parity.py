@@ -1215,11 +1215,13 @@ def test_word_sharded_blocks_reassemble(fr, world, name):
         parts = par.shard_words(strings, depths, world)
         maps = par.column_map(parts, depths, per_sum)
         out = np.zeros((X.shape[0], slc.nfeatures()))
+        from fruits_amd import _native as nat
         for r in range(world):
             cache = SharedSeedCache(X)
             if parts[r]:
                 assert slc._fused(X.shape[2], indices=parts[r]) is not None
-            block = par._device_block(slc, iss, X, cache, parts[r], depths, per_sum).cpu().numpy()
+            block = par._device_block(slc, iss, cache.input_device(X), cache, parts[r], depths,
+                                      per_sum).cpu().numpy()
             assert block.shape[1] == len(maps[r])
             out[:, maps[r]] = block
         want = ref[:, col0:col0 + slc.nfeatures()]
@@ -1232,6 +1234,44 @@ def test_word_sharded_blocks_reassemble(fr, world, name):
     if world == 1:
         full = par.transform_sharded(fruit, X, rank=0, world=1)
         np.testing.assert_allclose(full, ref, rtol=1e-12, atol=1e-300)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_word_sharded_coswiss_ffn(fr, world):
+    """A CosWISS with the randomised ffn (every (word, frequency) reads its own transformed copy
+    of the input, fruits/iss/cos.py:93-137) under word sharding: a rank's words go through the
+    word-by-word fused launches, never through a pipeline on the plain batch - the blocks
+    re-assemble to the unsharded transform; also with a rank that holds ONE word."""
+    from fruits_amd import parallel as par
+    from fruits_amd.cache import SharedSeedCache
+    T = 700
+    rng = np.random.default_rng(21)
+    X = rng.standard_normal((19, 2, T)).cumsum(axis=2) / 6.0
+    fruit = fr.Fruit("ffn sharded")
+    fruit.add(fr.preparation.INC)
+    words = [fr.words.SimpleWord(s) for s in ["[1]", "[1][2]", "[2][1][1]", "[2]"]]
+    fruit.add(fr.CosWISS(freqs=[0.1, 0.35], words=words, exponent=2, ffn_size=5))
+    fruit.add(fr.sieving.NPI(q=(0.4, 1.0)), fr.sieving.NPI(inc=2), fr.sieving.END(cut=[T // 2, -1]))
+    slc = fruit.get_slice()
+    slc.fit_sample_size = 1.0
+    np.random.seed(6)
+    fruit.fit(X)
+    ref = fruit.transform(X)
+    iss = slc.get_iss()[0]
+    strings = [str(w) for w in iss.words]
+    depths = [iss._depth(i) for i in range(len(strings))]
+    per_sum = sum(s.nfeatures() for s in slc.get_sieves())
+    parts = par.shard_words(strings, depths, world)
+    maps = par.column_map(parts, depths, per_sum)
+    out = np.zeros_like(ref)
+    for r in range(world):
+        cache = SharedSeedCache(X)
+        block = par._device_block(slc, iss, cache.input_device(X), cache, parts[r], depths, per_sum)
+        assert block.shape[1] == len(maps[r])
+        out[:, maps[r]] = block.cpu().numpy()
+    np.testing.assert_array_equal(np.nan_to_num(out), ref)
+    # the unsharded transform in between must not disturb a word's plan (its input stride)
+    np.testing.assert_array_equal(fruit.transform(X), ref)
 
 
 @pytest.mark.parametrize("name", ["readme", "cfg3_small", "cfg3_small_unweighted", "twi_small",
@@ -1869,7 +1909,7 @@ def test_word_sharded_config4_full_size(fr):
     out = torch.zeros((N, slc.nfeatures()), dtype=torch.float64, device="cuda")
     for r in range(world):
         assert slc._fused(T, indices=parts[r]) is not None
-        block = par._device_block(slc, iss, X, cache, parts[r], depths, per_sum)
+        block = par._device_block(slc, iss, cache.input_device(X), cache, parts[r], depths, per_sum)
         assert block.shape == (N, len(maps[r]))
         out[:, torch.as_tensor(maps[r], device="cuda")] = block
     np.testing.assert_array_equal(np.nan_to_num(out.cpu().numpy()), ref)

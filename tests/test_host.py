@@ -432,6 +432,52 @@ def test_numpy_sum_model(tmp_path):
     assert np.signbit(L.pw_host_sum(z.ctypes.data, 9)) == np.signbit(np.add.reduce(z))
 
 
+@pytest.mark.parametrize("key,piece,types", [("6,2", 64, 5), ("6,2", 128, 4), ("9,1", 64, 5), ("4,2", 16, None),
+                                             ("3,3", 8, None)])
+def test_plan_in_pieces_is_a_cover(key, piece, types):
+    """A large plan in pieces (csrc/plan.h PiecedProgram, what the fused walk of config 4 / 5
+    runs): walking every unit of every piece type - its items' chains, then their bodies - emits
+    every output row exactly once, in the walk order the tables claim; equal sub-tries are ONE
+    type (of_weight(6,2): 1351 nodes, five bodies of at most 62 nodes to compile), the recomputed
+    chains cost a few per cent of the node executions."""
+    ent = M["words"][key]
+    words = [fr.words.SimpleWord(s) for s in ent["words"]]
+    for kw in ({}, {"weighting": fr.iss.weighting.Indices()}):
+        plan = fr.ISS(words, mode=fr.ISSMode.EXTENDED, **kw)._plan(0, len(words))
+        pc = plan.pieces(piece)
+        assert pc is not None and pc["K"] == ent["K"] and pc["nodes"] == plan.nodes
+        if types is not None:
+            assert len(pc["types"]) == types
+        seen = np.zeros(pc["K"], dtype=int)
+        execs = 0
+        for t in pc["types"]:
+            recs, nb = t["recs"], t["body_nodes"]
+            assert nb <= piece and (recs[nb, 0] & 0xff) == 0xff            # (sentinel behind the body)
+            assert int(recs[:nb, 6].sum()) == t["body_rows"] and t["levels"] <= 8
+            assert (recs[:nb, 0] & 0xff).max() < t["levels"]
+            for u in range(t["units"]):
+                q, nodes = int(t["unit_row0"][u]), 0
+                for chain_off, row_base, node_base, _ in t["items"][t["unit_begin"][u]:t["unit_begin"][u + 1]]:
+                    assert node_base == nodes and chain_off % 64 == 0
+                    r = chain_off // 64
+                    while (recs[r, 0] & 0xff) != 0xff:                      # the chain: frame 0, in place
+                        assert (recs[r, 0] & 0xff) == 0 and (recs[r, 0] >> 8) & 1
+                        ne = int(recs[r, 6])
+                        assert ne == 0 or recs[r, 7] == q
+                        seen[pc["row_of_walk"][q:q + ne]] += 1
+                        q, r, nodes = q + ne, r + 1, nodes + 1
+                    assert row_base == q
+                    seen[pc["row_of_walk"][q:q + t["body_rows"]]] += 1
+                    q, nodes = q + t["body_rows"], nodes + nb
+                assert nodes <= t["max_unit_nodes"] and q - t["unit_row0"][u] <= t["max_unit_rows"]
+                execs += nodes
+        assert (seen == 1).all()
+        assert execs == pc["nodes"] + pc["chain_nodes"] - sum(
+            1 for t in pc["types"] for r in t["recs"][t["body_nodes"] + 1:] if (r[0] & 0xff) != 0xff and r[6] > 0)
+        if plan.nodes > 500:
+            assert pc["chain_nodes"] <= 0.06 * plan.nodes
+
+
 def test_static_schedules_are_valid_walks():
     """plan.cpp static_schedule: every node once, letters only on completed rows, children
     behind their parents - for the standard word sets and 1-3 groups per series."""

@@ -219,3 +219,64 @@ def test_fit_state_round_trip_coswiss(variant):
     fruit.add(cos, fr.sieving.END)
     fruit._fitted = fruit.get_slice()._fitted = True
     pickle.loads(pickle.dumps(fruit.fit_state()))
+
+
+def _sharded_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fruits_amd as fr
+        words = fr.words.of_weight(3, dim=3)
+        fruit = fr.Fruit("sharded")
+        fruit.add(fr.preparation.INC, fr.ISS(words, mode=fr.ISSMode.EXTENDED), fr.sieving.NPI, fr.sieving.END)
+        fruit.cut()
+        fruit.add(fr.ISS(fr.words.of_weight(2, dim=3), mode=fr.ISSMode.EXTENDED), fr.sieving.NPI, fr.sieving.END)
+        fruit._fitted = True                       # (nothing to fit: NPI() counts positive increments)
+        for slc in fruit:
+            slc._fitted = True
+        X = np.random.default_rng(13).random((5, 3, 40)) if rank == 0 else None
+        seen = {}
+
+        def block(slc, iss, Xb, cache, indices, depths, per_sum):
+            # the oracle stands in for the HIP pipeline; what is under test is what surrounds it:
+            # only the root handed the batch in, every rank sees it here
+            seen["shape"] = tuple(Xb.shape)
+            strings = [str(w) for w in iss.words]
+            return _oracle_block(Xb.numpy(), strings, depths, indices, 0.0)
+        full = par.transform_sharded(fruit, X, block=block)
+        assert seen["shape"] == (5, 3, 40)
+        dev = par.transform_sharded(fruit, X, block=block, on_device=True)
+        assert isinstance(dev, torch.Tensor) and tuple(dev.shape) == full.shape
+        np.save(os.path.join(out_dir, f"sharded{rank}.npy"), full)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_transform_sharded_from_the_root_alone(tmp_path):
+    """parallel.transform_sharded, world 2 over gloo: only rank 0 passes the batch (rank 1
+    passes None and receives it by broadcast), both slices' word lists are sharded, and every
+    rank ends up with the unsharded feature matrix."""
+    import fruits_amd as fr
+    world = 2
+    mp.spawn(_sharded_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    X = np.random.default_rng(13).random((5, 3, 40))
+    blocks = []
+    for w in (3, 2):
+        words = [str(x) for x in fr.words.of_weight(w, dim=3)]
+        depths = orc.cache_plan(words)
+        blocks.append(_oracle_block(X, words, depths, list(range(len(words))), 0.0).numpy())
+    ref = np.concatenate(blocks, axis=1)
+    for r in range(world):
+        np.testing.assert_array_equal(np.load(os.path.join(str(tmp_path), f"sharded{r}.npy")), ref)
+
+
+def test_gather_index_is_one_map():
+    ent = G.manifest["words"]["4,2"]
+    parts = par.shard_words(ent["words"], ent["plan"], 4)
+    maps = par.column_map(parts, ent["plan"], 3)
+    rank_of, pos_of = par.gather_index(maps, 3 * ent["K"])
+    for r, m in enumerate(maps):
+        assert (rank_of[m] == r).all() and (pos_of[m] == np.arange(len(m))).all()
+    with pytest.raises(ValueError):
+        par.gather_index(maps[:-1], 3 * ent["K"])
