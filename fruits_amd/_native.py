@@ -35,7 +35,7 @@ EXPORTS = [
     "fr_pipeline_create", "fr_pipeline_destroy", "fr_pipeline_info",
     "fr_pipeline_workspace_bytes", "fr_pipeline_run", "fr_pipeline_set_quantiles",
     "fr_select_ranks", "fr_coswiss_combine", "fr_plan_create_coswiss", "fr_nan_to_num",
-    "fr_plan_prepare", "fr_pipeline_prepare", "fr_pipeline_compile_plan", "fr_pipeline_prepare_cached", "fr_plan_fits", "fr_release_scratch",
+    "fr_plan_prepare", "fr_pipeline_prepare", "fr_pipeline_compile_plan", "fr_pipeline_prepare_cached", "fr_pipeline_bundle", "fr_plan_fits", "fr_release_scratch",
     "fr_pipeline_set_preparation", "fr_pipeline_set_series_cuts", "fr_arctic_argmax", "fr_coswiss_set_dropout",
     "fr_coswiss_set_input_stride", "fr_coswiss_ffn",
 ]
@@ -560,6 +560,22 @@ class Pipeline:
         """Run-time compiled kernels this pipeline holds (``static_only``: those with the plan
         as straight-line code)."""
         return int(lib().fr_pipeline_info(self._h, 4 if static_only else 3))
+
+    def bundle(self, quant: np.ndarray, out_dir: str, groups: int = 1) -> int:
+        """fr_pipeline_bundle: compiles this pipeline's kernels (the sieves as immediates; the
+        plan as straight-line code or in pieces) into ``out_dir`` without a device; ``quant``
+        (K, q_stride) carries the infinities of the thresholds (finite values are placeholders)."""
+        q = np.ascontiguousarray(quant, dtype=np.float64)
+        if q.shape != (self.plan.rows, self.q_stride):
+            raise ValueError("quantile table must be (K, q_stride)")
+        buf = C.create_string_buffer(4096)
+        L = lib()
+        L.fr_pipeline_bundle.restype = C.c_int32
+        rc = L.fr_pipeline_bundle(self._h, q.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(groups),
+                                  os.fsencode(out_dir), buf, C.c_int64(len(buf)))
+        if rc < 0:
+            raise NativeError(f"fr_pipeline_bundle: {last_error()}")
+        return int(rc)
 
     def fully_compiled(self) -> bool:
         """Whether the pipeline already holds the kernels a ``prepare`` would give it: the plan's

@@ -206,3 +206,6 @@ if __name__ == "__main__":
             defines.append(arg[2:])
     print(build_native(force="--force" in sys.argv, verbose="-v" in sys.argv, variant=variant,
                        defines=defines, only=only))
+    if not variant and "--no-bundle" not in sys.argv:
+        from fruits_amd.gen_bundle import build_bundle
+        print(build_bundle(force="--force" in sys.argv))

@@ -1573,6 +1573,13 @@ fr_pipeline_t *fr_pipeline_create(fr_plan_t *plan, int32_t n_sieves, const int32
 
 void fr_pipeline_destroy(fr_pipeline_t *pl) {
   if (!pl) return;
+  {
+    // (launches of the pipeline's own kernels may still run, a compilation may still be about to
+    // store its result: wait for the device, and take the lock the compilations store under)
+    std::lock_guard<std::mutex> lock(pl->jit_mu);
+    ++pl->jit_gen;
+    if (!pl->jit.empty() || !pl->jit_static.empty() || !pl->jit_pieces.empty()) (void)hipDeviceSynchronize();
+  }
   if (pl->d_ops) (void)hipFree(pl->d_ops);
   if (pl->d_mpi_cols) (void)hipFree(pl->d_mpi_cols);
   if (pl->d_npi_pairs) (void)hipFree(pl->d_npi_pairs);
@@ -1610,17 +1617,19 @@ int64_t fr_pipeline_info(const fr_pipeline_t *pl, int32_t what) {
   }
 }
 
-int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
-  if (!pl || !h_quant) return fail(FR_E_ARG, "fr_pipeline_set_quantiles: bad argument");
+// The host half of fr_pipeline_set_quantiles: the table of feature ops (and the NPI / MPI pairs
+// that share a population), nothing on the device.
+static void build_pipeline_ops(fr_pipeline_t *pl, const double *h_quant, std::vector<fr::FeatOp> &ops,
+                               std::vector<int32_t> &pairs) {
   const fr::Plan &p = *pl->plan->p;
   const int K = p.K;
-  std::vector<fr::FeatOp> ops((size_t)K * pl->n_ops_padded);
+  ops.assign((size_t)K * pl->n_ops_padded, fr::FeatOp{});
   // An NPI feature whose band, cut and differencing order equal an MPI feature's is that
   // MPI op's population (experiments/fruit_reduced.py pairs NPI and MPI sieves with the
   // same arguments, fitted on the same values): such NPI ops are dropped from the walk
   // and filled in from the population table by mpi_finalize_kernel.  Only when the same
   // pairs match in every row (the finalize kernel works on column patterns).
-  std::vector<int32_t> pairs;
+  pairs.clear();
   for (int pass = 0; pass < 2; ++pass) {
     const bool merge = pass == 0;
     bool uniform = true;
@@ -1692,27 +1701,13 @@ int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
     if (uniform) break;
     pairs.clear();  // rows disagree: second pass without merging
   }
-  if (pairs != pl->npi_pairs || (!pairs.empty() && !pl->d_npi_pairs)) {
-    if (pl->d_npi_pairs) (void)hipFree(pl->d_npi_pairs);
-    pl->d_npi_pairs = nullptr;
-    pl->npi_pairs = pairs;
-    if (!pairs.empty()) {
-      HIP_TRY(hipMalloc(&pl->d_npi_pairs, pairs.size() * 4));
-      HIP_TRY(hipMemcpy(pl->d_npi_pairs, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
-    }
-  }
-  // What a run-time compiled kernel takes as immediates: per op kind | differencing order | shape
-  // and the cuts - the same for every output row (the shape only if every row's thresholds agree
-  // on it: an infinite threshold in one row alone keeps the generic band).
-  std::lock_guard<std::mutex> jit_lock(pl->jit_mu);
-  ++pl->jit_gen;
-  for (auto &kv : pl->jit) fr::jit_unload(kv.second);
-  for (auto &kv : pl->jit_static) fr::jit_unload(kv.second);
-  pl->jit.clear();
-  pl->jit_static.clear();
-  pl->jit_static_tried.clear();
-  pl->jit_failed.clear();
-  pl->drop_pieces();
+}
+
+// What a run-time compiled kernel takes as immediates: per op kind | differencing order | shape
+// and the cuts - the same for every output row (the shape only if every row's thresholds agree
+// on it: an infinite threshold in one row alone keeps the generic band).  Caller holds jit_mu.
+static void set_pipeline_jit_ops(fr_pipeline_t *pl, const std::vector<fr::FeatOp> &ops) {
+  const int K = pl->plan->p->K;
   pl->jit_ops = fr::FusedOps{};
   pl->jit_ops.n_padded = pl->n_ops_padded;
   pl->jit_ops.full_chunks = pl->T % fr::walk_chunk_elems(pl->T) == 0;
@@ -1736,6 +1731,35 @@ int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
     pl->jit_ops.lo.push_back(ops[i].lo);
     pl->jit_ops.hi.push_back(ops[i].hi);
   }
+}
+
+int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
+  if (!pl || !h_quant) return fail(FR_E_ARG, "fr_pipeline_set_quantiles: bad argument");
+  std::vector<fr::FeatOp> ops;
+  std::vector<int32_t> pairs;
+  build_pipeline_ops(pl, h_quant, ops, pairs);
+  if (pairs != pl->npi_pairs || (!pairs.empty() && !pl->d_npi_pairs)) {
+    if (pl->d_npi_pairs) (void)hipFree(pl->d_npi_pairs);
+    pl->d_npi_pairs = nullptr;
+    pl->npi_pairs = pairs;
+    if (!pairs.empty()) {
+      HIP_TRY(hipMalloc(&pl->d_npi_pairs, pairs.size() * 4));
+      HIP_TRY(hipMemcpy(pl->d_npi_pairs, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
+    }
+  }
+  // (new thresholds: the kernels compiled for the old ops go - once the launches that may still
+  // be running them are done: fr_pipeline_run returns without a synchronisation)
+  std::lock_guard<std::mutex> jit_lock(pl->jit_mu);
+  if (!pl->jit.empty() || !pl->jit_static.empty() || !pl->jit_pieces.empty()) (void)hipDeviceSynchronize();
+  ++pl->jit_gen;
+  for (auto &kv : pl->jit) fr::jit_unload(kv.second);
+  for (auto &kv : pl->jit_static) fr::jit_unload(kv.second);
+  pl->jit.clear();
+  pl->jit_static.clear();
+  pl->jit_static_tried.clear();
+  pl->jit_failed.clear();
+  pl->drop_pieces();
+  set_pipeline_jit_ops(pl, ops);
   const size_t bytes = ops.size() * sizeof(fr::FeatOp);
   pl->h_ops = ops;
   if (!pl->d_ops && bytes) HIP_TRY(hipMalloc(&pl->d_ops, bytes));
@@ -1896,6 +1920,99 @@ static int pipeline_compile_plan(fr_pipeline_t *pl, int64_t N, int32_t groups, b
   }
   ensure_fused_static(*pl, key, fp, cache_only);
   return FR_OK;
+}
+
+int32_t fr_pipeline_bundle(fr_pipeline_t *pl, const double *h_quant, int32_t groups, const char *dir,
+                           char *msg, int64_t msg_cap) {
+  if (msg && msg_cap > 0) msg[0] = 0;
+  if (!pl || !pl->plan || !pl->plan->p || !h_quant || !dir || !*dir)
+    return fail(FR_E_ARG, "fr_pipeline_bundle: bad argument");
+  fr::Plan &p = *pl->plan->p;
+  std::vector<fr::FeatOp> ops;
+  std::vector<int32_t> pairs;
+  build_pipeline_ops(pl, h_quant, ops, pairs);
+  fr::FusedOps jops;
+  {
+    std::lock_guard<std::mutex> lock(pl->jit_mu);
+    set_pipeline_jit_ops(pl, ops);
+    if (!pl->jit_uniform) return 0;
+    jops = pl->jit_ops;
+  }
+  fr::FusedKey key;
+  LaunchShape shape;
+  if (!fused_instance_of(pl, 1 << 20, groups, key, shape)) return 0;
+  std::vector<std::string> errs;
+  std::atomic<int> done{0};
+  std::mutex err_mu;
+  auto one = [&](const fr::FusedOps &o, const fr::FusedKey &k, const fr::FusedPlan *fp) {
+    std::string err;
+    if (fr::jit_fused_into(o, k, fp, dir, err)) {
+      ++done;
+    } else {
+      std::lock_guard<std::mutex> lock(err_mu);
+      errs.push_back(err);
+    }
+  };
+  if (pieces_eligible(p)) {                    // a large plan: a kernel per piece type
+    const fr::PiecedProgram *pp;
+    {
+      std::lock_guard<std::mutex> lock(p.mu);
+      pp = &fr::pieced(p, piece_nodes_knob(), debug_knob("piece_unit", 0));
+    }
+    const int n_types = pp->ok ? (int)pp->types.size() : 0;
+    // the largest bodies first (the compiler's time grows faster than a body); job -1: the kernel
+    // with the sieves as immediates alone (the plan from its records)
+    std::vector<int> order{-1};
+    for (int t = 0; t < n_types; ++t) order.push_back(t);
+    std::stable_sort(order.begin() + 1, order.end(), [&](int x, int y) {
+      return pp->types[x].body_nodes > pp->types[y].body_nodes;
+    });
+    std::atomic<int> next{0};
+    auto worker = [&] {
+      for (int i = next++; i < (int)order.size(); i = next++) {
+        const int t = order[i];
+        if (t < 0) {
+          one(jops, key, nullptr);
+          continue;
+        }
+        fr::FusedPlan fp;
+        fp.w = pp->types[t].body_w;
+        fp.piece = true;
+        fr::FusedKey k = key;
+        k.LV = piece_level_variant(pp->types[t].levels);
+        fr::FusedOps type_ops = jops;
+        bool fits = false;
+        (void)piece_window(p, pp->types[t], pl->T, jops.cps, pl->n_ops_eff, !pl->mpi_cols.empty(), fits);
+        type_ops.window_fits = fits;
+        one(type_ops, k, &fp);
+      }
+    };
+    const int n_threads = std::max(1, std::min((int)order.size(), env_int("FRUITS_BUNDLE_THREADS", 4)));
+    std::vector<std::thread> pool;
+    for (int i = 1; i < n_threads; ++i) pool.emplace_back(worker);
+    worker();
+    for (std::thread &th : pool) th.join();
+  } else if ((int)p.nodes.size() <= fr::kFusedStaticMaxNodes && debug_knob("fused_static", 1) != 0) {
+    // a small plan as straight-line code, for the group program of `groups` groups per series
+    std::thread sieves_only([&] { one(jops, key, nullptr); });
+    fr::FusedPlan fp;
+    {
+      std::lock_guard<std::mutex> lock(p.mu);
+      const fr::GroupedProgram &gp = fr::grouped(p, groups > 0 ? groups : 1);
+      fp.w.reserve(gp.recs.size() * 16);
+      for (const fr::NodeRec &r : gp.recs) fp.w.insert(fp.w.end(), r.w, r.w + 16);
+      fp.group_begin.assign(gp.group_begin.begin(), gp.group_begin.begin() + gp.groups);
+    }
+    one(jops, key, &fp);
+    sieves_only.join();
+  } else {
+    one(jops, key, nullptr);
+  }
+  if (!errs.empty()) {
+    if (msg && msg_cap > 0) snprintf(msg, (size_t)msg_cap, "%s", errs[0].c_str());
+    return fail(FR_E_LIMIT, "fr_pipeline_bundle: " + errs[0]);
+  }
+  return done.load();
 }
 
 int fr_pipeline_set_series_cuts(fr_pipeline_t *pl, const int32_t *d_cuts, int64_t N, int32_t slots) {

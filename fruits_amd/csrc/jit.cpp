@@ -94,6 +94,18 @@ unsigned long long fnv1a(const std::string &s) {
   return h;
 }
 
+// a second, independent hash of the key (FNV-1a over the reversed string, another offset basis):
+// stored in the file's header, so that a collision of the 64-bit file name - or a stale file under
+// a recycled name - is refused instead of loaded as somebody else's kernel
+unsigned long long fnv1a_alt(const std::string &s) {
+  unsigned long long h = 0x9ae16a3b2f90404full;
+  for (size_t i = s.size(); i-- > 0;) {
+    h ^= (unsigned char)s[i];
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+
 std::string cache_dir() {
   if (const char *d = getenv("FRUITS_HIP_JIT_CACHE")) return *d ? std::string(d) : std::string();
   const char *home = getenv("XDG_CACHE_HOME");
@@ -106,14 +118,18 @@ std::string cache_dir() {
   return base + "/fruits_amd/jit";
 }
 
-// Creates the directory chain privately; true when `path` then is a directory the user owns and
-// nobody else can write to.
+// true when `path` is a real directory (not a symbolic link) the user owns and nobody else can
+// write to - checked before a cached object is written AND before one is read
+bool trusted_dir(const std::string &path) {
+  struct stat st;
+  if (lstat(path.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+  return st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+// Creates the directory chain privately, then trusted_dir.
 bool private_dir(const std::string &path) {
   for (size_t i = 1; i <= path.size(); ++i)
     if (i == path.size() || path[i] == '/') (void)mkdir(path.substr(0, i).c_str(), 0700);
-  struct stat st;
-  if (stat(path.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
-  return st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+  return trusted_dir(path);
 }
 
 const char *kCompileOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
@@ -129,6 +145,10 @@ std::string toolchain_tag() {
     t += "hiprtc " + std::to_string(major) + "." + std::to_string(minor);
   else
     t += "hiprtc ?";
+  // (the HIP runtime's full version number: patch level and build included; no device needed)
+  int rt = 0;
+  if (hipRuntimeGetVersion(&rt) == hipSuccess) t += " hip " + std::to_string(rt);
+  else (void)hipGetLastError();
   return t;
 }
 
@@ -136,38 +156,49 @@ std::string toolchain_tag() {
 // name's length).
 struct CacheHeader {
   char magic[8];            // "FRJITCO\1"
-  uint32_t format;          // 1
+  uint32_t format;          // 2
   uint32_t reserved;
   uint64_t payload_bytes;
   uint64_t payload_hash;    // FNV-1a of the payload
+  uint64_t key_hash;        // fnv1a_alt of what the file name hashes (source, options, toolchain)
 };
+constexpr uint32_t kCacheFormat = 2;
 const char kCacheMagic[8] = {'F', 'R', 'J', 'I', 'T', 'C', 'O', 1};
 
-bool read_cached(const std::string &file, std::string &payload) {
-  struct stat st;
-  if (stat(file.c_str(), &st) != 0 || !S_ISREG(st.st_mode) || st.st_uid != geteuid()) return false;
-  std::ifstream f(file, std::ios::binary);
-  if (!f) return false;
-  std::stringstream ss;
-  ss << f.rdbuf();
-  const std::string all = ss.str();
+bool parse_cached(const std::string &all, unsigned long long key_hash, std::string &payload) {
   CacheHeader h;
   if (all.size() < sizeof h) return false;
   std::memcpy(&h, all.data(), sizeof h);
-  if (std::memcmp(h.magic, kCacheMagic, 8) != 0 || h.format != 1 ||
+  if (std::memcmp(h.magic, kCacheMagic, 8) != 0 || h.format != kCacheFormat || h.key_hash != key_hash ||
       h.payload_bytes != all.size() - sizeof h || h.payload_bytes < 8)
     return false;
   payload = all.substr(sizeof h);
   return fnv1a(payload) == h.payload_hash;
 }
 
-void write_cached(const std::string &dir, const std::string &file, const std::string &payload) {
+bool read_cached(const std::string &file, unsigned long long key_hash, std::string &payload) {
+  // (the directory: the user's own and closed to others; the file: a regular one of the user's,
+  // not a link)
+  const size_t slash = file.rfind('/');
+  if (slash == std::string::npos || !trusted_dir(file.substr(0, slash))) return false;
+  struct stat st;
+  if (lstat(file.c_str(), &st) != 0 || !S_ISREG(st.st_mode) || st.st_uid != geteuid()) return false;
+  std::ifstream f(file, std::ios::binary);
+  if (!f) return false;
+  std::stringstream ss;
+  ss << f.rdbuf();
+  return parse_cached(ss.str(), key_hash, payload);
+}
+
+void write_cached(const std::string &dir, const std::string &file, unsigned long long key_hash,
+                  const std::string &payload) {
   if (!private_dir(dir)) return;
   CacheHeader h{};
   std::memcpy(h.magic, kCacheMagic, 8);
-  h.format = 1;
+  h.format = kCacheFormat;
   h.payload_bytes = payload.size();
   h.payload_hash = fnv1a(payload);
+  h.key_hash = key_hash;
   const std::string tmp = file + ".tmp" + std::to_string((long long)getpid());
   std::ofstream f(tmp, std::ios::binary);
   if (!f) return;
@@ -177,12 +208,41 @@ void write_cached(const std::string &dir, const std::string &file, const std::st
   if (!f || rename(tmp.c_str(), file.c_str()) != 0) (void)remove(tmp.c_str());
 }
 
+std::string cache_name(const std::string &src) {
+  char key[32];
+  snprintf(key, sizeof key, "%016llx", fnv1a(src + "\n//" + toolchain_tag()));
+  return std::string(key) + ".gfx950.co";
+}
+
 std::string cache_file(const std::string &src, std::string &dir) {
   dir = cache_dir();
   if (dir.empty()) return std::string();
-  char key[32];
-  snprintf(key, sizeof key, "%016llx", fnv1a(src + "\n//" + toolchain_tag()));
-  return dir + "/" + key + ".gfx950.co";
+  return dir + "/" + cache_name(src);
+}
+
+// The kernels SHIPPED WITH THE BUILD (fruits_amd/gen_bundle.py, run by build()): code objects
+// of the fused pipelines of the reference's experiment fruits and of the BASELINE configs, in
+// the cache's own file format, in `jit_bundle` next to this library (FRUITS_HIP_JIT_BUNDLE:
+// another directory; empty: none).  Read-only, looked up behind the user's cache and in front
+// of the compiler, so that a first launch on a fresh machine finds its own kernels.  Part of
+// the installation: trusted like the library itself (the header and payload hash are checked).
+std::string bundle_dir() {
+  if (const char *d = getenv("FRUITS_HIP_JIT_BUNDLE")) return std::string(d);
+  Dl_info info;
+  if (dladdr(reinterpret_cast<const void *>(&bundle_dir), &info) == 0 || !info.dli_fname) return std::string();
+  std::string lib(info.dli_fname);
+  const size_t slash = lib.rfind('/');
+  return (slash == std::string::npos ? std::string(".") : lib.substr(0, slash)) + "/jit_bundle";
+}
+
+bool read_bundled(const std::string &name, unsigned long long key_hash, std::string &payload) {
+  const std::string dir = bundle_dir();
+  if (dir.empty()) return false;
+  std::ifstream f(dir + "/" + name, std::ios::binary);
+  if (!f) return false;
+  std::stringstream ss;
+  ss << f.rdbuf();
+  return parse_cached(ss.str(), key_hash, payload);
 }
 
 }  // namespace
@@ -218,21 +278,33 @@ std::string jit_source(const StaticSchedule &sc) {
 // `cache_only`: take the code object from the disk cache or fail (err = kNotCached) - nothing is
 // compiled
 static const char *const kNotCached = "not in the disk cache";
+// `into`: write the code object THERE (a bundle being built, fruits_amd/gen_bundle.py) instead
+// of into the user's cache; what that directory already holds is not compiled again
 static bool compile_source(const std::string &src, const char *kernel_expr, const char *const *opts,
                            int n_opts, std::string &code, std::string &err, bool *from_cache,
-                           bool cache_only = false) {
+                           bool cache_only = false, const char *into = nullptr, bool no_bundle = false) {
   if (from_cache) *from_cache = false;
   std::string keyed = src + "\n//" + kernel_expr;
   for (int i = 0; i < n_opts; ++i) keyed += std::string(" ") + opts[i];
+  const unsigned long long key_hash = fnv1a_alt(keyed + "\n//" + toolchain_tag());
   std::string dir;
-  const std::string file = cache_file(keyed, dir);
+  std::string file = cache_file(keyed, dir);
+  if (into != nullptr) {
+    dir = into;
+    file = dir + "/" + cache_name(keyed);
+  }
   if (!file.empty()) {
-    if (read_cached(file, code)) {
+    if (read_cached(file, key_hash, code)) {
       if (from_cache) *from_cache = true;
       return true;
     }
     code.clear();
   }
+  if (into == nullptr && !no_bundle && read_bundled(cache_name(keyed), key_hash, code)) {
+    if (from_cache) *from_cache = true;
+    return true;
+  }
+  code.clear();
   if (cache_only) {
     err = kNotCached;
     return false;
@@ -274,7 +346,7 @@ static bool compile_source(const std::string &src, const char *kernel_expr, cons
     }
   }
   r.destroy(&prog);
-  if (ok && !file.empty()) write_cached(dir, file, code);
+  if (ok && !file.empty()) write_cached(dir, file, key_hash, code);
   return ok;
 }
 
@@ -387,6 +459,17 @@ std::string jit_fused_source(const FusedOps &ops, const FusedPlan *plan) {
 
 bool jit_not_cached(const std::string &err) { return err == kNotCached; }
 
+bool jit_fused_into(const FusedOps &ops, const FusedKey &key, const FusedPlan *plan, const char *dir,
+                    std::string &err) {
+  if (ops.w0.empty() || ops.w0.size() > 64) {
+    err = "no ops (or more than 64) per output row";
+    return false;
+  }
+  const std::string src = jit_fused_source(ops, plan), expr = fused_kernel_expr(key, plan != nullptr);
+  std::string code;
+  return compile_source(src, expr.c_str(), kFusedOptions, kNumFusedOptions, code, err, nullptr, false, dir);
+}
+
 bool jit_fused(const FusedOps &ops, const FusedKey &key, JitProgram &out, std::string &err,
                const FusedPlan *plan, bool cache_only) {
   if (ops.w0.empty() || ops.w0.size() > 64) {
@@ -397,8 +480,10 @@ bool jit_fused(const FusedOps &ops, const FusedKey &key, JitProgram &out, std::s
   for (int attempt = 0; attempt < 2; ++attempt) {
     std::string code;
     bool from_cache = false;
+    // (second attempt: the first one's object - from the user's cache, dropped below, or shipped
+    // with the build - was refused by the loader)
     if (!compile_source(src, expr.c_str(), kFusedOptions, kNumFusedOptions, code, err, &from_cache,
-                        cache_only))
+                        cache_only, nullptr, attempt > 0))
       return false;
     hipModule_t mod;
     hipFunction_t fn;

@@ -68,6 +68,10 @@ std::string jit_fused_source(const FusedOps &ops, const FusedPlan *plan = nullpt
 bool jit_fused(const FusedOps &ops, const FusedKey &key, JitProgram &out, std::string &err,
                const FusedPlan *plan = nullptr, bool cache_only = false);
 bool jit_not_cached(const std::string &err);
+// Compiles into the directory `dir` (the cache's file format) without loading anything: the
+// kernels shipped with the build (fruits_amd/gen_bundle.py).  Needs hipRTC, no GPU.
+bool jit_fused_into(const FusedOps &ops, const FusedKey &key, const FusedPlan *plan, const char *dir,
+                    std::string &err);
 hipError_t jit_launch_fused(const JitProgram &p, const IssArgs &a, size_t lds_bytes, hipStream_t st);
 hipError_t jit_launch(const JitProgram &p, const IssArgs &a, hipStream_t st);
 

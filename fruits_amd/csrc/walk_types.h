@@ -72,11 +72,10 @@ constexpr int kFusedStaticMaxNodes = 128;
 // pipeline's kernel (fwalk_shaped); the others take the generic body
 constexpr int kFusedShapes = 24;
 // ... or, the default since round 4, the plan in PIECES of at most this many nodes, each piece
-// type straight-line code in a kernel of its own (plan.h, PiecedProgram).  Measured on config 4
-// (of_weight(6,2)): bodies of <= 128 nodes 7.2 ms, but 37 s of compiler for the 115-node type
-// (the optimiser is superlinear in the size of one function) and a 240 KB kernel that the
-// instruction cache (64 KB per two CUs) serves worse than the 33-node type's; <= 64: 11 s cold.
-constexpr int kFusedPieceNodes = 64;
+// type straight-line code in a kernel of its own (plan.h, PiecedProgram).  Measured (config 4 /
+// config 5, hipRTC on the GPU box's host, cold cache): pieces of <= 128 nodes 6.57 / 11.65 ms
+// and 17 s of compiler, <= 64 nodes 6.74 / 12.03 ms and 12 s (the record loop: 8.46 / 15.57 ms).
+constexpr int kFusedPieceNodes = 128;
 // nodes of a unit (a few items of one type on one series; one staging of the series' rows).
 // Measured on config 4 with pieces of <= 64 nodes: units of one item 7.76 ms, <= 96 nodes 7.57,
 // <= 160 7.25, <= 256 8.31 (long workgroups: the last round of every launch runs half empty)

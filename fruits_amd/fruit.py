@@ -457,26 +457,9 @@ class FruitSlice:
                 rows = [r for i in indices for r in range(first[i], first[i + 1])]
             if chain_row:
                 rows = [chain_row * iss.n_iterated_sums() + r for r in rows]
-            # float ("coquantile") cuts differ from series to series: such a sieve names
-            # columns of a per-series table instead of indices; sieves with the same cuts
-            # share their columns (so NPI / MPI pairs still merge)
-            # (the sieves that transform are the fitted COPIES, which forget coquantile_norm -
-            # fruits/sieving/segment.py:90-91 - so the copies decide the norm here too)
-            specs, cut_columns, n_slots = [], {}, 0
             acting = (self._sieves_extended[rows[0]] if self._sieves_extended and len(rows)
                       else self._sieves)
-            for sv in acting:
-                inc = 0 if type(sv) is END else sv._inc
-                if sv._has_float_cuts():
-                    cuts_key = (tuple(sv._cut), sv._coquantile_norm)
-                    if cuts_key not in cut_columns:
-                        cut_columns[cuts_key] = (n_slots, sv)
-                        n_slots += len(sv._cut) + 1
-                    slot0 = cut_columns[cuts_key][0]
-                    specs.append((sv._kind | nat.FR_SIEVE_SERIES_CUTS, inc,
-                                  np.arange(slot0, slot0 + len(sv._cut) + 1), len(sv._q)))
-                else:
-                    specs.append((sv._kind, inc, sv._int_cut_row(T), len(sv._q)))
+            specs, cut_columns, n_slots = self._pipeline_specs(acting, T)
             try:
                 pipe = nat.Pipeline(plan, specs, T) if len(rows) and plan.fits(T) else None
             except ValueError:
@@ -500,6 +483,31 @@ class FruitSlice:
                 entry = pipe
         self._fused_cache[key] = entry
         return entry
+
+    @staticmethod
+    def _pipeline_specs(acting, T: int):
+        """What fr_pipeline_create is told about the sieves ``acting`` for series of length T:
+        (specs, cut columns, slots of the per-series cut table)."""
+        from .sieving.segment import END
+        # float ("coquantile") cuts differ from series to series: such a sieve names
+        # columns of a per-series table instead of indices; sieves with the same cuts
+        # share their columns (so NPI / MPI pairs still merge)
+        # (the sieves that transform are the fitted COPIES, which forget coquantile_norm -
+        # fruits/sieving/segment.py:90-91 - so the copies decide the norm here too)
+        specs, cut_columns, n_slots = [], {}, 0
+        for sv in acting:
+            inc = 0 if type(sv) is END else sv._inc
+            if sv._has_float_cuts():
+                cuts_key = (tuple(sv._cut), sv._coquantile_norm)
+                if cuts_key not in cut_columns:
+                    cut_columns[cuts_key] = (n_slots, sv)
+                    n_slots += len(sv._cut) + 1
+                slot0 = cut_columns[cuts_key][0]
+                specs.append((sv._kind | nat.FR_SIEVE_SERIES_CUTS, inc,
+                              np.arange(slot0, slot0 + len(sv._cut) + 1), len(sv._q)))
+            else:
+                specs.append((sv._kind, inc, sv._int_cut_row(T), len(sv._q)))
+        return specs, cut_columns, n_slots
 
     @staticmethod
     def _auto_prepare(pipe, N: int, T: int) -> None:

@@ -289,6 +289,16 @@ int64_t fr_pipeline_info(const fr_pipeline_t *pipeline, int32_t what);
 int64_t fr_pipeline_workspace_bytes(const fr_pipeline_t *pipeline, int64_t N,
                                     int64_t lookup_rows);
 int fr_pipeline_set_quantiles(fr_pipeline_t *pipeline, const double *h_quant);
+/* Build-time companion of fr_pipeline_prepare / fr_pipeline_compile_plan: compiles the kernels
+ * a pipeline with thresholds of this KIND would get at run time - `h_quant` (K, q_stride) needs
+ * the right infinities only (a band's shape is an immediate), every finite value stands for any
+ * other - into the directory `dir` in the cache's file format, without a device: the sieves as
+ * immediates, and the plan (a small one as straight-line code for `groups` groups per series, a
+ * large one in pieces).  fruits_amd/gen_bundle.py builds fruits_amd/jit_bundle with it; the
+ * library looks there behind the user's cache and in front of the compiler.  Returns the number
+ * of code objects the directory now holds for this pipeline, < 0 on error (`msg`). */
+int32_t fr_pipeline_bundle(fr_pipeline_t *pipeline, const double *h_quant, int32_t groups,
+                           const char *dir, char *msg, int64_t msg_cap);
 /* Fuses the slice's preparateurs into the launch: fr_pipeline_run then takes the RAW
  * (N, D, T) input and forms the prepared rows while it stages them - no prepared tensor is
  * written or read.  Covers the chains of the experiment fruits:

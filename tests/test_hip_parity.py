@@ -2341,3 +2341,33 @@ def test_zz_parity_bars():
         assert sum(r["exposed"] for r in big) <= 5e-2 * sum(r["entries"] for r in big), big
     maxplus = [r for r in STRICT_REPORT if r["cls"] == "max-plus"]
     assert maxplus and sum(r["differ"] for r in maxplus) == 0, maxplus
+
+
+def test_bundled_kernels_serve_a_cold_cache(fr, tmp_path, monkeypatch):
+    """The kernels shipped with the build (fruits_amd/jit_bundle, fruits_amd/gen_bundle.py): with
+    an EMPTY user cache and without asking the compiler (fr_pipeline_prepare_cached never
+    compiles) the pipelines of BASELINE configs 3 and 4 get their own kernels - the plan as
+    straight-line code / in pieces - and compute what the generic kernel computes."""
+    import fruits_amd.gen_bundle as gb
+    if not gb.up_to_date():
+        pytest.skip("fruits_amd/jit_bundle is not built (python -m fruits_amd.gen_bundle)")
+    monkeypatch.setenv("FRUITS_HIP_JIT_CACHE", str(tmp_path / "empty"))
+    monkeypatch.setenv("FRUITS_AMD_AUTO_PREPARE", "0")
+    rng = np.random.default_rng(8)
+    for weight, N in ((4, 1536), (6, 96)):
+        X = rng.standard_normal((N, 3, 1024)).cumsum(axis=2) / 5.0
+        fruit = fr.Fruit("bundled")
+        fruit.add(fr.preparation.INC)
+        fruit.add(fr.ISS(fr.words.of_weight(weight, dim=2), mode=fr.ISSMode.EXTENDED,
+                         weighting=fr.iss.weighting.Indices()))
+        fruit.add(fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END)
+        fruit.get_slice().fit_sample_size = 64 / N
+        np.random.seed(2)
+        fruit.fit(X)
+        generic = fruit.transform(X)
+        pipe = fruit.get_slice()._fused(1024)
+        assert pipe.jit_loaded() == 0 and pipe.pieces_loaded() == 0
+        pipe.prepare_cached(N)
+        assert pipe.fully_compiled(), "the bundle did not serve this pipeline"
+        assert not os.path.isdir(tmp_path / "empty") or os.listdir(tmp_path / "empty") == []
+        np.testing.assert_array_equal(fruit.transform(X), generic)
