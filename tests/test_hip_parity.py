@@ -1682,6 +1682,7 @@ def test_own_kernel_compiled_in_the_background(fr, tmp_path, monkeypatch):
     launches before the kernel is loaded take the generic instance, later ones the compiled one -
     all with the same features."""
     monkeypatch.setenv("FRUITS_HIP_JIT_CACHE", str(tmp_path / "jit"))   # (a cold cache: a real compilation)
+    monkeypatch.setenv("FRUITS_HIP_JIT_BUNDLE", "")      # (and none of the kernels shipped with the build)
     monkeypatch.setenv("FRUITS_AMD_AUTO_PREPARE", "1")
     rng = np.random.default_rng(11)
     X = rng.standard_normal((1024, 2, 1024)).cumsum(axis=2) / 5.0
