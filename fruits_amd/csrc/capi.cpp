@@ -1211,15 +1211,20 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
         return p.static_prog[g] > 0 || (js != nullptr && js->progs.count(g) != 0);
       };
       // Groups per series.  Small batches: as many groups as the schedule has, to fill the
-      // chip.  Batches whose input + output are at most twice the 256 MiB Infinity Cache: ONE
+      // chip.  Batches whose input + output are at most 1.4 x the 256 MiB Infinity Cache: ONE
       // group - every input row is then read once, with non-temporal loads that do not
       // allocate in that cache, where the input would only evict output lines (config 2:
       // 69 -> 56 us).  Larger batches stream through HBM whatever is done; there the
       // finer units balance better (N = 8192: 273 vs 283 us).
+      // (round 4, tools/static_window.py, fraction of 8 TB/s, one group + nt / three groups /
+      // no static program: N = 2048 (1.31 x the cache) 0.763 / 0.654 / 0.656; 2304 (1.48 x)
+      // 0.637 / 0.679 / 0.623; 3072 (1.97 x) 0.638 / 0.712 / 0.675; 4096 0.719 / 0.713 / 0.680 -
+      // the window used to end at 2 x, where the sweep showed the static program behind the
+      // walk without one)
       const int gmax = have(3) ? 3 : (have(2) ? 2 : 1);
       const double footprint = 8.0 * (double)N * (double)T * (double)(p.dims_used + p.K);
       const bool cache_sized = N >= kStaticSplitBelow &&
-                               footprint <= 2.0 * 256.0 * 1024.0 * 1024.0;
+                               footprint <= 0.01 * debug_knob("static_cache_x100", 140) * 256.0 * 1024.0 * 1024.0;
       static_groups = asked > 0 ? asked : (cache_sized ? 1 : gmax);
       // Batches that stream through HBM (beyond twice the cache): FOUR resident workgroups per
       // CU instead of six - fewer concurrent write streams suit the memory system better

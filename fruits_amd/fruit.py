@@ -518,6 +518,7 @@ class FruitSlice:
         iterated sums on); a compilation (seconds the first time) runs on a helper thread for
         launches from 256 MiB on - this launch and any other before it is done take the generic
         kernel, later ones the compiled one (same results).  FRUITS_AMD_AUTO_PREPARE=0: never,
+        =cached: what the disk cache and the kernels shipped with the build hold, no compiler,
         =all: every fused launch, and waited for; ``pipeline.prepare(N)`` is the explicit,
         synchronous way."""
         mode = os.environ.get("FRUITS_AMD_AUTO_PREPARE", "1")
@@ -536,7 +537,7 @@ class FruitSlice:
             # or the kernels shipped with the build hold: here, on the caller's thread ...
             pipe.prepare_cached(N)
             # ... the helper thread only compiles and loads what is still missing
-            if size >= (256 << 20) and not pipe.fully_compiled():
+            if size >= (256 << 20) and mode != "cached" and not pipe.fully_compiled():
                 pipe.prepare_in_background(N)
         else:
             return

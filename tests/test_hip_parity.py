@@ -1603,7 +1603,7 @@ def _debug_knobs(monkeypatch, **knobs):
     monkeypatch.setenv("FRUITS_HIP_DEBUG", ",".join(keep + [f"{k}={v}" for k, v in knobs.items()]))
 
 
-@pytest.mark.parametrize("which", ["indices", "total_inc", "arctic", "chunks", "bands_means", "repeats",
+@pytest.mark.parametrize("which", ["total_inc", "arctic", "chunks", "bands_means", "repeats",
                                    "high_orders", "bayesian_l1", "wide_root"])
 def test_large_plan_in_pieces(fr, which, monkeypatch):
     """A plan of more than 128 nodes runs IN PIECES (csrc/plan.h PiecedProgram, walk_fused.h
