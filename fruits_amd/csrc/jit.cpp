@@ -15,6 +15,7 @@
 #include "jit.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -296,6 +297,9 @@ static bool compile_source(const std::string &src, const char *kernel_expr, cons
   if (!file.empty()) {
     if (read_cached(file, key_hash, code)) {
       if (from_cache) *from_cache = true;
+      // (a bundle being rebuilt: what is still wanted is marked by its time stamp, the rest is
+      // swept afterwards - fruits_amd/gen_bundle.py)
+      if (into != nullptr) (void)utimensat(AT_FDCWD, file.c_str(), nullptr, 0);
       return true;
     }
     code.clear();

@@ -93,8 +93,16 @@ class Fruit:
     def fit(self, X: np.ndarray, cache: Optional[SharedSeedCache] = None) -> None:
         X = _check_batch(X)
         cache_ = SharedSeedCache(X) if cache is None else cache
-        for slc in self._slices:
-            slc.fit(X, cache=cache_)
+        # the slices are started one after the other; the device-side selections of a slice's
+        # thresholds (fr_select_ranks on a helper thread) run while the next slice is set up, and
+        # are waited for at the end
+        deferred: list = []
+        try:
+            for slc in self._slices:
+                slc.fit(X, cache=cache_, deferred=deferred)
+        finally:
+            for finish in deferred:
+                finish()
         # (the selection scratch of the device-side fit lives outside torch's allocator: hand it
         # back - a transform needs none of it)
         nat.release_scratch()
@@ -341,11 +349,15 @@ class FruitSlice:
                                                         iss_index + 1, upto)
 
     # ---- device-side fit ------------------------------------------------------------
-    def _fit_on_device(self, Sd, cache) -> bool:
+    def _fit_on_device(self, Sd, cache, deferred: Optional[list] = None) -> bool:
         """Fits the per-iterated-sum sieve copies without moving the fit sample's
         iterated sums to the host: the order statistics np.quantile interpolates
         between are selected on the device (fr_select_ranks).  Returns False when a
-        sieve or the ISS layout needs the host path."""
+        sieve or the ISS layout needs the host path.  ``deferred``: the selections are only
+        STARTED (one helper thread, in order); a closure per word batch that waits for its
+        selection and hands the thresholds to the sieve copies is appended - Fruit.fit runs them
+        when every slice has been started, so that a slice's selection runs on the device while
+        this thread is busy with the next slice."""
         from .sieving.segment import SegmentSieve
         if os.environ.get("FRUITS_AMD_DEVICE_FIT", "1") == "0" or len(self._iss) != 1:
             return False
@@ -390,11 +402,17 @@ class FruitSlice:
                     if reqs is not None:
                         owners.append((sieve, reqs, next(row_jobs)))
                 copies.append(fitted)
-            vals = pending.result() if pending is not None else np.zeros(0)
-            for sieve, reqs, idx in owners:
-                sieve._set_quantiles_from_stats(reqs, [vals[a] for a, _ in idx],
-                                                [vals[b] for _, b in idx])
+            def finish(pending=pending, owners=owners, block=block):
+                # (`block` lives until its selection is done)
+                vals = pending.result() if pending is not None else np.zeros(0)
+                for sieve, reqs, idx in owners:
+                    sieve._set_quantiles_from_stats(reqs, [vals[a] for a, _ in idx],
+                                                    [vals[b] for _, b in idx])
             self._sieves_extended.extend(copies)
+            if deferred is None:
+                finish()
+            else:
+                deferred.append(finish)
         return True
 
     # ---- fused ISS + sieves (one launch, no (K, N, T) tensor) --------------------
@@ -601,7 +619,8 @@ class FruitSlice:
             iss._attach_cache(None)
 
     # ---- fit / transform ----------------------------------------------------
-    def fit(self, X: np.ndarray, cache: Optional[SharedSeedCache] = None) -> None:
+    def fit(self, X: np.ndarray, cache: Optional[SharedSeedCache] = None,
+            deferred: Optional[list] = None) -> None:
         self._compile()
         self._fused_cache = {}
         X = _check_batch(X)
@@ -629,7 +648,7 @@ class FruitSlice:
             self._fitted = True
             return
         self._sieves_extended = []
-        if self._fit_on_device(Sd, cache):
+        if self._fit_on_device(Sd, cache, deferred):
             self._fitted = True
             return
         for itsum in self._iterate_iss_device(Sd):

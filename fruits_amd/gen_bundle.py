@@ -122,10 +122,13 @@ def build_bundle(force: bool = False, jobs: int = 0, verbose: bool = True) -> st
     (a large plan compiles its piece types on threads of its own)."""
     if not force and up_to_date():
         return BUNDLE
-    if os.path.isdir(BUNDLE):
+    if force and os.path.isdir(BUNDLE):
         for f in os.listdir(BUNDLE):
             os.remove(os.path.join(BUNDLE, f))
     os.makedirs(BUNDLE, mode=0o700, exist_ok=True)
+    # (incremental: a code object's file name hashes its source, so what an earlier build left
+    # and is still wanted is found - and touched - instead of compiled again; the rest is swept)
+    started = time.time() - 2.0
     import fruits_amd as fr
     entries = manifest(fr)
     # the entries with the most to compile first (nodes x sieves); every entry compiles its
@@ -143,6 +146,9 @@ def build_bundle(force: bool = False, jobs: int = 0, verbose: bool = True) -> st
             lines.append(f"{name}: {n} code objects, {dt:.0f} s")
             if verbose:
                 print(f"[bundle] {lines[-1]}", flush=True)
+    for f in os.listdir(BUNDLE):
+        if f.endswith(".co") and os.path.getmtime(os.path.join(BUNDLE, f)) < started:
+            os.remove(os.path.join(BUNDLE, f))
     files = sorted(f for f in os.listdir(BUNDLE) if f.endswith(".co"))
     with open(STAMP, "w") as f:
         f.write(manifest_key() + "\n" + "\n".join(lines) + "\n" + "\n".join(files) + "\n")
