@@ -1171,7 +1171,7 @@ __global__ __launch_bounds__(kWalkThreads) WALK_KERNEL_ATTR void iss_walk_kernel
   // groups of one series meet in one XCD's L2 (speed only, never correctness).  In the
   // first round the resident workgroups write CONSECUTIVE series of every output plane.
   // (Round 2 tried contiguous spans of units per workgroup - even spans, one staging shared
-  // by the groups of a series: 5-10 % slower at every batch size)
+  // by the groups of a series: 5-10 % slower at every batch size, docs/history.md 4.6.)
   int sink = 0;  // next-series prefetch (see below): one word per 128-byte line of the rows
   int pf_val = 0, pf_off = -1;
   static_assert(C::TEAM == 4 && C::MODE == 0,
