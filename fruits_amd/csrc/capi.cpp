@@ -1130,6 +1130,13 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
       a.cw_Lmax = c.Lmax;
     }
     a.cw_x_unit_stride = c.x_unit_stride;
+    if (fu && fu->prep) {
+      if (c.x_unit_stride != 0)
+        return fail(FR_E_LIMIT, w + ": a CosWISS with per-unit inputs (ffn) has no fused preparation");
+      a.prep = fu->prep;
+      a.stats = fu->stats;
+      a.n_prep = fu->n_prep;
+    }
     a.packed = (T <= 384 && debug_knob("packed", 1) != 0) ? 1 : 0;
     a.vec_ok = (T % 2 == 0) && aligned16(d_X) && aligned16(trig) &&
                (fu || (aligned16(d_out) && (out_k_stride % 2 == 0) && (out_n_stride % 2 == 0)));
@@ -1355,8 +1362,6 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
         return fail(FR_E_LIMIT, w + ": letter-sum (argmax) plans have no fused walk");
     }
     if (fu->prep) {
-      if (packed)
-        return fail(FR_E_LIMIT, w + ": the fused preparation needs the cooperative kernel");
       a.prep = fu->prep;
       a.stats = fu->stats;
       a.n_prep = fu->n_prep;
@@ -1799,9 +1804,12 @@ int fr_pipeline_set_preparation(fr_pipeline_t *pl, int32_t D, int32_t inc_lag, i
   pl->d_prep = nullptr;
   pl->prep_D = pl->prep_n = pl->prep_std = 0;
   if (inc_lag == 0 && standardize == 0) return FR_OK;   // nothing to fuse
-  if (p.cos || launch_shape(p, 1 << 20, pl->T, 0).packed)
-    return fail(FR_E_LIMIT, "fr_pipeline_set_preparation: only the cooperative walk kernel "
-                            "(Reals / Arctic / Bayesian plans, T > 384) fuses the preparation");
+  // (every fused kernel forms the prepared rows itself since round 4: the cooperative walk in its
+  // staging, the wave-per-series kernels in theirs, CosWISS where it reads a letter's rows - all
+  // but a CosWISS with the randomised ffn, whose units read transformed copies of the input)
+  if (p.cos && p.cos->x_unit_stride != 0)
+    return fail(FR_E_LIMIT, "fr_pipeline_set_preparation: a CosWISS with per-unit inputs (ffn) reads "
+                            "transformed copies of the prepared input");
   const int n_prep = as_new ? 2 * D : D;
   std::vector<int32_t> tab((size_t)n_prep * 4, 0);
   for (int d = 0; d < n_prep; ++d) {

@@ -51,6 +51,37 @@ __device__ __forceinline__ void load_global_row(const WalkCtx &cx, const double 
     }
 }
 
+// The same elements of PREPARED dimension `dp` of series n, formed from the RAW input on the way
+// (fused preparation, IssArgs::prep - INC / NEW(INC) / STD exactly as walk_fused.h's staging forms
+// them: x[t] - x[t - lag] with the zero padding of fruits/cache.py:8-13, then (x - mean) / (std +
+// eps) with the statistics of row_stats_kernel): no prepared tensor is written or read.
+template <class C>
+__device__ __forceinline__ void load_prepared_row(const WalkCtx &cx, const IssArgs &a, int64_t n, int dp,
+                                                  double (&v)[C::EP]) {
+  constexpr int E = C::E, P = C::P;
+  const int raw = as_const(a.prep)[4 * dp], lag = as_const(a.prep)[4 * dp + 1];
+  const bool standardise = as_const(a.prep)[4 * dp + 2] != 0;
+  const double *gp = a.X + (n * a.D + raw) * a.T;
+  double mean = 0.0, den = 1.0;
+  if (standardise) {
+    mean = as_const(a.stats)[(n * a.n_prep + dp) * 2];
+    den = as_const(a.stats)[(n * a.n_prep + dp) * 2 + 1];
+  }
+#pragma unroll
+  for (int h = 0; h < P; ++h)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int64_t t = cx.t0 + cx.wave * C::SPAN + h * C::PIECE + cx.lane * E + e;
+      double x = 0.0;
+      if (t < a.T) {
+        x = gp[t];
+        if (lag > 0) x = t >= lag ? x - gp[t - lag] : 0.0;
+        if (standardise) x = (x - mean) / den;
+      }
+      v[h * E + e] = x;
+    }
+}
+
 // v *= sin^(S-M) * cos^M by repeated multiplication, sines first (cos.py:37-40)
 template <int S, int M, int EP>
 __device__ __forceinline__ void mul_trig(double (&v)[EP], const double (&sn)[EP],
@@ -245,7 +276,10 @@ __device__ __forceinline__ void coswiss_unit(WalkCtx &cx, const double *xrow, co
     for (int f = fb; f < fe; ++f) {
       const int code = as_const(a.factors)[f];
       double v[EP];
-      load_global_row<C>(cx, xrow + (int64_t)(code & FAC_ROW_MASK) * a.T, v);
+      if (C::MODE == 1 && a.prep != nullptr)
+        load_prepared_row<C>(cx, a, cx.series, code & FAC_ROW_MASK, v);
+      else
+        load_global_row<C>(cx, xrow + (int64_t)(code & FAC_ROW_MASK) * a.T, v);
       if (code & FAC_DIV) {
 #pragma unroll
         for (int i = 0; i < EP; ++i) s[i] = s[i] / v[i];

@@ -53,6 +53,35 @@ __global__ __launch_bounds__(kWalkThreads) void iss_walk_packed_kernel(const Iss
     // hands back to it (wave-local, no barrier)
     for (int r = 0; r < a.R; ++r) {
       const int src = as_const(a.row_src)[r];
+      if (C::MODE == 1 && a.prep != nullptr && src >= 0) {
+        // fused preparation (IssArgs::prep): the prepared row formed from the RAW input on the
+        // way - INC / NEW(INC) / STD exactly as walk_fused.h's staging forms them
+        const int raw = as_const(a.prep)[4 * src], lag = as_const(a.prep)[4 * src + 1];
+        const bool standardise = as_const(a.prep)[4 * src + 2] != 0;
+        const double *xp = a.X + (n * a.D + raw) * a.T;
+        double mean = 0.0, den = 1.0;
+        if (standardise) {
+          mean = as_const(a.stats)[(n * a.n_prep + src) * 2];
+          den = as_const(a.stats)[(n * a.n_prep + src) * 2 + 1];
+        }
+#pragma unroll
+        for (int h = 0; h < C::P; ++h) {
+          const int i = h * C::PIECE + cx.lane * 2;
+          double e[2] = {0.0, 0.0};
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int64_t t = i + q;
+            if (t < a.T) {
+              double x = xp[t];
+              if (lag > 0) x = t >= lag ? x - xp[t - lag] : 0.0;
+              if (standardise) x = (x - mean) / den;
+              e[q] = x;
+            }
+          }
+          *reinterpret_cast<vd2 *>(rows_w + r * C::CHUNK + i) = vd2{e[0], e[1]};
+        }
+        continue;
+      }
       const double *gp = src >= 0
                              ? a.X + (n * a.D + src) * a.T
                              : a.aux + (int64_t)(-src - 1) * a.aux_tab_stride + n * a.aux_n_stride;

@@ -1321,13 +1321,14 @@ def test_fused_ragged_and_multichunk(fr, T):
     compare_features(got, ref, labels, expo, what=f"ragged / multi-chunk T={T}")
 
 
-@pytest.mark.parametrize("T", [511, 1024, 1500])
+@pytest.mark.parametrize("T", [200, 300, 511, 1024, 1500])
 @pytest.mark.parametrize("chain", ["INC", "INC3", "NEW_INC", "STD", "INC_STD", "NEW_INC_STD0"])
 def test_fused_preparation(fr, monkeypatch, chain, T):
     """INC / NEW(INC) / STD formed while the fused launch stages the RAW rows
     (fr_pipeline_set_preparation) against the same pipeline on a materialised prepared
     input - bit for bit (same arithmetic, same summation order of the statistics) - and
-    against the oracle; Reals + Indices and Arctic slices, single and multi chunk."""
+    against the oracle; Reals + Indices and Arctic slices; the wave-per-series kernels of short
+    series (T = 200, 300: round 4), one chunk and several."""
     preps = {"INC": [{"kind": "INC"}], "INC3": [{"kind": "INC", "shift": 3}],
              "NEW_INC": [{"kind": "NEW", "inner": {"kind": "INC"}}], "STD": [{"kind": "STD"}],
              "INC_STD": [{"kind": "INC"}, {"kind": "STD"}],
@@ -1366,6 +1367,41 @@ def test_fused_preparation(fr, monkeypatch, chain, T):
     compare_features(got, ref, labels, expo, what=f"fused preparation {chain} T={T}")
     monkeypatch.delenv("FRUITS_AMD_FUSED_PREP")
     strict_transform_parity(fruit, spec, X, X, labels, np_seed=1, what=f"fused preparation {chain} T={T}")
+
+
+@pytest.mark.parametrize("T", [300, 700, 1500])
+@pytest.mark.parametrize("chain", ["INC", "NEW_INC_STD", "STD0"])
+def test_fused_preparation_coswiss(fr, monkeypatch, chain, T):
+    """The same for a CosWISS slice (round 4): the kernel forms the prepared rows where it reads a
+    letter's rows from the RAW input (coswiss.h, load_prepared_row) - wave-per-unit kernels
+    (T = 300), the cooperative one, several time chunks; dropout rides along; equal to the
+    pipeline on a materialised prepared input bit for bit, and to the oracle."""
+    preps = {"INC": [{"kind": "INC"}],
+             "NEW_INC_STD": [{"kind": "NEW", "inner": {"kind": "INC"}}, {"kind": "STD"}],
+             "STD0": [{"kind": "STD", "var": False}]}[chain]
+    D = 2
+    Dp = 2 * D if chain.startswith("NEW") else D
+    rng = np.random.default_rng(T + len(chain))
+    X = rng.standard_normal((14, D, T)).cumsum(axis=2) / 4.0
+    words = ["[1]", "[1][%d]" % Dp, "[%d][1%d]" % (Dp, Dp)]
+    spec = {"slices": [
+        {"preps": preps, "iss": [{"kind": "CosWISS", "words": words, "freqs": [0.125, 0.5], "exponent": 2,
+                                  "total_weighting": chain != "INC"}],
+         "sieves": [{"kind": "NPI", "q": [0.5, 1.0]}, {"kind": "NPI", "inc": 2}, {"kind": "END"}],
+         "fit_sample_size": 1.0}]}
+    fruit = build_fruit(fr, spec)
+    np.random.seed(1)
+    fruit.fit(X)
+    got = fruit.transform(X)
+    pipe = fruit.get_slice()._fused(T)
+    assert pipe is not None and pipe.raw_dims == D          # the raw input went in
+    monkeypatch.setenv("FRUITS_AMD_FUSED_PREP", "0")
+    plain = fruit.transform(X)
+    assert fruit.get_slice()._fused(T).raw_dims == 0
+    np.testing.assert_array_equal(got, plain)
+    ref, expo = oracle_features(spec, X, X, np_seed=1)
+    labels = [fruit.label(i) for i in range(fruit.nfeatures())]
+    compare_features(got, ref, labels, expo, what=f"fused preparation CosWISS {chain} T={T}")
 
 
 @pytest.mark.parametrize("T", [1, 5, 7, 8, 9, 127, 128, 129, 1000, 1024, 1025, 4096, 8192, 8193, 20000])
