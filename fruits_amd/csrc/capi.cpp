@@ -893,10 +893,21 @@ void ensure_fused_static(fr_pipeline &pl, const fr::FusedKey &key, const fr::Fus
 // ---- a large plan in pieces (plan.h, PiecedProgram) ----------------------------------------
 // Plans of more than kFusedStaticMaxNodes nodes (developer knobs: pieces=0 - never;
 // piece_min=M - from M nodes on; piece_nodes=P - pieces of at most P nodes).
-int piece_nodes_knob() { return debug_knob("piece_nodes", fr::kFusedPieceNodes); }
-bool pieces_eligible(const fr::Plan &p) {
+// Nodes of the largest piece: a body's code grows with nodes x feature ops per node, and the
+// compiler's time faster than that - pipelines of more than two ops per output row (the experiment
+// fruits' seven sieves: four ops with MPI sums and second differences) get pieces of half the size
+// (the 115-node body of of_weight(6,2) with four ops: ~200 s on the build host, its 33 / 47 / 62-node
+// bodies ~60 s together).
+int piece_nodes_knob(const fr_pipeline &pl) {
+  return debug_knob("piece_nodes", pl.n_ops_eff > 2 ? fr::kFusedPieceNodes / 2 : fr::kFusedPieceNodes);
+}
+bool pieces_eligible(const fr_pipeline &pl) {
+  const fr::Plan &p = *pl.plan->p;
+  // (with more than two feature ops per output row a whole plan of ~100 nodes is as much code as
+  // a 200-node plan with two - a minute and more of compiler: in pieces from 65 nodes on)
+  const int from = pl.n_ops_eff > 2 ? fr::kFusedPieceNodes / 2 + 1 : fr::kFusedStaticMaxNodes + 1;
   return !p.cos && !p.letter_sum && debug_knob("pieces", 1) != 0 && env_int("FRUITS_HIP_JIT", 1) != 0 &&
-         (int)p.nodes.size() >= debug_knob("piece_min", fr::kFusedStaticMaxNodes + 1);
+         (int)p.nodes.size() >= debug_knob("piece_min", from);
 }
 
 // Uploads the tables of every piece type once per plan.  Caller holds p.mu; never inside a capture.
@@ -941,7 +952,7 @@ int ensure_piece_tables(fr::Plan &p, fr::PiecedProgram &pp, const char *who) {
 // never inside a capture.  FR_OK also when the plan has no cover.
 int ensure_pieces_tables(fr_pipeline &pl, const fr::FusedKey &key, const char *who) {
   fr::Plan &p = *pl.plan->p;
-  const int max_piece = piece_nodes_knob();
+  const int max_piece = piece_nodes_knob(pl);
   fr::PiecedProgram *pp;
   {
     std::lock_guard<std::mutex> lock(p.mu);
@@ -1790,7 +1801,7 @@ int64_t fr_pipeline_workspace_bytes(const fr_pipeline_t *pl, int64_t N, int64_t 
   if (!pl->mpi_cols.empty()) b += align_up((size_t)N * pl->per_sum * p.K * 8, 256);
   if (pl->prep_n > 0 && pl->prep_std != 0) b += align_up((size_t)N * pl->prep_n * 16, 256);
   // (a plan in pieces leaves its features in walk order first)
-  if (pieces_eligible(p)) b += align_up((size_t)N * pl->per_sum * p.K * 8, 256);
+  if (pieces_eligible(*pl)) b += align_up((size_t)N * pl->per_sum * p.K * 8, 256);
   return (int64_t)b;
 }
 
@@ -1865,7 +1876,7 @@ static int pipeline_prepare(fr_pipeline_t *pl, int64_t N, int32_t groups, bool c
   LaunchShape shape;
   if (fused_instance_of(pl, N, groups, key, shape)) {
     // (a large plan runs in pieces: their tables go up here, on the caller's thread)
-    if (pieces_eligible(p)) {
+    if (pieces_eligible(*pl)) {
       rc = ensure_pieces_tables(*pl, key, "fr_pipeline_prepare");
       if (rc != FR_OK) return rc;
     }
@@ -1898,7 +1909,7 @@ static int pipeline_compile_plan(fr_pipeline_t *pl, int64_t N, int32_t groups, b
   if (!fused_instance_of(pl, N, groups, key, shape) || debug_knob("fused_static", 1) == 0) return FR_OK;
   // a large plan: in pieces, every piece type straight-line code in a kernel of its own; the
   // node shapes below only where the plan has no such cover
-  if (pieces_eligible(p)) {
+  if (pieces_eligible(*pl)) {
     if (!cache_only) {
       int rc = ensure_pieces_tables(*pl, key, "fr_pipeline_compile_plan");
       if (rc != FR_OK) return rc;
@@ -1966,11 +1977,11 @@ int32_t fr_pipeline_bundle(fr_pipeline_t *pl, const double *h_quant, int32_t gro
       errs.push_back(err);
     }
   };
-  if (pieces_eligible(p)) {                    // a large plan: a kernel per piece type
+  if (pieces_eligible(*pl)) {                  // a large plan: a kernel per piece type
     const fr::PiecedProgram *pp;
     {
       std::lock_guard<std::mutex> lock(p.mu);
-      pp = &fr::pieced(p, piece_nodes_knob(), debug_knob("piece_unit", 0));
+      pp = &fr::pieced(p, piece_nodes_knob(*pl), debug_knob("piece_unit", 0));
     }
     const int n_types = pp->ok ? (int)pp->types.size() : 0;
     // the largest bodies first (the compiler's time grows faster than a body); job -1: the kernel
@@ -2115,7 +2126,7 @@ int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, 
     }
   }
   const int32_t *walk_of_row = nullptr;
-  if (pieces_eligible(p)) {
+  if (pieces_eligible(*pl)) {
     size_t off = plan_ws;
     if (!pl->mpi_cols.empty()) off += align_up((size_t)N * F * 8, 256);
     if (pl->prep_n > 0 && pl->prep_std != 0) off += align_up((size_t)N * pl->prep_n * 16, 256);

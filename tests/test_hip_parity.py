@@ -1620,7 +1620,8 @@ def test_fused_kernel_compiled_for_its_pipeline(fr, which, plan_too, monkeypatch
     pipe.prepare(X.shape[0])
     if pipe.jit_loaded() == 0:
         pytest.skip("hipRTC is not installed")
-    if which.startswith("large_plan") and plan_too:
+    pieces_on = "pieces=0" not in os.environ.get("FRUITS_HIP_DEBUG", "")     # (tools/gpu_knobs.sh)
+    if which.startswith("large_plan") and plan_too and pieces_on:
         assert pipe.pieces_loaded() >= 2      # (more than 128 nodes: in pieces, a kernel per piece type)
     else:
         assert pipe.jit_loaded(static_only=True) == (1 if plan_too else 0)
@@ -2388,6 +2389,8 @@ def test_bundled_kernels_serve_a_cold_cache(fr, tmp_path, monkeypatch):
     import fruits_amd.gen_bundle as gb
     if not gb.up_to_date():
         pytest.skip("fruits_amd/jit_bundle is not built (python -m fruits_amd.gen_bundle)")
+    if "pieces=0" in os.environ.get("FRUITS_HIP_DEBUG", "") or os.environ.get("FRUITS_HIP_JIT", "1") == "0":
+        pytest.skip("the knob sweep switched the bundled kernels' paths off")
     monkeypatch.setenv("FRUITS_HIP_JIT_CACHE", str(tmp_path / "empty"))
     monkeypatch.setenv("FRUITS_AMD_AUTO_PREPARE", "0")
     rng = np.random.default_rng(8)
