@@ -1641,7 +1641,7 @@ def _debug_knobs(monkeypatch, **knobs):
 
 
 @pytest.mark.parametrize("which", ["total_inc", "arctic", "chunks", "bands_means", "repeats",
-                                   "high_orders", "bayesian_l1", "wide_root"])
+                                   "high_orders", "bayesian_l1", "wide_root", "many_ops"])
 def test_large_plan_in_pieces(fr, which, monkeypatch):
     """A plan of more than 128 nodes runs IN PIECES (csrc/plan.h PiecedProgram, walk_fused.h
     fwalk_pieces): chains walked by the record loop, bodies - whole sub-tries, equal ones one
@@ -1650,12 +1650,14 @@ def test_large_plan_in_pieces(fr, which, monkeypatch):
     seconds of compiler): the same features as the record loop, bit for bit (band means: wave
     sums meet in LDS in arrival order) - weightings, semirings, several time chunks (carries
     counted per unit), repeated words (more than two output rows per node), high differencing
-    orders, a root with many small sub-tries."""
+    orders, a root with many small sub-tries (on a batch whose size is no multiple of 8: plain
+    unit numbering), nine feature ops per output row on two time chunks (a unit's features exceed
+    the LDS window: the kernels keep the flush test and every chunk adds onto the last one's)."""
     monkeypatch.setenv("FRUITS_AMD_AUTO_PREPARE", "0")
-    T = {"chunks": 2100, "high_orders": 1500}.get(which, 600)
+    T = {"chunks": 2100, "high_orders": 1500, "many_ops": 1100}.get(which, 600)
     rng = np.random.default_rng(len(which))
     D = 3 if which == "wide_root" else 2
-    X = rng.standard_normal((24, D, T)).cumsum(axis=2) / 5.0
+    X = rng.standard_normal((21 if which == "wide_root" else 24, D, T)).cumsum(axis=2) / 5.0
     W = fr.iss.weighting
     mode = fr.ISSMode.EXTENDED
     if which == "repeats":
@@ -1670,6 +1672,7 @@ def test_large_plan_in_pieces(fr, which, monkeypatch):
               "total_inc": dict(weighting=W.Indices(total=True)),
               "arctic": dict(semiring=fr.iss.semiring.Arctic(), weighting=W.Indices(total=True)),
               "chunks": dict(weighting=W.Indices()),
+              "many_ops": dict(weighting=W.Indices()),
               "bands_means": dict(weighting=W.Indices()),
               "high_orders": dict(weighting=W.Indices()),
               "bayesian_l1": dict(semiring=fr.iss.semiring.Bayesian(), weighting=W.L1())}[which]
@@ -1683,6 +1686,9 @@ def test_large_plan_in_pieces(fr, which, monkeypatch):
                   fr.sieving.NPI(inc=2), fr.sieving.MPI(inc=1), fr.sieving.END)
     elif which == "high_orders":
         fruit.add(fr.sieving.NPI(inc=3), fr.sieving.NPI(q=(0.4, 1.0), inc=-1), fr.sieving.END(cut=[T // 2, -1]))
+    elif which == "many_ops":
+        fruit.add(fr.sieving.NPI(q=(0.2, 0.4, 0.6, 0.8, 1.0)), fr.sieving.NPI(q=(0.1, 0.5, 1.0), inc=0),
+                  fr.sieving.END(cut=[T // 3, 2 * T // 3, -1]))
     else:
         fruit.add(fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.NPI, fr.sieving.END)
     fruit.get_slice().fit_sample_size = 1.0

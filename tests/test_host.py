@@ -660,3 +660,47 @@ def test_static_program_identity_includes_dimensions():
     assert index(w22) > 0
     assert index([s.replace("2", "3") for s in w22]) == 0          # dimensions (1, 3)
     assert index([s.replace("2", "3").replace("1", "2") for s in w22]) == 0   # dimensions (2, 3)
+
+
+def test_bundle_compiles_without_a_device(tmp_path, monkeypatch):
+    """fr_pipeline_bundle (what fruits_amd/gen_bundle.py builds fruits_amd/jit_bundle with): the
+    kernels a pipeline would compile at run time - the sieves as immediates, and the plan as
+    straight-line code or in pieces - compiled into a directory WITHOUT a GPU; a second call finds
+    them there; placeholder thresholds carry the infinities only."""
+    from fruits_amd import gen_bundle as gb
+    from fruits_amd.fruit import FruitSlice
+    monkeypatch.setenv("FRUITS_HIP_JIT_CACHE", "")
+    out = tmp_path / "bundle"
+    out.mkdir(mode=0o700)
+    S = fr.sieving
+    cases = [
+        # 9 nodes: straight-line plan; 33 nodes with pieces of <= 12: a plan in pieces
+        (fr.words.of_weight(2, 2), {}, 2),
+        (fr.words.of_weight(3, 2), {"FRUITS_HIP_DEBUG": "piece_min=20,piece_nodes=12"}, None),
+    ]
+    for words, env, want in cases:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        iss = fr.ISS(words, mode=fr.ISSMode.EXTENDED, weighting=fr.iss.weighting.Indices())
+        plan = iss._plan(0, len(words))
+        sieves = [S.NPI(q=(0.5, 1.0)), S.END()]
+        specs, _, _ = FruitSlice._pipeline_specs(sieves, 1024)
+        pipe = nat.Pipeline(plan, specs, 1024)
+        quant = gb.placeholder_quantiles(sieves, plan.rows, pipe.q_stride)
+        assert np.isinf(quant[:, 1]).all() and np.isfinite(quant[:, 0]).all()
+        try:
+            n = pipe.bundle(quant, str(out))
+        except nat.NativeError as e:
+            if "not available" in str(e):
+                pytest.skip("hipRTC is not installed")
+            raise
+        files = sorted(os.listdir(out))
+        if want is not None:
+            assert n == want and len(files) == want
+        else:
+            cover = plan.pieces(12)
+            assert n == 1 + len(cover["types"]) and len(files) == 2 + n
+        assert all(f.endswith(".gfx950.co") for f in files)
+        stamp = {f: os.path.getmtime(out / f) for f in files}
+        assert pipe.bundle(quant, str(out)) == n and sorted(os.listdir(out)) == files   # found, not rebuilt
+        assert all(os.path.getsize(out / f) > 4096 for f in files)
