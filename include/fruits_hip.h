@@ -309,9 +309,11 @@ int32_t fr_pipeline_bundle(fr_pipeline_t *pipeline, const double *h_quant, int32
  *                                                           fruits/preparation/transform.py:141-147
  * (INC with depth 1 and zero padding, _increments of fruits/cache.py:8-13; STD per series
  * and dimension).  With STD one small pre-pass computes the row statistics into the
- * workspace; everything else is the one fused launch.  D = raw input dimensions.  Returns
- * FR_E_LIMIT when the plan runs on a kernel without fused staging (wave-per-series kernels
- * for T <= 384, CosWISS): the caller then materialises the prepared input as before.
+ * workspace (np.mean / np.std in numpy's own summation order: bit-identical); everything else
+ * is the one fused launch.  D = raw input dimensions.  Every fused kernel forms the rows itself
+ * (the cooperative walk and the wave-per-series kernels in their staging, CosWISS where it reads
+ * a letter's rows); FR_E_LIMIT only for a CosWISS with per-unit inputs (the randomised ffn): the
+ * caller then materialises the prepared input as before.
  * Call before fr_pipeline_workspace_bytes / fr_pipeline_prepare; (0, 0, 0) switches it off. */
 int fr_pipeline_set_preparation(fr_pipeline_t *pipeline, int32_t D, int32_t inc_lag,
                                 int32_t as_new, int32_t standardize, double std_eps);
