@@ -1720,6 +1720,61 @@ def test_large_plan_in_pieces(fr, which, monkeypatch):
     assert slc._fused(T).pieces_loaded() == 0
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FRUITS_TEST_RANDOM_CASES", "5"))))
+def test_random_pieces_differential(fr, seed, monkeypatch):
+    """Random plans (mixed word sets with shared prefixes, repeated words, negative exponents),
+    semirings, weightings, sieves and series lengths, cut into random pieces (4 ... 24 nodes, units
+    of one item or many): the plan in pieces against the record loop - bit for bit (60 cases run
+    once in round 4: FRUITS_TEST_RANDOM_CASES=60)."""
+    monkeypatch.setenv("FRUITS_AMD_AUTO_PREPARE", "0")
+    rng = np.random.default_rng(9000 + seed)
+    D = int(rng.integers(1, 4))
+    T = int(rng.choice([400, 600, 1024, 1100, 2100]))
+    N = int(rng.choice([9, 16, 24]))
+    X = rng.standard_normal((N, D, T)).cumsum(axis=2) / 5.0
+    pool = []
+    for w in range(1, 5):
+        pool += [str(x) for x in fr.words.of_weight(w, dim=D)]
+    pool += ["[1][-1][1]", "[1][1][1][1][1]", "[%d][%d]" % (D, D)]
+    mode = fr.ISSMode.EXTENDED if rng.random() < 0.7 else fr.ISSMode.SINGLE
+    picks = rng.choice(len(pool), size=min(int(rng.integers(25, 70)), len(pool)),
+                       replace=mode == fr.ISSMode.SINGLE)
+    words = [fr.words.SimpleWord(pool[i]) for i in picks]
+    semi = rng.choice(["Reals", "Reals", "Arctic", "Bayesian"])
+    W = fr.iss.weighting
+    weighting = [None, W.Indices(), W.Indices(total=True), W.L1()][int(rng.integers(0, 4))]
+    fruit = fr.Fruit(f"random pieces {seed}")
+    if rng.random() < 0.7:
+        fruit.add(fr.preparation.INC)
+    fruit.add(fr.ISS(words, mode=mode, semiring=getattr(fr.iss.semiring, semi)(), weighting=weighting))
+    S = fr.sieving
+    sieves = [[S.NPI(q=(0.5, 1.0)), S.END()],
+              [S.NPI(), S.MPI(), S.END(cut=[T // 2, -1])],
+              [S.NPI(q=(0.25, 0.75), inc=2), S.MPI(q=(0.3, 1.0), inc=0), S.NPI(inc=0)],
+              [S.NPI(cut=[T // 3, -1], q=(0.2, 0.6, 1.0)), S.NPI(inc=3), S.END()]][int(rng.integers(0, 4))]
+    fruit.add(*sieves)
+    fruit.get_slice().fit_sample_size = 1.0
+    np.random.seed(seed)
+    fruit.fit(X)
+    pipe = fruit.get_slice()._fused(T)
+    if pipe is None or pipe.plan.nodes < 12:
+        pytest.skip("not a fused pipeline / too small a plan")
+    _debug_knobs(monkeypatch, pieces=0)
+    pipe.prepare(N)
+    if pipe.jit_loaded() == 0:
+        pytest.skip("no kernel of its own (hipRTC missing, or per-row sieve shapes)")
+    loop = fruit.transform(X)
+    piece = int(rng.integers(4, 25))
+    _debug_knobs(monkeypatch, pieces=1, piece_min=8, piece_nodes=piece, piece_unit=int(rng.choice([0, 1, 40])))
+    pipe.prepare(N)
+    assert pipe.pieces_loaded() >= 1
+    got = fruit.transform(X)
+    labels = [fruit.label(i) for i in range(fruit.nfeatures())]
+    exact = np.array(["MPI" not in lb for lb in labels])
+    np.testing.assert_array_equal(got[:, exact], loop[:, exact])
+    np.testing.assert_allclose(got, loop, rtol=1e-12, atol=1e-300)
+
+
 def test_own_kernel_compiled_in_the_background(fr, tmp_path, monkeypatch):
     """Fruit.transform asks for a large pipeline's own kernel without waiting for the compiler:
     launches before the kernel is loaded take the generic instance, later ones the compiled one -
