@@ -294,16 +294,19 @@ def _bench_fruit(fr, words, weighting, sieves):
     return fruit
 
 
-def cold_start(torch, fr, nat, which):
+def cold_start(torch, fr, nat, which, bundle=True):
     """What a one-shot user sees on a machine that has never run this fruit: an EMPTY user
     cache of run-time compiled kernels (FRUITS_HIP_JIT_CACHE = a fresh directory; the kernels
-    shipped with the build, fruits_amd/jit_bundle, are still there).  ms of the first
+    shipped with the build, fruits_amd/jit_bundle, are still there unless ``bundle`` is False -
+    the case of a fruit the build ships nothing for).  ms of the first
     Fruit.transform, of the transforms while a compilation runs in the background, seconds until
     the compiled kernels take over, ms after."""
     import tempfile
-    prev = {k: os.environ.get(k) for k in ("FRUITS_HIP_JIT_CACHE", "FRUITS_AMD_AUTO_PREPARE")}
+    prev = {k: os.environ.get(k) for k in ("FRUITS_HIP_JIT_CACHE", "FRUITS_AMD_AUTO_PREPARE", "FRUITS_HIP_JIT_BUNDLE")}
     os.environ["FRUITS_HIP_JIT_CACHE"] = tempfile.mkdtemp(prefix="fruits_cold_")
     os.environ["FRUITS_AMD_AUTO_PREPARE"] = "1"
+    if not bundle:       # (a fruit the build does not ship kernels for: everything through the compiler)
+        os.environ["FRUITS_HIP_JIT_BUNDLE"] = ""
     try:
         shape, words = {"cfg3": ((2048, 3, 1024), fr.words.of_weight(4, dim=2)),
                         "cfg4": ((8192, 3, 1024), fr.words.of_weight(6, dim=2))}[which]
@@ -420,6 +423,7 @@ def extras(torch, fr, nat, dev, quick=False):
     torch.cuda.empty_cache()
     # (e) a cold machine
     det["cold_start"] = {w: cold_start(torch, fr, nat, w) for w in ("cfg3", "cfg4")}
+    det["cold_start"]["cfg4_without_shipped_kernels"] = cold_start(torch, fr, nat, "cfg4", bundle=False)
     torch.cuda.empty_cache()
     return sec, sweep_rows, det
 
