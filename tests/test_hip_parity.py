@@ -1704,9 +1704,9 @@ def test_large_plan_in_pieces(fr, which, monkeypatch):
     loop = fruit.transform(X)
     assert pipe.pieces_loaded() == 0
     # (units of several items behind one staging by default; of one item each on two of the cases)
-    _debug_knobs(monkeypatch, pieces=1, piece_min=50, piece_nodes=20,
+    _debug_knobs(monkeypatch, pieces=1, piece_min=50, piece_nodes=12,
                  piece_unit=1 if which in ("chunks", "repeats") else 0)
-    cover = pipe.plan.pieces(20)
+    cover = pipe.plan.pieces(12)
     assert cover is not None and len(cover["types"]) >= 2
     pipe.prepare(X.shape[0])
     assert pipe.pieces_loaded() == len(cover["types"])
@@ -1720,7 +1720,7 @@ def test_large_plan_in_pieces(fr, which, monkeypatch):
     assert slc._fused(T).pieces_loaded() == 0
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("FRUITS_TEST_RANDOM_CASES", "5"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FRUITS_TEST_RANDOM_CASES", "4"))))
 def test_random_pieces_differential(fr, seed, monkeypatch):
     """Random plans (mixed word sets with shared prefixes, repeated words, negative exponents),
     semirings, weightings, sieves and series lengths, cut into random pieces (4 ... 24 nodes, units
