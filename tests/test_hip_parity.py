@@ -1698,7 +1698,7 @@ def test_large_plan_in_pieces(fr, which, monkeypatch):
     pipe = slc._fused(T)
     assert pipe is not None and pipe.plan.nodes >= 60
     _debug_knobs(monkeypatch, pieces=0)
-    pipe.prepare(X.shape[0])
+    pipe.prepare(X.shape[0], plan_too=False)       # (the record loop with the sieves as immediates)
     if pipe.jit_loaded() == 0:
         pytest.skip("hipRTC is not installed")
     loop = fruit.transform(X)
@@ -1760,7 +1760,7 @@ def test_random_pieces_differential(fr, seed, monkeypatch):
     if pipe is None or pipe.plan.nodes < 12:
         pytest.skip("not a fused pipeline / too small a plan")
     _debug_knobs(monkeypatch, pieces=0)
-    pipe.prepare(N)
+    pipe.prepare(N, plan_too=False)
     if pipe.jit_loaded() == 0:
         pytest.skip("no kernel of its own (hipRTC missing, or per-row sieve shapes)")
     loop = fruit.transform(X)
