@@ -580,7 +580,14 @@ class FruitSlice:
         experiment fruits - else None (the prepared input is then materialised)."""
         from .preparation.transform import INC, STD
         from .preparation.wrapper import NEW
-        if os.environ.get("FRUITS_AMD_FUSED_PREP", "1") == "0":
+        level = os.environ.get("FRUITS_AMD_FUSED_PREP", "1")
+        if level == "0":
+            return None
+        # (CosWISS: the kernel CAN form the prepared rows where a letter reads them - but it reads
+        # them once per (word, frequency, letter), so the differences and divisions are redone 165
+        # times per series for fruit_reduced's slices: 3.08 ms against 2.53 ms with the small
+        # prepared tensor materialised once.  Only on request: FRUITS_AMD_FUSED_PREP=2.)
+        if level != "2" and any(type(iss) is not ISS for iss in self._iss):
             return None
         preps = list(self._preparateurs)
         lag, as_new, std, eps = 0, False, 0, 0.0

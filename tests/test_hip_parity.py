@@ -1392,6 +1392,9 @@ def test_fused_preparation_coswiss(fr, monkeypatch, chain, T):
     fruit = build_fruit(fr, spec)
     np.random.seed(1)
     fruit.fit(X)
+    default = fruit.transform(X)
+    assert fruit.get_slice()._fused(T).raw_dims == 0        # (not by default: slower, see _fusable_preparation)
+    monkeypatch.setenv("FRUITS_AMD_FUSED_PREP", "2")
     got = fruit.transform(X)
     pipe = fruit.get_slice()._fused(T)
     assert pipe is not None and pipe.raw_dims == D          # the raw input went in
@@ -1399,6 +1402,7 @@ def test_fused_preparation_coswiss(fr, monkeypatch, chain, T):
     plain = fruit.transform(X)
     assert fruit.get_slice()._fused(T).raw_dims == 0
     np.testing.assert_array_equal(got, plain)
+    np.testing.assert_array_equal(default, plain)
     ref, expo = oracle_features(spec, X, X, np_seed=1)
     labels = [fruit.label(i) for i in range(fruit.nfeatures())]
     compare_features(got, ref, labels, expo, what=f"fused preparation CosWISS {chain} T={T}")
