@@ -118,6 +118,23 @@ def _event_time_us(torch, fn, reps=20):
     return a.elapsed_time(b) / reps * 1e3
 
 
+def _isolated_time_us(torch, fn, n=30):
+    """Median duration of ISOLATED launches: every launch between its own HIP event pair, the device
+    drained in front of it (what `rocprofv3 --kernel-trace`, which serialises dispatches, sees; an
+    event pair adds a few us of barrier packets).  Beside the back-to-back figure it separates a
+    kernel's own time from how consecutive launches overlap on the same output."""
+    ts = []
+    for _ in range(n):
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3)
+    return float(np.median(ts))
+
+
 def _batch_stats_us(torch, fn, batch=10, batches=50):
     """Per-launch time of `batches` batches of `batch` back-to-back launches, each batch
     between one HIP event pair on the launch stream (an event pair per launch would put
@@ -360,10 +377,11 @@ def extras(torch, fr, nat, dev, quick=False):
     w15 = fr.words.of_weight(2, dim=N_DIMS)
     plan = fr.ISS([w15[i % 15] for i in range(48)])._plan(0, 48)
     plan.prepare(N_SERIES, N_STEPS_T)     # (its static program: hipRTC, cached on disk)
-    placements, shift = [], []
+    placements, isolated, shift = [], [], []
     for trial in range(3):                # (the time depends on where the 805 MB output lies)
         buf = torch.empty((48, N_SERIES, N_STEPS_T), dtype=torch.float64, device=dev)
         placements.append(_event_time_us(torch, lambda: plan.run(Xd, None, out=buf)))
+        isolated.append(_isolated_time_us(torch, lambda: plan.run(Xd, None, out=buf)))
         del buf
         torch.cuda.empty_cache()
         shift.append(torch.empty((trial + 1) * 37_000_001, dtype=torch.uint8, device=dev))
@@ -372,7 +390,8 @@ def extras(torch, fr, nat, dev, quick=False):
     t = float(np.median(placements))
     b_alg = 8.0 * N_SERIES * N_STEPS_T * (3 + 48)
     sec["words48"] = {"us": round(t, 1), "frac": round(b_alg / (t * 1e-6) / 1e9 / HBM_PEAK_GBS, 3),
-                      "placements_us": [round(v, 1) for v in placements]}
+                      "placements_us": [round(v, 1) for v in placements],
+                      "isolated_launch_us": [round(v, 1) for v in isolated]}
     # (a') of_weight(4,2) EXTENDED, K = 115, materialised (1.9 GB): three placements too
     w42 = fr.words.of_weight(4, dim=2)
     plan = fr.ISS(w42, mode=fr.ISSMode.EXTENDED)._plan(0, len(w42))
