@@ -813,6 +813,48 @@ def test_capture_without_prior_eager_run(fr):
     assert plan.fits(T) and plan.fits(100)
 
 
+def test_capture_of_a_plan_in_pieces(fr, monkeypatch):
+    """The enqueue-only contract holds for a plan in pieces too: after fr_pipeline_prepare (tables,
+    kernels of every piece type) a run - one launch per piece type, the band means' finalize, the
+    gather of the row blocks - is captured into a graph and replays to the eager result."""
+    import torch
+    from fruits_amd import _native as nat
+    monkeypatch.setenv("FRUITS_AMD_AUTO_PREPARE", "0")
+    _debug_knobs(monkeypatch, pieces=1, piece_min=50, piece_nodes=16)
+    rng = np.random.default_rng(33)
+    N, T = 24, 1024
+    X = rng.standard_normal((N, 2, T)).cumsum(axis=2) / 5.0
+    fruit = fr.Fruit("pieces in a graph")
+    fruit.add(fr.ISS(fr.words.of_weight(4, 2), mode=fr.ISSMode.EXTENDED, weighting=fr.iss.weighting.Indices()))
+    fruit.add(fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.MPI(q=(0.5, 1.0)), fr.sieving.END)
+    fruit.get_slice().fit_sample_size = 1.0
+    np.random.seed(1)
+    fruit.fit(X)
+    slc = fruit.get_slice()
+    pipe = slc._fused(T)
+    pipe.prepare(N)
+    if pipe.pieces_loaded() == 0:
+        pytest.skip("hipRTC is not installed")
+    Xd = nat.to_device(X)
+    lk = slc.get_iss()[0].lookup_device(Xd)
+    feats = torch.zeros((N, pipe.n_features), dtype=torch.float64, device=Xd.device)
+    work = torch.empty(int(nat.lib().fr_pipeline_workspace_bytes(pipe._h, N, int(lk.shape[0]))) + 1,
+                       dtype=torch.uint8, device=Xd.device)
+    eager = pipe.run(Xd, lk, work=work).clone()
+    torch.cuda.synchronize()
+    g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            pipe.run(Xd, lk, feats=feats, work=work)
+    feats.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    labels = [fruit.label(i) for i in range(fruit.nfeatures())]
+    exact = torch.tensor(["MPI" not in lb for lb in labels], device=feats.device)
+    assert bool((feats[:, exact] == eager[:, exact]).all())
+    torch.testing.assert_close(feats, eager, rtol=1e-12, atol=0.0)
+
+
 def test_end_cut_out_of_range_raises(fr):
     """END(cut=c) with c - 1 outside [-T, T-1]: the reference raises IndexError
     (np.take_along_axis); fused and unfused paths agree on that."""
