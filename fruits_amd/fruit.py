@@ -372,42 +372,54 @@ class FruitSlice:
         for s, e in iss.word_batches(Ns, T):
             block = iss.transform_device(Sd, s, e, lookup)
             copies, owners = [], []
-            jobs: dict = {}          # (row, inc, rank) -> job index: sieves that differ only in
-            rows, incs, ranks = [], [], []   # kind (NPI / MPI) or band ask for the same statistics
-
-            def job(k, inc, rank):
-                key = (k, inc, rank)
-                if key not in jobs:
-                    jobs[key] = len(rows)
-                    rows.append(k); incs.append(inc); ranks.append(rank)
-                return jobs[key]
             # (what a sieve asks for depends on its q and the sample size only: once per sieve,
             # not once per copy)
             asks = [sv._quantile_requests(n) if sv.requires_fitting else None for sv in self._sieves]
-            wanted = [(sv._inc, [(lo, hi) for (_, lo, hi, _) in reqs])
-                      for sv, reqs in zip(self._sieves, asks) if reqs is not None]
-            per_row = []
-            for k in range(block.shape[0]):
-                per_row.append([[(job(k, inc, lo), job(k, inc, hi)) for lo, hi in pairs]
-                                for inc, pairs in wanted])
+            # Every iterated sum is asked for the same order statistics: the jobs of ONE row -
+            # (differencing order, rank) pairs, those that several sieves share (NPI / MPI with the
+            # same band) once - are laid out as a template and repeated for the rows with numpy
+            # (19 000 jobs per fit of fruit_reduced: as Python loops their construction left the
+            # device idle for 2-4 ms per slice between the iterated sums and their selection)
+            t_index: dict = {}
+            t_inc, t_rank, t_pairs = [], [], []
+            for sv, reqs in zip(self._sieves, asks):
+                if reqs is None:
+                    continue
+                idx = []
+                for (_, lo, hi, _) in reqs:
+                    for r in (lo, hi):
+                        if (sv._inc, r) not in t_index:
+                            t_index[(sv._inc, r)] = len(t_inc)
+                            t_inc.append(sv._inc)
+                            t_rank.append(r)
+                    idx.append((t_index[(sv._inc, lo)], t_index[(sv._inc, hi)]))
+                t_pairs.append((np.asarray([a for a, _ in idx], dtype=np.int64),
+                                np.asarray([b for _, b in idx], dtype=np.int64)))
+            K_rows, J = int(block.shape[0]), len(t_inc)
+            rows = np.repeat(np.arange(K_rows, dtype=np.int32), J)
+            incs = np.tile(np.asarray(t_inc, dtype=np.int32), K_rows)
+            ranks = np.tile(np.asarray(t_rank, dtype=np.int64), K_rows)
             # the selection runs on the device (the C call releases the interpreter lock) while
             # this thread makes the per-row copies of the sieves
             pending = (_SELECT_POOL.submit(nat.select_ranks, block, rows, incs, ranks, nat.stream_ptr())
-                       if rows else None)
-            for k in range(block.shape[0]):
+                       if len(rows) else None)
+            for k in range(K_rows):
                 fitted = [sieve.copy() for sieve in self._sieves]
-                row_jobs = iter(per_row[k])
+                which = 0
                 for sieve, reqs in zip(fitted, asks):
                     sieve._cache = cache
                     if reqs is not None:
-                        owners.append((sieve, reqs, next(row_jobs)))
+                        owners.append((sieve, reqs, k * J, which))
+                        which += 1
                 copies.append(fitted)
-            def finish(pending=pending, owners=owners, block=block):
+
+            def finish(pending=pending, owners=owners, block=block, t_pairs=t_pairs):
                 # (`block` lives until its selection is done)
                 vals = pending.result() if pending is not None else np.zeros(0)
-                for sieve, reqs, idx in owners:
-                    sieve._set_quantiles_from_stats(reqs, [vals[a] for a, _ in idx],
-                                                    [vals[b] for _, b in idx])
+                for sieve, reqs, base, which in owners:
+                    lo_idx, hi_idx = t_pairs[which]
+                    sieve._set_quantiles_from_stats(reqs, vals[base + lo_idx].tolist(),
+                                                    vals[base + hi_idx].tolist())
             self._sieves_extended.extend(copies)
             if deferred is None:
                 finish()
