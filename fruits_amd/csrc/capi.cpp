@@ -365,8 +365,10 @@ struct JitState {
 // batches below this many series run a static program with all its groups (to fill the chip)
 constexpr int kStaticSplitBelow = 768;
 
+// (T in (384, 512]: the 1024-element chunk with half of its lanes idle - still ahead of the
+// interpreter's 512-element chunk on cache-sized batches, see run_walk)
 bool static_shape_ok(const fr::Plan &p, int64_t T) {
-  return !p.cos && p.weighting == 0 && p.semiring == fr::kSemiReals && T > 512 && T <= 1024;
+  return !p.cos && p.weighting == 0 && p.semiring == fr::kSemiReals && T > debug_knob("static_min_T", 384) && T <= 1024;
 }
 
 // Compiles and loads the plan's static programs (one group and min(3, units) groups per
@@ -1250,7 +1252,12 @@ int run_walk(const char *who, fr::Plan &p, const double *d_X, int64_t N, int64_t
       // per workgroup is how a launch asks for that.  Cache-sized and small batches keep six
       // (N = 2048: 56.2 vs 58.6 us with four).
       static_lds_pad = (!cache_sized && N >= kStaticSplitBelow) ? 16384 : 0;
-      if (have(static_groups)) {
+      // Series of 385 ... 512 elements fill half of the program's 1024-element chunk: measured
+      // (round 4, of_weight(2,3), fraction of 8 TB/s, interpreter with its 512-element chunk /
+      // static program) T = 512: N = 2048 0.572 / 0.625, 4096 0.567 / 0.744, 8192 (streams through
+      // HBM) 0.641 / 0.538; T = 400: 0.506 / 0.594, 0.559 / 0.736, 0.503 / 0.443 - the program on
+      // cache-sized batches only
+      if (have(static_groups) && (T > 512 || cache_sized)) {
         static_prog = p.static_prog[static_groups] > 0 ? p.static_prog[static_groups] : -1;
         if (static_prog < 0) {
           jit_prog = &js->progs[static_groups];

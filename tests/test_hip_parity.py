@@ -2075,7 +2075,10 @@ def test_static_programs(fr, monkeypatch, wd, mode):
     plan = iss._plan(0, len(words))
     assert plan.static_schedule(1) is not None
     strs = [str(x) for x in words]
-    for N, T, dist in ((37, 1024, "normal"), (1601, 1024, "uniform"), (64, 600, "normal"), (3080, 1022, "normal")):
+    # ((1601, 448): series of 385 ... 512 elements run the program too on cache-sized batches,
+    # half of its 1024-element chunk idle - round 4)
+    for N, T, dist in ((37, 1024, "normal"), (1601, 1024, "uniform"), (64, 600, "normal"), (3080, 1022, "normal"),
+                       (1601, 448, "uniform")):
         X = gen_input({"seed": N + T, "dist": dist, "shape": [N, d, T]})
         Xd = nat.to_device(X)
         monkeypatch.setenv("FRUITS_HIP_STATIC", "1")
@@ -2095,7 +2098,7 @@ def test_static_programs(fr, monkeypatch, wd, mode):
 def test_static_program_is_what_runs(fr, monkeypatch):
     """A word list that compiles to the records of a standard set runs the static kernel
     whatever it was built from; an explicit group count the schedule was not generated for,
-    a weighting or T <= 512 fall back to the interpreter - all with the same results."""
+    a weighting or T <= 384 fall back to the interpreter - all with the same results."""
     from fruits_amd import _native as nat
     X = gen_input({"seed": 11, "dist": "normal", "shape": [520, 3, 1024]})
     Xd = nat.to_device(X)
