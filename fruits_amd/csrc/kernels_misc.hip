@@ -461,6 +461,65 @@ __device__ __forceinline__ void next_level(int t, double (&v)[MI + 1]) {
 #pragma unroll
   for (int j = 0; j + LVL <= MI; ++j) v[j] = (t - j >= 1) ? v[j] - v[j + 1] : 0.0;
 }
+// The element loop of the data passes: block b takes series b, b + grid, ... and its threads stride
+// over the time axis (no per-element 64-bit division; few series: the time axis is split over the
+// blocks).  A wave takes FOUR elements per lane at a time wherever all of them exist (f4; the rest
+// one by one, f1): the loads of the four are in flight together, only the first of them can lie in
+// the zero-padded head of a series (the others need no bounds tests), and whatever a pass reads
+// per JOB - its prefix, its histogram row - is read once for the four.
+constexpr int kSelUnroll = 4;
+constexpr int kSelBlocks = 4096;
+template <int MI>
+__device__ __forceinline__ void element_load_inner(const double *__restrict__ row, int t, double (&v)[MI + 1]) {
+#pragma unroll
+  for (int j = 0; j <= MI; ++j) v[j] = row[t - j];
+}
+template <int MI, int LVL>
+__device__ __forceinline__ void next_level_inner(double (&v)[MI + 1]) {
+#pragma unroll
+  for (int j = 0; j + LVL <= MI; ++j) v[j] = v[j] - v[j + 1];
+}
+// level LVL - 1 -> LVL of four elements; only element 0 can be one of a series' first MI
+template <int MI, int LVL>
+__device__ __forceinline__ void next_level4(const int (&t)[kSelUnroll], double (&v)[kSelUnroll][MI + 1]) {
+  next_level<MI, LVL>(t[0], v[0]);
+#pragma unroll
+  for (int u = 1; u < kSelUnroll; ++u) next_level_inner<MI, LVL>(v[u]);
+}
+template <int MI, class F4, class F1>
+__device__ __forceinline__ void for_elements(const double *__restrict__ base, int64_t N, int64_t T, F4 f4, F1 f1) {
+  static_assert(MI < 64, "elements 1 .. 3 of a group of four lie behind the padded head");
+  const int64_t per_series = (N >= (int64_t)gridDim.x) ? 1 : ((int64_t)gridDim.x + N - 1) / N;
+  const int64_t n_first = (int64_t)blockIdx.x / per_series, part = (int64_t)blockIdx.x % per_series;
+  const int64_t n_step = ((int64_t)gridDim.x + per_series - 1) / per_series;
+  const int64_t t_len = (T + per_series - 1) / per_series;
+  const int t_lo = (int)(part * t_len), t_hi = (int)((part * t_len + t_len < T) ? part * t_len + t_len : T);
+  const int step = (int)blockDim.x;
+  const int wave_last = (int)(threadIdx.x | 63u);   // the wave's last lane
+  for (int64_t n = n_first; n < N; n += n_step) {
+    const double *__restrict__ row = base + n * T;
+    for (int tb = t_lo; tb < t_hi; tb += step * kSelUnroll) {
+      const int t0 = tb + (int)threadIdx.x;
+      if (tb + (kSelUnroll - 1) * step + wave_last < t_hi) {   // (uniform in the wave)
+        int t[kSelUnroll];
+        double v[kSelUnroll][MI + 1];
+#pragma unroll
+        for (int u = 0; u < kSelUnroll; ++u) t[u] = t0 + u * step;
+        element_load<MI>(row, t[0], v[0]);
+#pragma unroll
+        for (int u = 1; u < kSelUnroll; ++u) element_load_inner<MI>(row, t[u], v[u]);
+        f4(t, v);
+      } else {
+        for (int t = t0; t < t_hi; t += step) {
+          double v[MI + 1];
+          element_load<MI>(row, t, v);
+          f1(t, v);
+        }
+      }
+    }
+  }
+}
+
 // The leading 32 bits of the order-preserving key: all that the first three digits and the bucket
 // tests of the gather pass look at (32-bit operations instead of 64-bit shifts and compares).
 __device__ __forceinline__ unsigned int order_key_hi(double v) {
@@ -561,7 +620,59 @@ __device__ __forceinline__ void hist_level(const SelGroup &g, unsigned int (*lh)
   }
 }
 
-template <int MI>
+// The same for a group of four elements (for_elements) and a digit known at compile time (the
+// four digits of the leading dword: every pass of a usual fit): a job's row and prefix are read
+// once for the four, the digit and the prefix test are immediates.
+template <int SHIFT>
+__device__ __forceinline__ void hist_count(unsigned int *__restrict__ row, unsigned int kh, unsigned int ph) {
+  static_assert(SHIFT >= 32 && SHIFT <= 56, "a digit of the leading dword");
+  const bool match = SHIFT == 56 || ((kh ^ ph) >> (SHIFT - 24)) == 0u;
+  const unsigned int bin = (kh >> (SHIFT - 32)) & 255u;
+  unsigned long long m = __ballot(match);
+  if (m == 0) return;
+  bool todo = match;
+  // the first digit (sign, seven exponent bits) has two to four values in a wave: two of them are
+  // counted lane group by lane group (one: 2.26 ms for 64 groups, two: 2.14, three: 2.19)
+  constexpr int kRounds = SHIFT == 56 ? 2 : 1;
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int leader = __ffsll((long long)m) - 1;
+    const unsigned int lead_bin = (unsigned int)__builtin_amdgcn_readlane((int)bin, leader);
+    const bool same = todo && bin == lead_bin;
+    const unsigned long long ms = __ballot(same);
+    if (SHIFT >= 48 || ms == m) {   // (see hist_level)
+      if ((int)(threadIdx.x & 63) == leader) atomicAdd(&row[lead_bin], (unsigned int)__popcll(ms));
+      todo = todo && !same;
+      m &= ~ms;
+    }
+    if (m == 0) return;
+  }
+  if (todo) atomicAdd(&row[bin], 1u);
+}
+template <int MI, int SHIFT, int LVL>
+__device__ __forceinline__ void hist_level4(const SelGroup &g, unsigned int (*lh)[256],
+                                            const int (&t)[kSelUnroll], double (&v)[kSelUnroll][MI + 1]) {
+  if constexpr (LVL <= MI) {
+    if constexpr (LVL > 0) next_level4<MI, LVL>(t, v);
+    const int kb = __builtin_amdgcn_readfirstlane(g.lvl[LVL]), ke = __builtin_amdgcn_readfirstlane(g.lvl[LVL + 1]);
+    if (kb != ke) {
+      unsigned int kh[kSelUnroll];
+#pragma unroll
+      for (int u = 0; u < kSelUnroll; ++u) kh[u] = order_key_hi(v[u][0]);
+      for (int k = kb; k < ke; ++k) {
+        unsigned int *row = lh[__builtin_amdgcn_readfirstlane(g.act[k])];
+        const unsigned int ph = (unsigned int)__builtin_amdgcn_readfirstlane((int)g.act_hi[k]);
+#pragma unroll
+        for (int u = 0; u < kSelUnroll; ++u) hist_count<SHIFT>(row, kh[u], ph);
+      }
+    }
+    hist_level4<MI, SHIFT, LVL + 1>(g, lh, t, v);
+  }
+}
+
+// SHIFT: the digit when it is one of the leading dword's (the four-wide path), else 0 - then the
+// run-time `shift` counts (the low digits: jobs with heavy ties only)
+template <int MI, int SHIFT>
 __global__ __launch_bounds__(256) void select_hist_kernel(const SelJob *__restrict__ jobs,
                                                            const int2 *__restrict__ groups,
                                                            int64_t N, int64_t T, int shift,
@@ -572,26 +683,27 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const SelJob *__restri
   // jobs that finish among their gathered candidates take no part in later passes; first pass:
   // no prefix yet - jobs of one differencing order see the same histogram, which is counted
   // once and copied below
+  if constexpr (SHIFT != 0) shift = SHIFT;
   const int n_act = load_group<MI>(g, jobs, jb, nj, [&](int j) {
     return !(g.pad[j] & 4) && !(shift == 56 && j > 0 && g.inc[j] == g.inc[j - 1]);
   });
   if (n_act == 0) return;
   for (int j = 0; j < nj; ++j) lh[j][threadIdx.x] = 0;
   __syncthreads();
-  const double *base = jobs[jb].base;
-  // element order: block b takes series b, b + grid, ... and its threads stride over the time
-  // axis (no per-element 64-bit division; few series: the time axis is split over the blocks)
-  const int64_t per_series = (N >= (int64_t)gridDim.x) ? 1 : ((int64_t)gridDim.x + N - 1) / N;
-  const int64_t n_first = (int64_t)blockIdx.x / per_series, part = (int64_t)blockIdx.x % per_series;
-  const int64_t n_step = ((int64_t)gridDim.x + per_series - 1) / per_series;
-  const int64_t t_len = (T + per_series - 1) / per_series;
-  const int64_t t_lo = part * t_len, t_hi = (t_lo + t_len < T) ? t_lo + t_len : T;
-  for (int64_t n = n_first; n < N; n += n_step)
-    for (int t = (int)t_lo + (int)threadIdx.x; t < (int)t_hi; t += (int)blockDim.x) {
-      double v[MI + 1];
-      element_load<MI>(base + n * T, t, v);
-      hist_level<MI, 0>(g, lh, t, v, shift);
-    }
+  if constexpr (SHIFT != 0) {
+    for_elements<MI>(
+        jobs[jb].base, N, T,
+        [&](const int (&t)[kSelUnroll], double (&v)[kSelUnroll][MI + 1]) { hist_level4<MI, SHIFT, 0>(g, lh, t, v); },
+        [&](int t, double (&v)[MI + 1]) { hist_level<MI, 0>(g, lh, t, v, SHIFT); });
+  } else {
+    const auto one = [&](int t, double (&v)[MI + 1]) { hist_level<MI, 0>(g, lh, t, v, shift); };
+    for_elements<MI>(jobs[jb].base, N, T,
+                     [&](const int (&t)[kSelUnroll], double (&v)[kSelUnroll][MI + 1]) {
+#pragma unroll
+                       for (int u = 0; u < kSelUnroll; ++u) one(t[u], v[u]);
+                     },
+                     one);
+  }
   __syncthreads();
   for (int j = 0; j < nj; ++j) {
     if (g.pad[j] & 4) continue;
@@ -664,6 +776,32 @@ struct GatherBig {   // up to two jobs of the group whose candidates may all be 
   unsigned long long ref0, ref1;   // the first candidate anybody saw
   bool other0, other1;
 };
+// one element's key against job j of the group (hit: it lies in the job's bucket)
+__device__ __forceinline__ void gather_job(int jb, int j, bool hit, unsigned long long key, GatherBig &gb,
+                                           unsigned long long *__restrict__ cand,
+                                           unsigned int *__restrict__ cnt) {
+  if (j == gb.big0 || j == gb.big1) {
+    unsigned long long &ref = j == gb.big0 ? gb.ref0 : gb.ref1;
+    // nobody has published a candidate yet: ONE lane of the wave tries (a compare-and-swap
+    // per thread on one address would serialise a hundred thousand of them) and tells
+    // the others what the reference is
+    const unsigned long long ask = __ballot(hit && ref == ~0ull);
+    if (ask != 0) {
+      const int leader = __ffsll((long long)ask) - 1;
+      unsigned long long got = 0;
+      if ((int)(threadIdx.x & 63) == leader) {
+        const unsigned long long old = atomicCAS(&cand[(int64_t)(jb + j) * kSelSmall], ~0ull, key);
+        got = old == ~0ull ? key : old;
+      }
+      const unsigned long long told = __shfl(got, leader);
+      if (ref == ~0ull) ref = told;
+    }
+    if (hit && key != ref) (j == gb.big0 ? gb.other0 : gb.other1) = true;
+  } else if (hit) {
+    const unsigned int slot = atomicAdd(&cnt[jb + j], 1u);
+    if (slot < (unsigned int)kSelSmall) cand[(int64_t)(jb + j) * kSelSmall + slot] = key;
+  }
+}
 template <int MI, int LVL>
 __device__ __forceinline__ void gather_level(const SelGroup &g, int jb, int t, double (&v)[MI + 1],
                                              unsigned long long (&above)[MI + 1][kSelTrack],
@@ -680,34 +818,54 @@ __device__ __forceinline__ void gather_level(const SelGroup &g, int jb, int t, d
 #pragma unroll
       for (int a = 0; a < kSelTrack; ++a)   // (the level's first jobs: the host flags only those)
         if (bucket > track[LVL][a] && key < above[LVL][a]) above[LVL][a] = key;
-      for (int k = kb; k < ke; ++k) {
-        const int j = g.act[k];
-        const bool hit = bucket == (g.act_hi[k] >> (kSelSmallShift - 32));
-        if (j == gb.big0 || j == gb.big1) {
-          unsigned long long &ref = j == gb.big0 ? gb.ref0 : gb.ref1;
-          // nobody has published a candidate yet: ONE lane of the wave tries (a compare-and-swap
-          // per thread on one address would serialise a hundred thousand of them) and tells
-          // the others what the reference is
-          const unsigned long long ask = __ballot(hit && ref == ~0ull);
-          if (ask != 0) {
-            const int leader = __ffsll((long long)ask) - 1;
-            unsigned long long got = 0;
-            if ((int)(threadIdx.x & 63) == leader) {
-              const unsigned long long old =
-                  atomicCAS(&cand[(int64_t)(jb + j) * kSelSmall], ~0ull, key);
-              got = old == ~0ull ? key : old;
-            }
-            const unsigned long long told = __shfl(got, leader);
-            if (ref == ~0ull) ref = told;
-          }
-          if (hit && key != ref) (j == gb.big0 ? gb.other0 : gb.other1) = true;
-        } else if (hit) {
-          const unsigned int slot = atomicAdd(&cnt[jb + j], 1u);
-          if (slot < (unsigned int)kSelSmall) cand[(int64_t)(jb + j) * kSelSmall + slot] = key;
-        }
-      }
+      for (int k = kb; k < ke; ++k)
+        gather_job(jb, g.act[k], bucket == (g.act_hi[k] >> (kSelSmallShift - 32)), key, gb, cand, cnt);
     }
     gather_level<MI, LVL + 1>(g, jb, t, v, above, track, gb, cand, cnt);
+  }
+}
+// ... of a group of four elements (for_elements): a job's bucket is read once for the four, and a
+// job none of the wave's 256 elements falls to - nearly every job, nearly every time: a bucket holds
+// at most kSelSmall of the millions - costs four compares and a branch
+template <int MI, int LVL>
+__device__ __forceinline__ void gather_level4(const SelGroup &g, int jb, const int (&t)[kSelUnroll],
+                                              double (&v)[kSelUnroll][MI + 1],
+                                              unsigned long long (&above)[MI + 1][kSelTrack],
+                                              const unsigned int (&track)[MI + 1][kSelTrack],
+                                              GatherBig &gb, unsigned long long *__restrict__ cand,
+                                              unsigned int *__restrict__ cnt) {
+  if constexpr (LVL <= MI) {
+    if constexpr (LVL > 0) next_level4<MI, LVL>(t, v);
+    const int kb = __builtin_amdgcn_readfirstlane(g.lvl[LVL]), ke = __builtin_amdgcn_readfirstlane(g.lvl[LVL + 1]);
+    if (kb != ke) {
+      unsigned int bucket[kSelUnroll];
+      unsigned long long key[kSelUnroll];
+#pragma unroll
+      for (int u = 0; u < kSelUnroll; ++u) {
+        bucket[u] = order_key_hi(v[u][0]) >> (kSelSmallShift - 32);
+        key[u] = order_key(v[u][0]);
+      }
+#pragma unroll
+      for (int a = 0; a < kSelTrack; ++a) {
+        const unsigned int tr = (unsigned int)__builtin_amdgcn_readfirstlane((int)track[LVL][a]);
+        if (tr == ~0u) continue;   // (nothing is tracked in this place)
+#pragma unroll
+        for (int u = 0; u < kSelUnroll; ++u)
+          if (bucket[u] > tr && key[u] < above[LVL][a]) above[LVL][a] = key[u];
+      }
+      for (int k = kb; k < ke; ++k) {
+        const int j = __builtin_amdgcn_readfirstlane(g.act[k]);
+        const unsigned int jbucket =
+            (unsigned int)__builtin_amdgcn_readfirstlane((int)g.act_hi[k]) >> (kSelSmallShift - 32);
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < kSelUnroll; ++u) any = any || bucket[u] == jbucket;
+        if (__ballot(any) == 0) continue;
+#pragma unroll
+        for (int u = 0; u < kSelUnroll; ++u) gather_job(jb, j, bucket[u] == jbucket, key[u], gb, cand, cnt);
+      }
+    }
+    gather_level4<MI, LVL + 1>(g, jb, t, v, above, track, gb, cand, cnt);
   }
 }
 template <int MI, int LVL>
@@ -762,18 +920,12 @@ __global__ __launch_bounds__(256) void select_gather_kernel(const SelJob *__rest
       const bool on = k < g.lvl[i + 1] && (g.pad[g.act[k < kSelGroupJobs ? k : 0]] & 16);
       track[i][a] = on ? g.act_hi[k < kSelGroupJobs ? k : 0] >> (kSelSmallShift - 32) : ~0u;
     }
-  const double *base = jobs[jb].base;
-  const int64_t per_series = (N >= (int64_t)gridDim.x) ? 1 : ((int64_t)gridDim.x + N - 1) / N;
-  const int64_t n_first = (int64_t)blockIdx.x / per_series, part = (int64_t)blockIdx.x % per_series;
-  const int64_t n_step = ((int64_t)gridDim.x + per_series - 1) / per_series;
-  const int64_t t_len = (T + per_series - 1) / per_series;
-  const int64_t t_lo = part * t_len, t_hi = (t_lo + t_len < T) ? t_lo + t_len : T;
-  for (int64_t n = n_first; n < N; n += n_step)
-    for (int t = (int)t_lo + (int)threadIdx.x; t < (int)t_hi; t += (int)blockDim.x) {
-      double v[MI + 1];
-      element_load<MI>(base + n * T, t, v);
-      gather_level<MI, 0>(g, jb, t, v, above, track, gb, cand, cnt);
-    }
+  for_elements<MI>(
+      jobs[jb].base, N, T,
+      [&](const int (&t)[kSelUnroll], double (&v)[kSelUnroll][MI + 1]) {
+        gather_level4<MI, 0>(g, jb, t, v, above, track, gb, cand, cnt);
+      },
+      [&](int t, double (&v)[MI + 1]) { gather_level<MI, 0>(g, jb, t, v, above, track, gb, cand, cnt); });
   if (gb.other0) cand[(int64_t)(jb + gb.big0) * kSelSmall + 1] = 1ull;
   if (gb.other1) cand[(int64_t)(jb + gb.big1) * kSelSmall + 1] = 1ull;
   gather_publish<MI, 0>(g, jb, above, succ);
@@ -788,7 +940,9 @@ __global__ __launch_bounds__(256) void select_small_kernel(SelJob *__restrict__ 
                                                             unsigned long long *__restrict__ succ,
                                                             unsigned int *__restrict__ n_big) {
   __shared__ unsigned long long keys[kSelSmall];
-  __shared__ unsigned long long next_key;
+  __shared__ unsigned long long next_key, s_prefix;
+  __shared__ unsigned int lh[256];
+  __shared__ int s_k, s_eq;
   const int job = blockIdx.x;
   if (jobs[job].pad & 8) {
     // more candidates than a workgroup settles: done all the same when they are ONE value
@@ -812,32 +966,61 @@ __global__ __launch_bounds__(256) void select_small_kernel(SelJob *__restrict__ 
   if (!(jobs[job].pad & 4)) return;
   int n = (int)cnt[job];
   if (n > kSelSmall) n = kSelSmall;   // (cannot happen: the histogram counted the same elements)
-  const long long k = jobs[job].k;
   for (int i = threadIdx.x; i < n; i += blockDim.x) keys[i] = cand[(int64_t)job * kSelSmall + i];
-  if (threadIdx.x == 0) next_key = ~0ull;
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const unsigned long long mine = keys[i];
-    int lt = 0, eq = 0;
-    for (int j = 0; j < n; ++j) {
-      const unsigned long long other = keys[j];
-      lt += other < mine;
-      eq += other == mine;
-    }
-    if (lt <= k && k < lt + eq) {          // (every copy of the k-th key writes the same)
-      out[job] = key_to_double(mine);
-      jobs[job].prefix = mine;
-      if (jobs[job].pad & 1) {
-        if (k + 1 < lt + eq) succ[job] = mine;
-        else atomicMin(&next_key, ~0ull - 1);   // marks: look for the smallest larger key
+  if (threadIdx.x == 0) {
+    next_key = ~0ull;
+    s_prefix = jobs[job].prefix;   // (the leading 24 bits: every candidate has them)
+    s_k = (int)jobs[job].k;
+  }
+  // the remaining five digits by the same radix selection, inside LDS (ranking every candidate
+  // against all the others - 4 million compares for a full list - took as long as a pass over
+  // the data)
+  for (int shift = kSelSmallShift - 8; shift >= 0; shift -= 8) {
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned long long prefix = s_prefix;
+    const int k = s_k;
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+      if ((keys[i] >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&lh[(keys[i] >> shift) & 255u], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {   // lane l: bins 4 l .. 4 l + 3
+      const int l = threadIdx.x;
+      const unsigned int c0 = lh[4 * l], c1 = lh[4 * l + 1], c2 = lh[4 * l + 2], c3 = lh[4 * l + 3];
+      const unsigned int mine = c0 + c1 + c2 + c3;
+      unsigned int incl = mine;
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int w = __shfl_up(incl, o);
+        if (l >= o) incl += w;
       }
+      const unsigned int excl = incl - mine;
+      if ((unsigned int)k >= excl && (unsigned int)k < incl) {   // (one lane: k < the number counted)
+        unsigned int r = (unsigned int)k - excl;
+        int d = 4 * l;
+        unsigned int c = c0;
+        if (r >= c0) { r -= c0; ++d; c = c1;
+          if (r >= c1) { r -= c1; ++d; c = c2;
+            if (r >= c2) { r -= c2; ++d; c = c3; } } }
+        s_k = (int)r;
+        s_eq = (int)c;
+        s_prefix = prefix | ((unsigned long long)d << shift);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const unsigned long long mine = s_prefix;   // the k-th key; s_eq copies of it, s_k of them in front
+    out[job] = key_to_double(mine);
+    jobs[job].prefix = mine;
+    if (jobs[job].pad & 1) {
+      if (s_k + 1 < s_eq) succ[job] = mine;
+      else next_key = ~0ull - 1;   // marks: look for the smallest larger key
     }
   }
   __syncthreads();
   if (!(jobs[job].pad & 1) || next_key == ~0ull) return;
   // the next order statistic is the smallest candidate above the selected key - or, when the
   // selected key is the largest candidate, the smallest key above the bucket
-  const unsigned long long sel = jobs[job].prefix;
+  const unsigned long long sel = s_prefix;
   unsigned long long best = ~0ull;
   for (int i = threadIdx.x; i < n; i += blockDim.x)
     if (keys[i] > sel && keys[i] < best) best = keys[i];
@@ -912,18 +1095,13 @@ __global__ __launch_bounds__(256) void select_succ_kernel(const SelJob *__restri
   unsigned long long best[MI + 1];
 #pragma unroll
   for (int i = 0; i <= MI; ++i) best[i] = ~0ull;
-  const double *base = jobs[jb].base;
-  const int64_t per_series = (N >= (int64_t)gridDim.x) ? 1 : ((int64_t)gridDim.x + N - 1) / N;
-  const int64_t n_first = (int64_t)blockIdx.x / per_series, part = (int64_t)blockIdx.x % per_series;
-  const int64_t n_step = ((int64_t)gridDim.x + per_series - 1) / per_series;
-  const int64_t t_len = (T + per_series - 1) / per_series;
-  const int64_t t_lo = part * t_len, t_hi = (t_lo + t_len < T) ? t_lo + t_len : T;
-  for (int64_t n = n_first; n < N; n += n_step)
-    for (int t = (int)t_lo + (int)threadIdx.x; t < (int)t_hi; t += (int)blockDim.x) {
-      double v[MI + 1];
-      element_load<MI>(base + n * T, t, v);
-      succ_level<MI, 0>(g, jb, t, v, best, succ);
-    }
+  const auto one = [&](int t, double (&v)[MI + 1]) { succ_level<MI, 0>(g, jb, t, v, best, succ); };
+  for_elements<MI>(jobs[jb].base, N, T,
+                   [&](const int (&t)[kSelUnroll], double (&v)[kSelUnroll][MI + 1]) {
+#pragma unroll
+                     for (int u = 0; u < kSelUnroll; ++u) one(t[u], v[u]);
+                   },
+                   one);
   succ_publish<MI, 0>(g, jb, best, succ);
 }
 
@@ -934,15 +1112,24 @@ static hipError_t select_ranks_mi(SelJob *jb, int n_jobs, const int2 *gr, int n_
                                   const int32_t *h_groups, int2 *gr_active, bool untracked, int64_t N, int64_t T,
                                   unsigned int *hist, double *out, unsigned long long *succ,
                                   unsigned long long *cand, unsigned int *cand_count, hipStream_t st) {
+  // blocks per group: about kSelBlocks in all (16 per CU) - a block zeroes and publishes its
+  // histograms whatever it counts (64 groups: 32768 blocks 2.62 ms, 8192 2.33, 4096 2.24, 2048 2.30)
   int64_t bpj = (N * T + 256 * 16 - 1) / (256 * 16);
   if (bpj > 512) bpj = 512;
+  if (bpj * n_groups > kSelBlocks) bpj = (kSelBlocks + n_groups - 1) / n_groups;
   if (bpj < 1) bpj = 1;
   const int2 *pass_groups = gr;
   int pass_n = n_groups;
   bool trailing = false;   // some jobs go through all eight digits
   for (int shift = 56; shift >= 0; shift -= 8) {
-    hipLaunchKernelGGL(select_hist_kernel<MI>, dim3((unsigned)bpj, (unsigned)pass_n), dim3(256), 0,
-                       st, jb, pass_groups, N, T, shift, hist);
+    const dim3 hgrid((unsigned)bpj, (unsigned)pass_n);
+    switch (shift) {
+      case 56: hipLaunchKernelGGL((select_hist_kernel<MI, 56>), hgrid, dim3(256), 0, st, jb, pass_groups, N, T, shift, hist); break;
+      case 48: hipLaunchKernelGGL((select_hist_kernel<MI, 48>), hgrid, dim3(256), 0, st, jb, pass_groups, N, T, shift, hist); break;
+      case 40: hipLaunchKernelGGL((select_hist_kernel<MI, 40>), hgrid, dim3(256), 0, st, jb, pass_groups, N, T, shift, hist); break;
+      case 32: hipLaunchKernelGGL((select_hist_kernel<MI, 32>), hgrid, dim3(256), 0, st, jb, pass_groups, N, T, shift, hist); break;
+      default: hipLaunchKernelGGL((select_hist_kernel<MI, 0>), hgrid, dim3(256), 0, st, jb, pass_groups, N, T, shift, hist);
+    }
     hipLaunchKernelGGL(select_pick_kernel, dim3((unsigned)n_jobs), dim3(64), 0, st, jb, shift,
                        hist, out, succ, cand_count + n_jobs, cand, cand_count);
     if (shift == kSelSmallShift) {
