@@ -39,6 +39,97 @@ def _check_batch(X) -> np.ndarray:
 from concurrent.futures import ThreadPoolExecutor as _ThreadPoolExecutor
 _SELECT_POOL = _ThreadPoolExecutor(max_workers=1, thread_name_prefix="fruits-select")
 
+
+class _FittedRows:
+    """The fitted sieve copies of a slice, one list per iterated sum - what fruits/fruit.py:462-476
+    builds as it fits - held as ARRAYS: per sieve the thresholds of all rows, computed from the
+    device's order statistics with numpy (np.quantile's interpolation over the rows at once).  The
+    copy objects are made when somebody asks for a row; the fused pipeline reads the arrays.
+    (fruit_reduced: 633 rows x 7 sieves - as eager Python objects, each fitted by a call of its
+    own, they were 20 of the 36 ms of Fruit.fit, all on the thread that also feeds the device.)"""
+
+    def __init__(self, sieves, cache) -> None:
+        self._sieves = list(sieves)
+        self._cache = cache
+        self._segments: list = []     # [first row, rows, per sieve (rows, len(q)) array or None]
+        self._n = 0
+        self._made: dict = {}
+
+    def __getstate__(self):
+        # (copies somebody changed are part of the state; the cache is the process's)
+        return {"_sieves": self._sieves, "_cache": None, "_n": self._n, "_made": {},
+                "_segments": [[r0, n, [None if q is None else q.copy() for q in qs]]
+                              for r0, n, qs in self._with_made()]}
+
+    def _with_made(self):
+        for r0, n, qs in self._segments:
+            qs = [None if q is None else q.copy() for q in qs]
+            for k, fitted in self._made.items():
+                if r0 <= k < r0 + n:
+                    for i, sv in enumerate(fitted):
+                        if qs[i] is not None:
+                            qs[i][k - r0] = sv._quantiles
+            yield r0, n, qs
+
+    def add_rows(self, n: int) -> list:
+        """A run of ``n`` more rows; returns its (still empty) list of threshold arrays."""
+        seg = [self._n, n, [None] * len(self._sieves)]
+        self._segments.append(seg)
+        self._n += n
+        return seg[2]
+
+    def __len__(self) -> int:
+        return self._n
+
+    def __bool__(self) -> bool:
+        return self._n > 0
+
+    def __iter__(self):
+        return (self[k] for k in range(self._n))
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(self._n))]
+        if k < 0:
+            k += self._n
+        if not 0 <= k < self._n:
+            raise IndexError(k)
+        fitted = self._made.get(k)
+        if fitted is None:
+            r0, _, qs = next(seg for seg in self._segments if seg[0] <= k < seg[0] + seg[1])
+            fitted = [sv.copy() for sv in self._sieves]
+            for sv, q in zip(fitted, qs):
+                sv._cache = self._cache
+                if q is not None:
+                    sv._quantiles = q[k - r0].copy()
+            self._made[k] = fitted
+        return fitted
+
+    def thresholds(self, i: int, rows) -> Optional[np.ndarray]:
+        """(len(rows), len(q)) thresholds of sieve ``i`` (None: it is not fitted on data)."""
+        if not self._segments or self._segments[0][2][i] is None:
+            return None
+        if len(self._segments) == 1 and not self._made:
+            table = self._segments[0][2][i]
+        else:
+            table = np.concatenate([qs[i] for _, _, qs in self._with_made()])
+        return table[np.asarray(rows, dtype=np.int64)]
+
+
+def _interpolated_quantiles(sieve, reqs, lo_vals: np.ndarray, hi_vals: np.ndarray) -> np.ndarray:
+    """SegmentSieve._set_quantiles_from_stats for all rows at once: (rows, len(q)) thresholds
+    from the (rows, len(reqs)) order statistics np.quantile interpolates between."""
+    qs = np.empty((lo_vals.shape[0], len(sieve._q)))
+    qs[:] = [np.inf if q == 1.0 else (-np.inf if q == -1.0 else 0.0) for q in sieve._q]
+    for j, (i, _, _, gamma) in enumerate(reqs):
+        # numpy's _lerp (lib/_function_base_impl.py): a + (b-a)*t, from the other end
+        # when t >= 0.5
+        a, b = lo_vals[:, j], hi_vals[:, j]
+        d = b - a
+        qs[:, i] = a + d * gamma if gamma < 0.5 else b - d * (1 - gamma)
+    return np.sort(qs, axis=1)
+
+
 class Fruit:
     """Feature extractor made of one or more :class:`FruitSlice` objects whose
     features are concatenated.
@@ -369,9 +460,9 @@ class FruitSlice:
         Ns, T = int(Sd.shape[0]), int(Sd.shape[2])
         n = Ns * T
         lookup = iss.lookup_device(Sd)
+        self._sieves_extended = _FittedRows(self._sieves, cache)
         for s, e in iss.word_batches(Ns, T):
             block = iss.transform_device(Sd, s, e, lookup)
-            copies, owners = [], []
             # (what a sieve asks for depends on its q and the sample size only: once per sieve,
             # not once per copy)
             asks = [sv._quantile_requests(n) if sv.requires_fitting else None for sv in self._sieves]
@@ -399,28 +490,22 @@ class FruitSlice:
             rows = np.repeat(np.arange(K_rows, dtype=np.int32), J)
             incs = np.tile(np.asarray(t_inc, dtype=np.int32), K_rows)
             ranks = np.tile(np.asarray(t_rank, dtype=np.int64), K_rows)
-            # the selection runs on the device (the C call releases the interpreter lock) while
-            # this thread makes the per-row copies of the sieves
+            # the selection runs on the device (the C call releases the interpreter lock); the
+            # thresholds of the rows are formed as arrays when it is done (_FittedRows)
             pending = (_SELECT_POOL.submit(nat.select_ranks, block, rows, incs, ranks, nat.stream_ptr())
                        if len(rows) else None)
-            for k in range(K_rows):
-                fitted = [sieve.copy() for sieve in self._sieves]
-                which = 0
-                for sieve, reqs in zip(fitted, asks):
-                    sieve._cache = cache
-                    if reqs is not None:
-                        owners.append((sieve, reqs, k * J, which))
-                        which += 1
-                copies.append(fitted)
+            tables = self._sieves_extended.add_rows(K_rows)
 
-            def finish(pending=pending, owners=owners, block=block, t_pairs=t_pairs):
+            def finish(pending=pending, block=block, t_pairs=t_pairs, tables=tables, asks=asks,
+                       K_rows=K_rows, J=J):
                 # (`block` lives until its selection is done)
-                vals = pending.result() if pending is not None else np.zeros(0)
-                for sieve, reqs, base, which in owners:
-                    lo_idx, hi_idx = t_pairs[which]
-                    sieve._set_quantiles_from_stats(reqs, vals[base + lo_idx].tolist(),
-                                                    vals[base + hi_idx].tolist())
-            self._sieves_extended.extend(copies)
+                vals = (pending.result() if pending is not None else np.zeros(0)).reshape(K_rows, J)
+                which = 0
+                for i, (sieve, reqs) in enumerate(zip(self._sieves, asks)):
+                    if reqs is not None:
+                        lo_idx, hi_idx = t_pairs[which]
+                        tables[i] = _interpolated_quantiles(sieve, reqs, vals[:, lo_idx], vals[:, hi_idx])
+                        which += 1
             if deferred is None:
                 finish()
             else:
@@ -497,7 +582,19 @@ class FruitSlice:
             if pipe is not None:
                 assert plan.rows == len(rows)
                 quant = np.zeros((len(rows), pipe.q_stride))
-                for k, row in enumerate(rows):
+                lazy = isinstance(self._sieves_extended, _FittedRows)
+                if lazy:     # (the thresholds of all rows are arrays already)
+                    off = 0
+                    for i, sv in enumerate(self._sieves):
+                        if type(sv) is END:
+                            continue
+                        th = self._sieves_extended.thresholds(i, rows)
+                        if th is None:
+                            sv._get_unfitted_quantiles()
+                            th = sv._quantiles
+                        quant[:, off:off + len(sv._q)] = th
+                        off += len(sv._q)
+                for k, row in enumerate(() if lazy else rows):
                     sieves = self._sieves_extended[row] if self._sieves_extended else self._sieves
                     off = 0
                     for sv in sieves:
