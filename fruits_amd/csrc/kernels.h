@@ -34,7 +34,9 @@ hipError_t launch_sieve(int kind, const double *A, int64_t N, int64_t T, int64_t
 // groups = int2 {first job, count}
 constexpr int kSelGroupMax = 8;
 constexpr int kSelTrackJobs = 2;     // jobs per group and differencing order whose successor the gather pass tracks
-constexpr int kSelSmallCap = 2048;   // candidates a job settles inside one workgroup (kernels_misc.hip)
+// (fruit_reduced's fit: 2048 23.0 ms - a few jobs per slice went on through five more digits -
+// 4096 20.1, 8192 20.3, 16384 20.3)
+constexpr int kSelSmallCap = 4096;   // candidates a job settles inside one workgroup (kernels_misc.hip)
 // job.pad bit 0: also return the next order statistic (succ[job] = its order key; all-ones
 // when there is none); succ must be preset to all-ones
 hipError_t launch_select_ranks(void *jobs, int n_jobs, const void *groups, int n_groups,

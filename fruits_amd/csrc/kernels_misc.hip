@@ -939,7 +939,6 @@ __global__ __launch_bounds__(256) void select_small_kernel(SelJob *__restrict__ 
                                                             double *__restrict__ out,
                                                             unsigned long long *__restrict__ succ,
                                                             unsigned int *__restrict__ n_big) {
-  __shared__ unsigned long long keys[kSelSmall];
   __shared__ unsigned long long next_key, s_prefix;
   __shared__ unsigned int lh[256];
   __shared__ int s_k, s_eq;
@@ -966,7 +965,8 @@ __global__ __launch_bounds__(256) void select_small_kernel(SelJob *__restrict__ 
   if (!(jobs[job].pad & 4)) return;
   int n = (int)cnt[job];
   if (n > kSelSmall) n = kSelSmall;   // (cannot happen: the histogram counted the same elements)
-  for (int i = threadIdx.x; i < n; i += blockDim.x) keys[i] = cand[(int64_t)job * kSelSmall + i];
+  // (the candidates stay where the gather pass put them: five sweeps over a list that is in L2)
+  const unsigned long long *__restrict__ keys = cand + (int64_t)job * kSelSmall;
   if (threadIdx.x == 0) {
     next_key = ~0ull;
     s_prefix = jobs[job].prefix;   // (the leading 24 bits: every candidate has them)
