@@ -36,7 +36,7 @@ EXPORTS = [
     "fr_pipeline_workspace_bytes", "fr_pipeline_run", "fr_pipeline_set_quantiles",
     "fr_select_ranks", "fr_coswiss_combine", "fr_plan_create_coswiss", "fr_nan_to_num",
     "fr_plan_prepare", "fr_pipeline_prepare", "fr_pipeline_compile_plan", "fr_pipeline_prepare_cached", "fr_pipeline_bundle", "fr_plan_fits", "fr_release_scratch",
-    "fr_pipeline_set_preparation", "fr_pipeline_set_series_cuts", "fr_arctic_argmax", "fr_coswiss_set_dropout",
+    "fr_pipeline_set_preparation", "fr_pipeline_set_series_cuts", "fr_pipeline_set_argmax", "fr_arctic_argmax", "fr_coswiss_set_dropout",
     "fr_coswiss_set_input_stride", "fr_coswiss_ffn",
 ]
 
@@ -100,6 +100,7 @@ def lib():
     L.fr_pipeline_compile_plan.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     L.fr_pipeline_prepare_cached.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     L.fr_pipeline_set_series_cuts.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+    L.fr_pipeline_set_argmax.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.fr_pipeline_set_preparation.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                               C.c_int32, C.c_double]
     _lib = L
@@ -442,7 +443,9 @@ class Pipeline:
     ``cut_row`` the transformed int64 cuts (sorted, leading 0) for length ``T``.
     Raises ValueError when a sieve is outside the fused set."""
 
-    def __init__(self, plan: Plan, sieves, T: int):
+    def __init__(self, plan: Plan, sieves, T: int, argmax_lengths=None):
+        """``argmax_lengths``: the plan holds every prefix of words of these lengths and the
+        pipeline's rows are those of Arctic(argmax=True) (fr_pipeline_set_argmax)."""
         L = lib()
         self._h = None
         self.plan = plan
@@ -463,6 +466,16 @@ class Pipeline:
             raise (IndexError if "out of bounds" in msg else ValueError)(msg)
         self._h = C.c_void_p(h)
         self.raw_dims = 0    # > 0: fused preparation, run() takes the raw input
+        self.rows = plan.rows
+        if argmax_lengths is not None:
+            lens = np.ascontiguousarray(argmax_lengths, dtype=np.int32)
+            rc = L.fr_pipeline_set_argmax(self._h, C.c_int32(len(lens)), lens.ctypes.data_as(ip))
+            if rc != 0:
+                msg = last_error()
+                L.fr_pipeline_destroy(self._h)
+                self._h = None
+                raise ValueError(msg)
+            self.rows = int(sum(int(n) + int(n) * (int(n) + 1) // 2 for n in lens))
         self.per_sum = int(L.fr_pipeline_info(self._h, 0))
         self.q_stride = int(L.fr_pipeline_info(self._h, 1))
         self.n_features = int(L.fr_pipeline_info(self._h, 2))
@@ -479,7 +492,7 @@ class Pipeline:
         """``quant`` (K, q_stride) host array: the sorted thresholds of every
         iterated sum's band sieves, in sieve order."""
         q = np.ascontiguousarray(quant, dtype=np.float64)
-        if q.shape != (self.plan.rows, self.q_stride):
+        if q.shape != (self.rows, self.q_stride):
             raise ValueError("quantile table must be (K, q_stride)")
         check(lib().fr_pipeline_set_quantiles(self._h, q.ctypes.data_as(C.POINTER(C.c_double))),
               "fr_pipeline_set_quantiles")

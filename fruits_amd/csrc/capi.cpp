@@ -742,7 +742,14 @@ struct fr_pipeline {
   void *d_npi_pairs = nullptr;
   std::vector<PipeSieve> sieves;
   std::vector<int32_t> mpi_cols;   // columns inside one iterated sum's block
-  void *d_ops = nullptr;           // (K, n_ops_padded) FeatOp
+  // Arctic argmax (fr_pipeline_set_argmax): the OUTPUT rows are the L + L (L + 1) / 2 rows of every
+  // word (running maxima and back-tracked positions, fruits/iss/semiring.py:239-284), not the
+  // plan's; (n_words, 4) {first plan row, letters, first output row, 0}
+  std::vector<int32_t> argmax_words;
+  void *d_argmax_words = nullptr;
+  int32_t argmax_rows = 0, argmax_max_len = 0;
+  int rows() const { return argmax_words.empty() ? plan->p->K : argmax_rows; }   // output rows
+  void *d_ops = nullptr;           // (rows, n_ops_padded) FeatOp
   void *d_mpi_cols = nullptr;
   bool have_quantiles = false;
   // per-series cut table (fr_pipeline_set_series_cuts): device (cuts_N, cut_slots) int32, owned
@@ -1612,6 +1619,7 @@ void fr_pipeline_destroy(fr_pipeline_t *pl) {
   if (pl->d_mpi_cols) (void)hipFree(pl->d_mpi_cols);
   if (pl->d_npi_pairs) (void)hipFree(pl->d_npi_pairs);
   if (pl->d_prep) (void)hipFree(pl->d_prep);
+  if (pl->d_argmax_words) (void)hipFree(pl->d_argmax_words);
   for (auto &kv : pl->jit) fr::jit_unload(kv.second);
   for (auto &kv : pl->jit_static) fr::jit_unload(kv.second);
   pl->drop_pieces();
@@ -1623,7 +1631,7 @@ int64_t fr_pipeline_info(const fr_pipeline_t *pl, int32_t what) {
   switch (what) {
     case 0: return pl->per_sum;
     case 1: return pl->q_stride;
-    case 2: return (int64_t)pl->per_sum * pl->plan->p->K;
+    case 2: return (int64_t)pl->per_sum * pl->rows();
     case 3: {                                    // run-time compiled kernels loaded
       fr_pipeline *m = const_cast<fr_pipeline *>(pl);
       std::lock_guard<std::mutex> lock(m->jit_mu);
@@ -1649,8 +1657,7 @@ int64_t fr_pipeline_info(const fr_pipeline_t *pl, int32_t what) {
 // that share a population), nothing on the device.
 static void build_pipeline_ops(fr_pipeline_t *pl, const double *h_quant, std::vector<fr::FeatOp> &ops,
                                std::vector<int32_t> &pairs) {
-  const fr::Plan &p = *pl->plan->p;
-  const int K = p.K;
+  const int K = pl->rows();
   ops.assign((size_t)K * pl->n_ops_padded, fr::FeatOp{});
   // An NPI feature whose band, cut and differencing order equal an MPI feature's is that
   // MPI op's population (experiments/fruit_reduced.py pairs NPI and MPI sieves with the
@@ -1735,7 +1742,7 @@ static void build_pipeline_ops(fr_pipeline_t *pl, const double *h_quant, std::ve
 // and the cuts - the same for every output row (the shape only if every row's thresholds agree
 // on it: an infinite threshold in one row alone keeps the generic band).  Caller holds jit_mu.
 static void set_pipeline_jit_ops(fr_pipeline_t *pl, const std::vector<fr::FeatOp> &ops) {
-  const int K = pl->plan->p->K;
+  const int K = pl->rows();
   pl->jit_ops = fr::FusedOps{};
   pl->jit_ops.n_padded = pl->n_ops_padded;
   pl->jit_ops.full_chunks = pl->T % fr::walk_chunk_elems(pl->T) == 0;
@@ -1759,6 +1766,47 @@ static void set_pipeline_jit_ops(fr_pipeline_t *pl, const std::vector<fr::FeatOp
     pl->jit_ops.lo.push_back(ops[i].lo);
     pl->jit_ops.hi.push_back(ops[i].hi);
   }
+}
+
+int fr_pipeline_set_argmax(fr_pipeline_t *pl, int32_t n_words, const int32_t *lengths) {
+  if (!pl || !pl->plan || !pl->plan->p || n_words < 1 || !lengths)
+    return fail(FR_E_ARG, "fr_pipeline_set_argmax: bad argument");
+  const fr::Plan &p = *pl->plan->p;
+  if (!p.letter_sum || p.semiring != fr::kSemiArctic || p.cos)
+    return fail(FR_E_ARG, "fr_pipeline_set_argmax: the plan must be an Arctic letter-sum plan "
+                          "(FR_PLAN_ARCTIC | FR_PLAN_LETTER_SUM) with every prefix of every word as a row");
+  if (pl->have_quantiles)
+    return fail(FR_E_ARG, "fr_pipeline_set_argmax: call it before fr_pipeline_set_quantiles");
+  std::vector<int32_t> words;
+  int64_t v0 = 0, o0 = 0;
+  int max_len = 0;
+  for (int w = 0; w < n_words; ++w) {
+    const int L = lengths[w];
+    if (L < 1 || L > 63) return fail(FR_E_LIMIT, "fr_pipeline_set_argmax: words of 1 to 63 letters");
+    words.insert(words.end(), {(int32_t)v0, L, (int32_t)o0, 0});
+    v0 += L;
+    o0 += L + L * (L + 1) / 2;
+    max_len = std::max(max_len, L);
+  }
+  if (v0 != p.K)
+    return fail(FR_E_ARG, "fr_pipeline_set_argmax: the plan has " + std::to_string(p.K) +
+                              " rows, the words' prefixes are " + std::to_string(v0));
+  if (o0 > 0x7fffffffLL / std::max(1, pl->per_sum) || n_words > 65535)
+    return fail(FR_E_LIMIT, "fr_pipeline_set_argmax: too many rows");
+  for (const PipeSieve &sv : pl->sieves)
+    if (sv.kind != FR_SIEVE_END && (sv.inc < 0 || sv.inc > 2))
+      return fail(FR_E_LIMIT, "fr_pipeline_set_argmax: differencing orders 0 to 2");
+  if (pl->T > 65535 || fr::argmax_sieve_lds(pl->T, max_len) > fr::kArgmaxSieveLds)
+    return fail(FR_E_LIMIT, "fr_pipeline_set_argmax: a row of maxima and the positions of a word's "
+                            "prefixes must fit a workgroup's LDS");
+  if (pl->d_argmax_words) (void)hipFree(pl->d_argmax_words);
+  pl->d_argmax_words = nullptr;
+  HIP_TRY(hipMalloc(&pl->d_argmax_words, words.size() * 4));
+  HIP_TRY(hipMemcpy(pl->d_argmax_words, words.data(), words.size() * 4, hipMemcpyHostToDevice));
+  pl->argmax_words = words;
+  pl->argmax_rows = (int32_t)o0;
+  pl->argmax_max_len = max_len;
+  return FR_OK;
 }
 
 int fr_pipeline_set_quantiles(fr_pipeline_t *pl, const double *h_quant) {
@@ -1805,7 +1853,9 @@ int64_t fr_pipeline_workspace_bytes(const fr_pipeline_t *pl, int64_t N, int64_t 
   if (!pl || N < 0) return fail(FR_E_ARG, "fr_pipeline_workspace_bytes: bad argument");
   const fr::Plan &p = *pl->plan->p;
   size_t b = align_up(work_layout(p, N, pl->T, p.weighting ? lookup_rows : 0).total(), 256);
-  if (!pl->mpi_cols.empty()) b += align_up((size_t)N * pl->per_sum * p.K * 8, 256);
+  if (!pl->mpi_cols.empty()) b += align_up((size_t)N * pl->per_sum * pl->rows() * 8, 256);
+  // (argmax: the running maxima of the plan's rows are materialised, the argmax rows are not)
+  if (!pl->argmax_words.empty()) b += align_up((size_t)p.K * N * pl->T * 8, 256);
   if (pl->prep_n > 0 && pl->prep_std != 0) b += align_up((size_t)N * pl->prep_n * 16, 256);
   // (a plan in pieces leaves its features in walk order first)
   if (pieces_eligible(*pl)) b += align_up((size_t)N * pl->per_sum * p.K * 8, 256);
@@ -1822,6 +1872,9 @@ int fr_pipeline_set_preparation(fr_pipeline_t *pl, int32_t D, int32_t inc_lag, i
   pl->d_prep = nullptr;
   pl->prep_D = pl->prep_n = pl->prep_std = 0;
   if (inc_lag == 0 && standardize == 0) return FR_OK;   // nothing to fuse
+  if (!pl->argmax_words.empty())
+    return fail(FR_E_LIMIT, "fr_pipeline_set_preparation: an argmax pipeline materialises the running "
+                            "maxima from the prepared input");
   // (every fused kernel forms the prepared rows itself since round 4: the cooperative walk in its
   // staging, the wave-per-series kernels in theirs, CosWISS where it reads a letter's rows - all
   // but a CosWISS with the randomised ffn, whose units read transformed copies of the input)
@@ -1874,6 +1927,8 @@ static int pipeline_prepare(fr_pipeline_t *pl, int64_t N, int32_t groups, bool c
   if (!pl->have_quantiles)
     return fail(FR_E_ARG, "fr_pipeline_prepare: call fr_pipeline_set_quantiles first");
   fr::Plan &p = *pl->plan->p;
+  if (!pl->argmax_words.empty())   // (the plan runs as a materialising walk, the sieves in a kernel of the library)
+    return prepare_plan(p, N, pl->T, groups, false, "fr_pipeline_prepare");
   int rc = prepare_plan(p, N, pl->T, groups, true, "fr_pipeline_prepare");
   if (rc != FR_OK) return rc;
   // The pipeline's own kernel: the fused walk with the sieves as compile-time constants (hipRTC,
@@ -2068,7 +2123,7 @@ int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, 
   if (T != pl->T) return fail(FR_E_ARG, "fr_pipeline_run: pipeline was created for another T");
   if (!pl->have_quantiles)
     return fail(FR_E_ARG, "fr_pipeline_run: call fr_pipeline_set_quantiles first");
-  const int64_t F = (int64_t)pl->per_sum * p.K;
+  const int64_t F = (int64_t)pl->per_sum * pl->rows();
   if (N == 0 || F == 0) return FR_OK;
   if (!d_feats || feat_stride < F) return fail(FR_E_ARG, "fr_pipeline_run: bad feature buffer");
   const int64_t need = fr_pipeline_workspace_bytes(pl, N, lookup_rows);
@@ -2131,6 +2186,28 @@ int fr_pipeline_run(fr_pipeline_t *pl, const double *d_X, int64_t N, int64_t D, 
       if (e != hipSuccess) return hip_fail(e, "row_stats launch");
       fu.stats = stats;
     }
+  }
+  if (!pl->argmax_words.empty()) {
+    // Arctic argmax: the running maxima of every prefix (the plan's rows) as a (K, N, T) block of
+    // the workspace, then ONE kernel that forms the argmax rows and their features
+    size_t off = plan_ws;
+    if (!pl->mpi_cols.empty()) off += align_up((size_t)N * F * 8, 256);
+    double *V = reinterpret_cast<double *>(static_cast<char *>(d_work) + off);
+    int rc = run_walk("fr_pipeline_run", p, d_X, N, D, T, d_lookup, lookup_rows, V, N * T, T, d_work,
+                      (int64_t)plan_ws, groups, st, nullptr);
+    if (rc != FR_OK) return rc;
+    hipError_t e = fr::launch_argmax_sieves(V, N, T, pl->d_argmax_words, (int)pl->argmax_words.size() / 4,
+                                            pl->argmax_max_len, fu.ops, fu.n_ops, fu.n_ops_padded, d_feats,
+                                            fu.cnt, feat_stride, fu.series_cuts, fu.cut_slots, st);
+    if (e != hipSuccess) return hip_fail(e, "argmax_sieves launch");
+    if (!pl->mpi_cols.empty()) {
+      e = fr::launch_mpi_finalize(d_feats, fu.cnt, N, feat_stride,
+                                  static_cast<const int32_t *>(pl->d_mpi_cols), (int)pl->mpi_cols.size(),
+                                  static_cast<const int32_t *>(pl->d_npi_pairs),
+                                  (int)pl->npi_pairs.size() / 2, pl->per_sum, pl->rows(), st);
+      if (e != hipSuccess) return hip_fail(e, "mpi_finalize launch");
+    }
+    return FR_OK;
   }
   const int32_t *walk_of_row = nullptr;
   if (pieces_eligible(*pl)) {

@@ -60,6 +60,15 @@ hipError_t launch_coswiss_combine(const double *A, int64_t N, int64_t T, int n_o
 hipError_t launch_nan_to_num(double *x, int64_t count, hipStream_t st);
 hipError_t launch_standardize(const double *X, int64_t rows, int64_t T, int div_std, double eps,
                               double *out, hipStream_t st);
+// Arctic argmax rows -> features (kernels_misc.hip, argmax_sieve_kernel): `words` = device
+// (n_words, 4) int32 {first V row, letters, first output row, 0}; the dynamic LDS of a workgroup
+// (one row of V, the positions of a word's prefixes) must fit kArgmaxSieveLds
+constexpr size_t kArgmaxSieveLds = 64 * 1024 - 4096;
+size_t argmax_sieve_lds(int64_t T, int max_len);
+hipError_t launch_argmax_sieves(const double *V, int64_t N, int64_t T, const void *words, int n_words,
+                                int max_len, const FeatOp *ops, int n_ops, int n_ops_padded,
+                                double *feats, double *cnt, int64_t feat_stride,
+                                const int32_t *series_cuts, int cut_slots, hipStream_t st);
 hipError_t launch_arctic_argmax(const double *V, int64_t rows, int64_t N, int64_t T, int n_jobs,
                                 const int32_t *jobs, double *P, double *out, hipStream_t st);
 hipError_t launch_row_stats(const double *X, int64_t N, int64_t D, int64_t T, const int32_t *prep,

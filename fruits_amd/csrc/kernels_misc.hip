@@ -415,6 +415,171 @@ hipError_t launch_arctic_argmax(const double *V, int64_t rows, int64_t N, int64_
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- Arctic argmax + sieves
+// The rows of Arctic(argmax=True) straight into NPI / MPI / END features (fr_pipeline_set_argmax):
+// one workgroup per (series, word).  Of a word of L letters the running maxima V_0 .. V_(L-1) of
+// its prefixes exist (the walk kernel wrote them); prefix k contributes the row V_k and k + 1
+// position rows (see above), L + L (L + 1) / 2 rows in all, every one a function of V alone - so
+// none of them is written: V_k is staged in LDS, its positions P_k join the positions of the
+// prefixes in front (LDS, 16 bits each: T < 65536), and every row is formed element by element
+// for the feature ops that look at it - R_s[t] = P_(s-1)[min(t, m_s)].
+struct ArgmaxWord {
+  int32_t v_row0, L, out_row0, pad;
+};
+// values of a row: V_k, or a frozen position row
+struct ArgmaxRow {
+  const double *v;            // LDS: V_k, or nullptr
+  const unsigned short *p;    // LDS: P_(s-1)
+  int m;                      // frozen from here on
+  __device__ __forceinline__ double operator()(int t) const {
+    if (v) return v[t];
+    return (double)p[t < m ? t : m];
+  }
+};
+// the inc-th zero-padded difference at t (fruits/cache.py:8-13; the triangle of the selection)
+template <int INC>
+__device__ __forceinline__ double argmax_diff(const ArgmaxRow &r, int t) {
+  double v[INC + 1];
+#pragma unroll
+  for (int j = 0; j <= INC; ++j) v[j] = t - j >= 0 ? r(t - j) : 0.0;
+#pragma unroll
+  for (int lvl = 1; lvl <= INC; ++lvl)
+#pragma unroll
+    for (int j = 0; j + lvl <= INC; ++j) v[j] = (t - j >= 1) ? v[j] - v[j + 1] : 0.0;
+  return v[0];
+}
+// one band op over the row: the sum and the number of the elements t in [lo, hi) whose
+// difference lies in (qlo, qhi]; the whole workgroup takes part, thread 0 gets the totals
+template <int INC>
+__device__ __forceinline__ void argmax_band(const ArgmaxRow &r, int lo, int hi, double qlo, double qhi,
+                                            double *red, double &sum, double &cnt) {
+  double s = 0.0, c = 0.0;
+  for (int t = lo + (int)threadIdx.x; t < hi; t += (int)blockDim.x) {
+    const double d = argmax_diff<INC>(r, t);
+    if (qlo < d && d <= qhi) {
+      s += d;
+      c += 1.0;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    c += __shfl_xor(c, o);
+  }
+  __syncthreads();   // (red is reused op after op)
+  if ((threadIdx.x & 63) == 0) {
+    red[2 * (threadIdx.x >> 6)] = s;
+    red[2 * (threadIdx.x >> 6) + 1] = c;
+  }
+  __syncthreads();
+  sum = cnt = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+      sum += red[2 * w];
+      cnt += red[2 * w + 1];
+    }
+}
+
+__global__ __launch_bounds__(256) void argmax_sieve_kernel(
+    const double *__restrict__ V, int64_t N, int64_t T, const ArgmaxWord *__restrict__ words,
+    const FeatOp *__restrict__ ops, int n_ops, int n_ops_padded, double *__restrict__ feats,
+    double *__restrict__ cnt, int64_t feat_stride, const int32_t *__restrict__ series_cuts,
+    int cut_slots) {
+  extern __shared__ double dyn_lds[];
+  __shared__ double red[8];
+  __shared__ int part[256];
+  __shared__ int m[66];   // m_s for s = 1 .. k + 1 (words of <= 63 letters)
+  const int64_t n = blockIdx.x;
+  const ArgmaxWord w = words[blockIdx.y];
+  const int Ti = (int)T, tid = (int)threadIdx.x;
+  double *vrow = dyn_lds;
+  unsigned short *pos = reinterpret_cast<unsigned short *>(dyn_lds + T);   // [L][T]
+  const int32_t *cut_row = series_cuts ? series_cuts + n * cut_slots : nullptr;
+  double *frow = feats + n * feat_stride, *crow = cnt + n * feat_stride;
+  int out_row = w.out_row0;
+  for (int k = 0; k < w.L; ++k) {
+    // V_k into LDS; P_k[t] = the index at which the running maximum was last raised
+    const double *v = V + ((int64_t)(w.v_row0 + k) * N + n) * T;
+    __syncthreads();   // (the previous prefix's ops are done with vrow)
+    for (int t = tid; t < Ti; t += 256) vrow[t] = v[t];
+    __syncthreads();
+    unsigned short *pk = pos + (int64_t)k * T;
+    const int per = (Ti + 255) / 256, lo = tid * per, hi = lo + per < Ti ? lo + per : Ti;
+    int best = 0;
+    for (int t = lo > 0 ? lo : 1; t < hi; ++t)
+      if (vrow[t] > vrow[t - 1]) best = t;
+    part[tid] = best;
+    __syncthreads();
+    int run = 0;
+    for (int i = 0; i < tid; ++i) run = part[i] > run ? part[i] : run;
+    for (int t = lo; t < hi; ++t) {
+      if (t > 0 && vrow[t] > vrow[t - 1]) run = t;
+      pk[t] = (unsigned short)run;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      m[k + 1] = Ti - 1;
+      for (int s = k; s >= 1; --s) m[s] = pos[(int64_t)s * T + m[s + 1]];
+    }
+    __syncthreads();
+    // the k + 2 rows of this prefix: V_k, then R_1 .. R_(k+1)
+    for (int s = 0; s <= k + 1; ++s, ++out_row) {
+      ArgmaxRow r{s == 0 ? vrow : nullptr, s == 0 ? nullptr : pos + (int64_t)(s - 1) * T, s == 0 ? 0 : m[s]};
+      const FeatOp *row_ops = ops + (int64_t)out_row * n_ops_padded;
+      for (int i = 0; i < n_ops; ++i) {
+        const FeatOp op = row_ops[i];
+        const int kind = op.kind_inc & 0xff, inc = (int)(int8_t)((op.kind_inc >> 8) & 0xff);
+        const bool cuts = (op.kind_inc & (1 << 16)) != 0;
+        if (kind == FR_SIEVE_END_K) {
+          int pick = op.lo;
+          if (cuts) {   // X[:, cut - 1], index -1 wrapping like numpy
+            pick = cut_row[op.lo] - 1;
+            if (pick < 0) pick += Ti;
+          }
+          if (tid == 0 && pick >= 0 && pick < Ti) frow[op.col] = r(pick);   // (else: a padding op)
+          continue;
+        }
+        int lo_t = op.lo, hi_t = op.hi;
+        if (cuts) {
+          lo_t = cut_row[op.lo];
+          hi_t = cut_row[op.hi];
+        }
+        lo_t = lo_t < 0 ? 0 : lo_t;
+        hi_t = hi_t > Ti ? Ti : hi_t;
+        double sum, c;
+        if (inc == 0) argmax_band<0>(r, lo_t, hi_t, op.qlo, op.qhi, red, sum, c);
+        else if (inc == 1) argmax_band<1>(r, lo_t, hi_t, op.qlo, op.qhi, red, sum, c);
+        else argmax_band<2>(r, lo_t, hi_t, op.qlo, op.qhi, red, sum, c);
+        if (tid == 0) {
+          if (kind == FR_SIEVE_MPI_K) {
+            frow[op.col] = sum;
+            crow[op.col] = c;
+          } else {
+            frow[op.col] = c;
+          }
+        }
+      }
+    }
+  }
+}
+
+size_t argmax_sieve_lds(int64_t T, int max_len) {
+  return (size_t)T * 8 + (size_t)max_len * (size_t)T * 2 + 16;
+}
+
+hipError_t launch_argmax_sieves(const double *V, int64_t N, int64_t T, const void *words, int n_words,
+                                int max_len, const FeatOp *ops, int n_ops, int n_ops_padded,
+                                double *feats, double *cnt, int64_t feat_stride,
+                                const int32_t *series_cuts, int cut_slots, hipStream_t st) {
+  if (N <= 0 || T <= 0 || n_words <= 0) return hipSuccess;
+  if (N > 0x7fffffffLL || n_words > 65535 || T > 65535 || max_len > 63) return hipErrorInvalidValue;
+  const size_t lds = argmax_sieve_lds(T, max_len);
+  if (lds > kArgmaxSieveLds) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(argmax_sieve_kernel, dim3((unsigned)N, (unsigned)n_words), dim3(256), lds, st, V, N, T,
+                     static_cast<const ArgmaxWord *>(words), ops, n_ops, n_ops_padded, feats, cnt,
+                     feat_stride, series_cuts, cut_slots);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- rank selection (fit)
 // SegmentSieve._fit needs np.quantile of the pre-transformed fit sample
 // (fruits/sieving/segment.py:66-75, increment.py:73-74).  np.quantile interpolates

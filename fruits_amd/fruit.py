@@ -522,7 +522,14 @@ class FruitSlice:
             return False
         last = self._iss[-1]
         if getattr(last, "_argmax", False):
-            return False     # (position rows are assembled from materialised maxima)
+            # Arctic argmax: the running maxima are materialised, every argmax row is formed in
+            # LDS for the sieves that look at it (fr_pipeline_set_argmax) - differencing orders
+            # 0 to 2, single ISS; anything else keeps fr_arctic_argmax + one launch per sieve
+            if len(self._iss) != 1 or os.environ.get("FRUITS_AMD_FUSED_ARGMAX", "1") == "0":
+                return False
+            for sv in self._sieves:
+                if type(sv) in (NPI, MPI) and not 0 <= sv._inc <= 2:
+                    return False
         if type(last) is not ISS:
             from .iss.cos import CosWISS
             # the factorised CosWISS kernels fuse; the term-by-term path reduces first
@@ -558,9 +565,12 @@ class FruitSlice:
             iss._check_supported()
             if hasattr(iss, "_arm_plan"):     # CosWISS dropout: the plan carries the mask
                 iss._check_supported()
+            argmax = None
+            if getattr(iss, "_argmax", False):   # (the pipeline's rows are the argmax rows, not the plan's)
+                argmax = [len(iss.words[i]) for i in (range(len(iss.words)) if indices is None else indices)]
             if indices is None:
                 plan = iss._plan(0, len(iss.words))
-                rows = range(plan.rows)
+                rows = range(plan.rows if argmax is None else iss._rows_of(0, len(iss.words)))
                 if hasattr(iss, "_arm_plan"):
                     iss._arm_plan(plan, tuple(range(len(iss.words))), T)
             else:
@@ -576,11 +586,12 @@ class FruitSlice:
                       else self._sieves)
             specs, cut_columns, n_slots = self._pipeline_specs(acting, T)
             try:
-                pipe = nat.Pipeline(plan, specs, T) if len(rows) and plan.fits(T) else None
+                pipe = (nat.Pipeline(plan, specs, T, argmax_lengths=argmax)
+                        if len(rows) and plan.fits(T) else None)
             except ValueError:
                 pipe = None
             if pipe is not None:
-                assert plan.rows == len(rows)
+                assert pipe.rows == len(rows)
                 quant = np.zeros((len(rows), pipe.q_stride))
                 lazy = isinstance(self._sieves_extended, _FittedRows)
                 if lazy:     # (the thresholds of all rows are arrays already)

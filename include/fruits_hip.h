@@ -449,6 +449,18 @@ int fr_coswiss_combine(const double *d_terms, int64_t n_terms, int64_t N, int64_
 int fr_arctic_argmax(const double *d_V, int64_t rows, int64_t N, int64_t T, int32_t n_jobs,
                      const int32_t *d_jobs, double *d_P, double *d_out, void *stream);
 
+/* The same rows straight into features: a pipeline over an FR_PLAN_ARCTIC |
+ * FR_PLAN_ARCTIC_LETTER_SUM plan whose rows are all prefixes of `n_words` words of `lengths[w]`
+ * letters (in the plan's order) then has sum of L + L(L+1)/2 OUTPUT rows - what FruitSlice.transform
+ * sieves for ISS(semiring=Arctic(argmax=True)), fruits/fruit.py:538-550 over iss.py:140-146 - and
+ * fr_pipeline_set_quantiles takes one row of thresholds per output row.  fr_pipeline_run materialises
+ * the running maxima (sum of L rows, in the workspace) and ONE more kernel forms every argmax row
+ * in LDS for the NPI / MPI / END ops that look at it: neither the positions nor the argmax rows are
+ * written.  Call between fr_pipeline_create and fr_pipeline_set_quantiles.  FR_E_LIMIT (the caller
+ * keeps fr_arctic_argmax + fr_sieve): a sieve differences more than twice or cumulates, or a row
+ * of maxima and the positions of a word's prefixes (8 T + 2 L T bytes) exceed 60 KB of LDS. */
+int fr_pipeline_set_argmax(fr_pipeline_t *pipeline, int32_t n_words, const int32_t *lengths);
+
 /* ------------------------------------------------------------------ Fruit.transform epilogue
  * np.nan_to_num(result, copy=False, nan=0.0) of Fruit.transform (fruits/fruit.py:172) on the
  * device-resident feature matrix, in place: NaN -> 0, +inf / -inf -> the largest / lowest

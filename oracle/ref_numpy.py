@@ -826,7 +826,7 @@ def _iterate_iss(X, iss_list, X_raw, idx=0):
     else:
         lookup, total = _weight_lookup(i.get("weighting"), X, X_raw)
         its = iss_transform(X, i["words"], i["mode"], i.get("alphas"), lookup, total,
-                            i.get("semiring", "Reals"))
+                            i.get("semiring", "Reals"), argmax=i.get("argmax", False))
     for itsum in its:
         yield from _iterate_iss(itsum[:, None, :], iss_list, X_raw, idx + 1)
 

@@ -148,6 +148,53 @@ def test_arctic_argmax_random(fr, T):
     np.testing.assert_array_equal(feats[:, 0::2], ref[:, :, -1].T)
 
 
+@pytest.mark.parametrize("T", [2, 63, 300, 1024, 1500])
+@pytest.mark.parametrize("weighting", [None, {"kind": "Indices", "scale": 2.0}])
+def test_arctic_argmax_fused(fr, monkeypatch, T, weighting):
+    """Arctic(argmax=True) under sieves (fr_pipeline_set_argmax: the running maxima materialised,
+    every argmax row formed in LDS for the ops that look at it) against the oracle's
+    FruitSlice (fruits/fruit.py:538-550 over semiring.py:239-284) and against the materialising
+    path (fr_arctic_argmax + one launch per sieve) with the same thresholds: values, positions,
+    their first and second differences, integer and float cuts."""
+    rng = np.random.default_rng(T + (7 if weighting else 0))
+    X = rng.standard_normal((9, 2, T)).cumsum(axis=2)
+    X[1] = np.round(X[1])            # plateaus and exact ties: `>=` keeps the earlier index
+    cut = [max(T // 3, 1), -1]
+    spec = {"slices": [{
+        "preps": [], "iss": [{"words": ["[1][2][-1]", "[2]", "[12][1][1][2]"], "mode": "EXTENDED",
+                              "semiring": "Arctic", "argmax": True, "weighting": weighting}],
+        "sieves": [{"kind": "NPI", "q": [0.25, 0.5, 1.0]}, {"kind": "NPI", "q": [0.5, 1.0], "inc": 1},
+                   {"kind": "MPI", "q": [0.3, 1.0], "inc": 2, "cut": cut}, {"kind": "MPI", "q": [-1.0, 0.5]},
+                   {"kind": "END", "cut": cut}, {"kind": "NPI", "q": [0.5, 1.0], "cut": [0.5, -1]}],
+        "fit_sample_size": 1.0}]}
+    fruit = build_fruit(fr, spec)
+    np.random.seed(3)
+    fruit.fit(X)
+    slc = fruit.get_slice()
+    got = fruit.transform(X)
+    pipe = slc._fused(T)
+    assert pipe is not None and pipe.rows == slc.niteratedsums() == 3 + 6 + 1 + 1 + 4 + 10
+    monkeypatch.setenv("FRUITS_AMD_FUSED_ARGMAX", "0")
+    slc._fused_cache = {}
+    assert slc._fused(T) is None
+    mat = fruit.transform(X)
+    per_sum = [type(sv).__name__ != "MPI" for sv in slc._sieves for _ in range(sv.nfeatures())]
+    counts = np.array(per_sum * slc.niteratedsums())
+    np.testing.assert_array_equal(got[:, counts], mat[:, counts])       # counts and picked values
+    np.testing.assert_allclose(got[:, ~counts], mat[:, ~counts], rtol=1e-12, atol=1e-12)
+    # the oracle, with the GPU's thresholds (the fit is compared on its own elsewhere)
+    np.random.seed(3)
+    fitted = orc.fruit_fit(spec, X)
+    fit_parity(fruit, fitted, "argmax")
+    transplant_thresholds(fruit, fitted)
+    monkeypatch.setenv("FRUITS_AMD_FUSED_ARGMAX", "1")
+    ref = np.nan_to_num(orc.fruit_transform(spec, fitted, X))
+    got = fruit.transform(X)
+    assert slc._fused(T) is not None
+    np.testing.assert_array_equal(got[:, counts], ref[:, counts])
+    np.testing.assert_allclose(got[:, ~counts], ref[:, ~counts], rtol=1e-11, atol=1e-12)
+
+
 @pytest.mark.parametrize("T", [5, 511, 1024, 1025, 3000])
 def test_arctic_ragged_and_long_chains(fr, T):
     rng = np.random.default_rng(T)
@@ -966,8 +1013,9 @@ def build_fruit(fr, spec):
                 fruit.add(fr.CosWISS(freqs=i["freqs"], words=ws, exponent=i.get("exponent", 2),
                                      total_weighting=i.get("total_weighting", False)))
                 continue
+            semiring = getattr(fr.semiring, i.get("semiring", "Reals"))
             fruit.add(fr.ISS(ws, mode=getattr(fr.ISSMode, i["mode"]),
-                             semiring=getattr(fr.semiring, i.get("semiring", "Reals"))(),
+                             semiring=semiring(argmax=True) if i.get("argmax") else semiring(),
                              weighting=make_weighting(fr, i.get("weighting"))))
         for s in sl["sieves"]:
             kw = {k: (tuple(v) if k == "q" else v) for k, v in s.items() if k != "kind"}
