@@ -1326,6 +1326,70 @@ def test_word_sharded_blocks_reassemble(fr, world, name):
         np.testing.assert_allclose(full, ref, rtol=1e-12, atol=1e-300)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_word_sharded_argmax(fr, world):
+    """A rank's share of the words of an Arctic(argmax=True) slice is one argmax pipeline
+    (fr_pipeline_set_argmax over the share's words); the shares reassemble to the unsharded
+    transform."""
+    from fruits_amd import parallel as par
+    from fruits_amd.cache import SharedSeedCache
+    rng = np.random.default_rng(world)
+    X = rng.standard_normal((11, 2, 257)).cumsum(axis=2)
+    fruit = fr.Fruit()
+    fruit.add(fr.ISS(fr.words.of_weight(3, 2), mode=fr.ISSMode.EXTENDED,
+                     semiring=fr.semiring.Arctic(argmax=True)))
+    fruit.add(fr.sieving.NPI(q=(0.4, 1.0), inc=1), fr.sieving.END, fr.sieving.MPI(q=(0.5, 1.0)))
+    fruit.get_slice().fit_sample_size = 1.0
+    np.random.seed(0)
+    fruit.fit(X)
+    ref = fruit.transform(X)
+    slc = fruit.get_slice()
+    iss = slc.get_iss()[0]
+    strings = [str(w) for w in iss.words]
+    depths = [iss._depth(i) for i in range(len(strings))]
+    per_sum = sum(s.nfeatures() for s in slc.get_sieves())
+    parts = par.shard_words(strings, depths, world)
+    maps = par.column_map(parts, depths, per_sum)
+    out = np.zeros_like(ref)
+    for r in range(world):
+        cache = SharedSeedCache(X)
+        pipe = slc._fused(X.shape[2], indices=parts[r])
+        assert pipe is not None and pipe.rows == sum(depths[i] for i in parts[r])
+        out[:, maps[r]] = par._device_block(slc, iss, cache.input_device(X), cache, parts[r], depths,
+                                            per_sum).cpu().numpy()
+    np.testing.assert_allclose(np.nan_to_num(out), ref, rtol=1e-12, atol=1e-300)
+
+
+def test_argmax_pipeline_limits(fr):
+    """What fr_pipeline_set_argmax refuses keeps the materialising path (same features): series
+    whose maxima and positions exceed a workgroup's LDS, a sieve that differences three times."""
+    rng = np.random.default_rng(5)
+    for T, inc in ((7000, 1), (300, 3)):
+        X = rng.standard_normal((3, 1, T)).cumsum(axis=2)
+        fruit = fr.Fruit()
+        fruit.add(fr.ISS([fr.words.SimpleWord("[1][1][1][1]"), fr.words.SimpleWord("[1][-1]")],
+                         mode=fr.ISSMode.EXTENDED, semiring=fr.semiring.Arctic(argmax=True)))
+        fruit.add(fr.sieving.NPI(q=(0.5, 1.0), inc=inc), fr.sieving.END)
+        fruit.get_slice().fit_sample_size = 1.0
+        np.random.seed(0)
+        feats = fruit.fit_transform(X)
+        assert fruit.get_slice()._fused(T) is None
+        rows = orc.iss_transform(X, ["[1][1][1][1]", "[1][-1]"], "EXTENDED", semiring="Arctic", argmax=True)
+        np.testing.assert_array_equal(feats[:, 1::2], rows[:, :, -1].T)
+    # (at T = 4096 a word of three letters still fits: 32 KB + 3 x 8 KB)
+    X = rng.standard_normal((3, 1, 4096)).cumsum(axis=2)
+    fruit = fr.Fruit()
+    fruit.add(fr.ISS([fr.words.SimpleWord("[1][1][1]")], mode=fr.ISSMode.EXTENDED,
+                     semiring=fr.semiring.Arctic(argmax=True)))
+    fruit.add(fr.sieving.NPI(q=(0.5, 1.0)), fr.sieving.END)
+    fruit.get_slice().fit_sample_size = 1.0
+    np.random.seed(0)
+    feats = fruit.fit_transform(X)
+    assert fruit.get_slice()._fused(4096) is not None
+    rows = orc.iss_transform(X, ["[1][1][1]"], "EXTENDED", semiring="Arctic", argmax=True)
+    np.testing.assert_array_equal(feats[:, 1::2], rows[:, :, -1].T)
+
+
 @pytest.mark.parametrize("world", [1, 2, 3])
 def test_word_sharded_coswiss_ffn(fr, world):
     """A CosWISS with the randomised ffn (every (word, frequency) reads its own transformed copy
