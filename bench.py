@@ -440,11 +440,38 @@ def extras(torch, fr, nat, dev, quick=False):
     sec["cfg5"] = _fused_entry(p5, pipe5, _event_time_us(torch, fn, reps=3), issue, "cfg5")
     del p5, fn, pipe5
     torch.cuda.empty_cache()
+    # (f) the reference's experiments/fruit_reduced.py (four slices: Reals + Indices, Arctic, two
+    # CosWISS; 4431 features) on (2048,1,1024): Fruit.fit (3798 order statistics selected on the
+    # device) and Fruit.transform, wall clock with the input on the host
+    det["fruit_reduced"] = fruit_reduced_times(torch)
     # (e) a cold machine
     det["cold_start"] = {w: cold_start(torch, fr, nat, w) for w in ("cfg3", "cfg4")}
     det["cold_start"]["cfg4_without_shipped_kernels"] = cold_start(torch, fr, nat, "cfg4", bundle=False)
     torch.cuda.empty_cache()
     return sec, sweep_rows, det
+
+
+def fruit_reduced_times(torch, reps=5):
+    tools = os.path.join(ROOT, "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import bench_pipeline as bp
+    X = np.random.default_rng(0).standard_normal((2048, 1, 1024)).cumsum(axis=2)
+    fruit = bp.build_reduced()
+    fits, trs = [], []
+    for i in range(reps + 1):
+        np.random.seed(0)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        fruit.fit(X)
+        torch.cuda.synchronize(); fits.append(time.perf_counter() - t0)
+    fruit.transform(X)
+    for i in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        fruit.transform(X)
+        torch.cuda.synchronize(); trs.append(time.perf_counter() - t0)
+    return {"shape": [2048, 1, 1024], "features": int(fruit.nfeatures()),
+            "fit_ms": round(float(np.median(fits[1:])) * 1e3, 1),
+            "transform_ms": round(float(np.median(trs)) * 1e3, 1)}
 
 
 # --------------------------------------------------------------------------- word-sharded config 4

@@ -805,7 +805,9 @@ __device__ __forceinline__ void hist_count(unsigned int *__restrict__ row, unsig
     const unsigned int lead_bin = (unsigned int)__builtin_amdgcn_readlane((int)bin, leader);
     const bool same = todo && bin == lead_bin;
     const unsigned long long ms = __ballot(same);
-    if (SHIFT >= 48 || ms == m) {   // (see hist_level)
+    // (the first digit alone counts a partial lane group: in the second one - four exponent and
+    // four mantissa bits - the rest of the wave is spread out already, 1.81 -> 1.74 ms)
+    if (SHIFT >= 56 || ms == m) {
       if ((int)(threadIdx.x & 63) == leader) atomicAdd(&row[lead_bin], (unsigned int)__popcll(ms));
       todo = todo && !same;
       m &= ~ms;
