@@ -704,3 +704,50 @@ def test_bundle_compiles_without_a_device(tmp_path, monkeypatch):
         stamp = {f: os.path.getmtime(out / f) for f in files}
         assert pipe.bundle(quant, str(out)) == n and sorted(os.listdir(out)) == files   # found, not rebuilt
         assert all(os.path.getsize(out / f) > 4096 for f in files)
+
+
+def test_fitted_rows_table():
+    """What a device-side fit leaves in FruitSlice._sieves_extended (fruit.py, _FittedRows): the
+    thresholds of all rows as arrays, formed like SegmentSieve._set_quantiles_from_stats forms one
+    row's (numpy's _lerp, both ends; NaN-last sort), the list-of-lists of fruits/fruit.py:462-476
+    made on demand - changed copies are seen by later reads and survive pickling."""
+    import pickle
+    from fruits_amd.fruit import _FittedRows, _interpolated_quantiles
+    rng = np.random.default_rng(0)
+    npi = fr.sieving.NPI(q=(0.25, 0.7, 1.0), inc=1)
+    mpi = fr.sieving.MPI(q=(-1.0, 0.5))
+    end = fr.sieving.END()
+    n = 1001
+    rows = 7
+    tables = []
+    for sv in (npi, mpi):
+        reqs = sv._quantile_requests(n)
+        lo = rng.standard_normal((rows, len(reqs)))
+        hi = lo + rng.random((rows, len(reqs)))
+        lo[2, 0] = np.nan
+        got = _interpolated_quantiles(sv, reqs, lo, hi)
+        for k in range(rows):
+            one = sv.copy()
+            one._set_quantiles_from_stats(reqs, lo[k].tolist(), hi[k].tolist())
+            np.testing.assert_array_equal(got[k], one._quantiles)
+        tables.append(got)
+    ext = _FittedRows([npi, mpi, end], cache=None)
+    first = ext.add_rows(3)
+    second = ext.add_rows(rows - 3)
+    for i in range(2):
+        first[i], second[i] = tables[i][:3], tables[i][3:]
+    assert len(ext) == rows and bool(ext) and not _FittedRows([npi], None)
+    assert ext.thresholds(2, range(rows)) is None          # END is not fitted on data
+    np.testing.assert_array_equal(ext.thresholds(0, [5, 1]), tables[0][[5, 1]])
+    row = ext[-1]
+    assert [type(s) for s in row] == [fr.sieving.NPI, fr.sieving.MPI, fr.sieving.END] and ext[rows - 1] is row
+    np.testing.assert_array_equal(row[1]._quantiles, tables[1][-1])
+    assert row[0]._inc == 1 and len(list(ext)) == rows and len(ext[1:4]) == 3
+    with pytest.raises(IndexError):
+        ext[rows]
+    row[0]._quantiles = np.array([1.0, 2.0, 3.0])       # (what transplant_thresholds does)
+    np.testing.assert_array_equal(ext.thresholds(0, [rows - 1, 0]), [[1.0, 2.0, 3.0], tables[0][0]])
+    back = pickle.loads(pickle.dumps(ext))
+    assert len(back) == rows and back._cache is None
+    np.testing.assert_array_equal(back[rows - 1][0]._quantiles, [1.0, 2.0, 3.0])
+    np.testing.assert_array_equal(back.thresholds(1, range(rows)), tables[1])
