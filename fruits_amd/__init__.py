@@ -13,3 +13,10 @@ from .iss.cos import CosWISS
 from .iss.iss import ISS, ISSMode
 
 __version__ = "0.1.0"
+
+
+def release_scratch() -> None:
+    """Frees the device and page-locked scratch a device-side ``Fruit.fit`` keeps for the next
+    one (fr_release_scratch); not in the reference."""
+    from . import _native
+    _native.release_scratch()

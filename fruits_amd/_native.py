@@ -34,7 +34,7 @@ EXPORTS = [
     "fr_pathlen_lookup", "fr_sieve", "fr_pre_transform", "fr_standardize",
     "fr_pipeline_create", "fr_pipeline_destroy", "fr_pipeline_info",
     "fr_pipeline_workspace_bytes", "fr_pipeline_run", "fr_pipeline_set_quantiles",
-    "fr_select_ranks", "fr_coswiss_combine", "fr_plan_create_coswiss", "fr_nan_to_num",
+    "fr_select_ranks", "fr_select_ranks_begin", "fr_select_ranks_end", "fr_coswiss_combine", "fr_plan_create_coswiss", "fr_nan_to_num",
     "fr_plan_prepare", "fr_pipeline_prepare", "fr_pipeline_compile_plan", "fr_pipeline_prepare_cached", "fr_pipeline_bundle", "fr_plan_fits", "fr_release_scratch",
     "fr_pipeline_set_preparation", "fr_pipeline_set_series_cuts", "fr_pipeline_set_argmax", "fr_arctic_argmax", "fr_coswiss_set_dropout",
     "fr_coswiss_set_input_stride", "fr_coswiss_ffn",
@@ -101,6 +101,8 @@ def lib():
     L.fr_pipeline_prepare_cached.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
     L.fr_pipeline_set_series_cuts.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     L.fr_pipeline_set_argmax.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.fr_select_ranks_begin.restype = C.c_void_p
+    L.fr_select_ranks_end.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.fr_pipeline_set_preparation.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                               C.c_int32, C.c_double]
     _lib = L
@@ -168,7 +170,30 @@ def to_device(arr, dtype=None):
             x = x.to(dtype)
         return x.contiguous()
     a = np.ascontiguousarray(arr, dtype=dtype or np.float64)
-    return t.from_numpy(a).to(dev)
+    # The copy from pageable memory is synchronous with the stream it is queued on - on the
+    # caller's stream it would wait for everything queued there (Fruit.fit: the selection of the
+    # slice before).  It goes through a stream of its own; the caller's stream waits for it on
+    # the device.
+    cur = t.cuda.current_stream(dev)
+    if t.cuda.is_current_stream_capturing():
+        return t.from_numpy(a).to(dev)
+    up = _upload_stream(dev)
+    with t.cuda.stream(up):
+        x = t.from_numpy(a).to(dev)
+    cur.wait_stream(up)
+    x.record_stream(cur)
+    return x
+
+
+_upload_streams: dict = {}
+
+
+def _upload_stream(dev):
+    key = str(dev)
+    st = _upload_streams.get(key)
+    if st is None:
+        st = _upload_streams[key] = torch().cuda.Stream(device=dev)
+    return st
 
 
 # Downloads of at least this many bytes land in page-locked memory from torch's caching host
@@ -742,6 +767,47 @@ def select_ranks(block, job_row, job_inc, job_rank, stream=None) -> np.ndarray:
         stream_ptr() if stream is None else stream)
     check(rc, "fr_select_ranks")
     return out
+
+
+class Selection:
+    """fr_select_ranks_begin / _end: the selection is queued on the current stream and the call
+    returns; ``result()`` waits for it and returns the values (once)."""
+
+    def __init__(self, block, job_row, job_inc, job_rank):
+        rows, N, T = block.shape
+        if not block.is_contiguous():
+            raise ValueError("block must be contiguous")
+        jr = np.ascontiguousarray(job_row, dtype=np.int32)
+        ji = np.ascontiguousarray(job_inc, dtype=np.int32)
+        jk = np.ascontiguousarray(job_rank, dtype=np.int64)
+        self._n = len(jr)
+        self._block = block      # (read by the passes until result())
+        self._vals = None
+        L = lib()
+        h = L.fr_select_ranks_begin(
+            dptr(block), C.c_int64(rows), C.c_int64(N), C.c_int64(T), C.c_int32(self._n),
+            jr.ctypes.data_as(C.POINTER(C.c_int32)), ji.ctypes.data_as(C.POINTER(C.c_int32)),
+            jk.ctypes.data_as(C.POINTER(C.c_int64)), stream_ptr())
+        if not h:
+            raise NativeError(f"fr_select_ranks_begin: {last_error()}")
+        self._h = C.c_void_p(h)
+
+    def result(self) -> np.ndarray:
+        if self._vals is None:
+            out = np.zeros(self._n)
+            h, self._h = self._h, None
+            check(lib().fr_select_ranks_end(h, out.ctypes.data_as(C.POINTER(C.c_double))),
+                  "fr_select_ranks_end")
+            self._vals, self._block = out, None
+        return self._vals
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and _lib is not None:
+                _lib.fr_select_ranks_end(self._h, None)     # (waits, frees the handle and its scratch)
+                self._h = None
+        except Exception:
+            pass
 
 
 def standardize(Xd, div_std: bool, eps: float):

@@ -29,22 +29,30 @@ namespace {
 
 thread_local std::string g_err;
 
-// grow-only device scratch of the synchronous fit entry point (fr_select_ranks), per device
+// Scratch of the fit's selections (fr_select_ranks_begin / _end), per device: a few blobs - device
+// memory (jobs, histograms, candidate lists, results) and page-locked host memory (the job table
+// on its way up, the results on their way down) - that selections in flight own and later ones
+// reuse; grow-only, freed by fr_release_scratch
 struct Scratch {
-  void *ptr = nullptr;
-  size_t bytes = 0;
+  void *ptr = nullptr, *host = nullptr;
+  size_t bytes = 0, host_bytes = 0;
+  bool busy = false;
 };
-constexpr int kScratchDevices = 64;
+constexpr int kScratchDevices = 64, kScratchBlobs = 8;
 std::mutex g_scratch_mu[kScratchDevices];   // one per device: fits on different devices do not queue
-Scratch g_scratch[kScratchDevices];
+Scratch g_scratch[kScratchDevices][kScratchBlobs];
+
+thread_local int g_last_code = 0;   // of the entry points that return a handle (fr_select_ranks_begin)
 
 int fail(int code, const std::string &msg) {
   g_err = msg;
+  g_last_code = code;
   return code;
 }
 
 int hip_fail(hipError_t e, const char *what) {
   g_err = std::string(what) + ": " + hipGetErrorString(e);
+  g_last_code = FR_E_HIP;
   return FR_E_HIP;
 }
 
@@ -2332,16 +2340,36 @@ int fr_sieve(int32_t kind, const double *d_A, int64_t N, int64_t T, int64_t a_st
   return FR_OK;
 }
 
-int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32_t n_jobs,
-                    const int32_t *job_row, const int32_t *job_inc, const int64_t *job_rank,
-                    double *h_out, void *stream) {
-  if (rows < 0 || N < 1 || T < 1 || n_jobs < 0 || (n_jobs > 0 && (!job_row || !job_inc ||
-                                                                   !job_rank || !h_out)))
-    return fail(FR_E_ARG, "fr_select_ranks: bad argument");
-  if (n_jobs == 0) return FR_OK;
-  if (!d_A) return fail(FR_E_ARG, "fr_select_ranks: null device pointer");
+struct fr_selection {
+  int dev = -1, blob = -1, n_jobs = 0, n_dev = 0;
+  hipEvent_t done = nullptr;
+  std::vector<int> order, dev_of, via_succ;   // per sorted position (see fr_select_ranks_begin)
+  const double *h_out_dev = nullptr;          // page-locked: the jobs' values ...
+  const unsigned long long *h_succ = nullptr; // ... and the keys of the next order statistics
+};
+
+static void release_selection(fr_selection *sel) {
+  if (!sel) return;
+  if (sel->done) (void)hipEventDestroy(sel->done);
+  if (sel->dev >= 0 && sel->blob >= 0) {
+    std::lock_guard<std::mutex> lock(g_scratch_mu[sel->dev]);
+    g_scratch[sel->dev][sel->blob].busy = false;
+  }
+  delete sel;
+}
+
+fr_selection_t *fr_select_ranks_begin(const double *d_A, int64_t rows, int64_t N, int64_t T,
+                                      int32_t n_jobs, const int32_t *job_row, const int32_t *job_inc,
+                                      const int64_t *job_rank, void *stream) {
+  auto bad = [](int code, const std::string &msg) -> fr_selection_t * {
+    fail(code, msg);
+    return nullptr;
+  };
+  if (rows < 0 || N < 1 || T < 1 || n_jobs < 1 || !job_row || !job_inc || !job_rank)
+    return bad(FR_E_ARG, "fr_select_ranks: bad argument");
+  if (!d_A) return bad(FR_E_ARG, "fr_select_ranks: null device pointer");
   if (T >= (int64_t(1) << 31))
-    return fail(FR_E_LIMIT, "fr_select_ranks: series of 2^31 elements or more (time indices are 32-bit)");
+    return bad(FR_E_LIMIT, "fr_select_ranks: series of 2^31 elements or more (time indices are 32-bit)");
   struct HostJob {
     const double *base;
     unsigned long long prefix;
@@ -2352,13 +2380,18 @@ int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32
   for (int j = 0; j < n_jobs; ++j)
     if (job_row[j] < 0 || job_row[j] >= rows || job_inc[j] < 0 || job_inc[j] > 8 ||
         job_rank[j] < 0 || job_rank[j] >= N * T)
-      return fail(FR_E_ARG, "fr_select_ranks: job " + std::to_string(j) + " out of range");
+      return bad(FR_E_ARG, "fr_select_ranks: job " + std::to_string(j) + " out of range");
   // jobs that read the same row block share their passes over it (sorted by row, then
   // differencing order, then rank, so a group computes every difference once per element);
   // identical jobs are run once, and a job that asks for rank r + 1 of the same values as
   // its predecessor's rank r rides on it (one extra pass instead of eight: np.quantile
   // always asks for such neighbours)
-  std::vector<int> order(n_jobs);
+  fr_selection *sel = new fr_selection;
+  sel->n_jobs = n_jobs;
+  std::vector<int> &order = sel->order, &dev_of = sel->dev_of, &via_succ = sel->via_succ;
+  order.resize(n_jobs);
+  dev_of.resize(n_jobs);
+  via_succ.assign(n_jobs, 0);
   for (int j = 0; j < n_jobs; ++j) order[j] = j;
   std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
     if (job_row[x] != job_row[y]) return job_row[x] < job_row[y];
@@ -2366,7 +2399,6 @@ int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32
     return job_rank[x] < job_rank[y];
   });
   std::vector<HostJob> jobs;
-  std::vector<int> dev_of(n_jobs), via_succ(n_jobs, 0);   // per sorted position
   std::vector<int32_t> groups;  // {first, count} pairs
   std::vector<int> group_row;
   for (int s = 0; s < n_jobs; ++s) {
@@ -2400,6 +2432,7 @@ int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32
   }
   const int n_dev = (int)jobs.size();
   const int n_groups = (int)groups.size() / 2;
+  sel->n_dev = n_dev;
   // The gather pass tracks the smallest key above the bucket of the first kSelTrackJobs jobs per
   // group and differencing order that want a neighbour (pad bit 4); any further one costs a
   // pass of its own (select_succ_kernel)
@@ -2416,74 +2449,149 @@ int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32
   }
   int max_inc = 0;
   for (int j = 0; j < n_jobs; ++j) max_inc = std::max(max_inc, (int)job_inc[j]);
-  std::vector<double> dev_out(n_dev);
-  std::vector<unsigned long long> dev_succ(n_dev);
   hipStream_t st = (hipStream_t)stream;
-  // one grow-only scratch blob per device (jobs | groups | histograms | results | successors):
-  // fit calls this once per word batch and slice, and hipMalloc / hipFree synchronise
+  // device: jobs | groups | (groups still in the passes) | histograms | results | successors |
+  // counts | candidate lists; host (page-locked): jobs | groups | results | successors
   const size_t o_jobs = 0;
   const size_t o_groups = align_up(o_jobs + jobs.size() * sizeof(HostJob), 256);
-  const size_t o_groups2 = align_up(o_groups + groups.size() * 4, 256);   // (groups still in the passes)
+  const size_t o_groups2 = align_up(o_groups + groups.size() * 4, 256);
   const size_t o_hist = align_up(o_groups2 + groups.size() * 4, 256);
   const size_t o_out = align_up(o_hist + (size_t)n_dev * 256 * 4, 256);
   const size_t o_succ = align_up(o_out + (size_t)n_dev * 8, 256);
   const size_t o_cnt = align_up(o_succ + (size_t)n_dev * 8, 256);
   const size_t o_cand = align_up(o_cnt + ((size_t)n_dev + 1) * 4, 256);   // (+1: jobs left in the passes)
   const size_t need = align_up(o_cand + (size_t)n_dev * fr::kSelSmallCap * 8, 256);
+  const size_t ho_groups = align_up(jobs.size() * sizeof(HostJob), 256);
+  const size_t ho_out = align_up(ho_groups + groups.size() * 4, 256);
+  const size_t ho_succ = align_up(ho_out + (size_t)n_dev * 8, 256);
+  const size_t need_host = align_up(ho_succ + (size_t)n_dev * 8, 256);
   const int dev = current_device_id();
-  if (dev < 0 || dev >= kScratchDevices) return fail(FR_E_ARG, "fr_select_ranks: device id");
-  std::lock_guard<std::mutex> lock(g_scratch_mu[dev]);
-  Scratch &sc = g_scratch[dev];
-  if (sc.bytes < need) {
-    if (sc.ptr) (void)hipFree(sc.ptr);
-    sc.ptr = nullptr;
-    sc.bytes = 0;
-    const size_t want = std::max(need + need / 2, (size_t)32 << 20);   // (one allocation per fit: the slices' needs differ)
-    HIP_TRY(hipMalloc(&sc.ptr, want));
-    sc.bytes = want;
+  if (dev < 0 || dev >= kScratchDevices) {
+    delete sel;
+    return bad(FR_E_ARG, "fr_select_ranks: device id");
   }
-  char *b = static_cast<char *>(sc.ptr);
+  Scratch *sc = nullptr;
+  {
+    // a free blob that is large enough, else the free one that is grown (a blob in use - a
+    // selection that has begun and not ended - is never touched)
+    std::lock_guard<std::mutex> lock(g_scratch_mu[dev]);
+    int pick = -1;
+    for (int i = 0; i < kScratchBlobs && pick < 0; ++i)
+      if (!g_scratch[dev][i].busy && g_scratch[dev][i].bytes >= need && g_scratch[dev][i].host_bytes >= need_host)
+        pick = i;
+    for (int i = 0; i < kScratchBlobs && pick < 0; ++i)
+      if (!g_scratch[dev][i].busy) pick = i;
+    if (pick < 0) {
+      delete sel;
+      return bad(FR_E_LIMIT, "fr_select_ranks: " + std::to_string(kScratchBlobs) +
+                                 " selections are in flight on this device - end one first");
+    }
+    sc = &g_scratch[dev][pick];
+    if (sc->bytes < need) {
+      if (sc->ptr) (void)hipFree(sc->ptr);
+      sc->ptr = nullptr;
+      sc->bytes = 0;
+      const size_t want = std::max(need + need / 2, (size_t)32 << 20);   // (the slices' needs differ)
+      if (hipMalloc(&sc->ptr, want) != hipSuccess) {
+        (void)hipGetLastError();
+        sc->ptr = nullptr;
+        delete sel;
+        return bad(FR_E_NOMEM, "fr_select_ranks: device scratch");
+      }
+      sc->bytes = want;
+    }
+    if (sc->host_bytes < need_host) {
+      if (sc->host) (void)hipHostFree(sc->host);
+      sc->host = nullptr;
+      sc->host_bytes = 0;
+      const size_t want = std::max(need_host * 2, (size_t)1 << 20);
+      if (hipHostMalloc(&sc->host, want, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        sc->host = nullptr;
+        delete sel;
+        return bad(FR_E_NOMEM, "fr_select_ranks: page-locked scratch");
+      }
+      sc->host_bytes = want;
+    }
+    sc->busy = true;
+    sel->dev = dev;
+    sel->blob = pick;
+  }
+  char *b = static_cast<char *>(sc->ptr), *h = static_cast<char *>(sc->host);
+  std::memcpy(h, jobs.data(), jobs.size() * sizeof(HostJob));
+  std::memcpy(h + ho_groups, groups.data(), groups.size() * 4);
+  sel->h_out_dev = reinterpret_cast<const double *>(h + ho_out);
+  sel->h_succ = reinterpret_cast<const unsigned long long *>(h + ho_succ);
   hipError_t e;
-  if ((e = hipMemcpyAsync(b + o_jobs, jobs.data(), jobs.size() * sizeof(HostJob),
-                          hipMemcpyHostToDevice, st)) != hipSuccess ||
-      (e = hipMemcpyAsync(b + o_groups, groups.data(), groups.size() * 4, hipMemcpyHostToDevice,
-                          st)) != hipSuccess ||
+  if ((e = hipEventCreateWithFlags(&sel->done, hipEventDisableTiming)) != hipSuccess ||
+      (e = hipMemcpyAsync(b + o_jobs, h, jobs.size() * sizeof(HostJob), hipMemcpyHostToDevice, st)) != hipSuccess ||
+      (e = hipMemcpyAsync(b + o_groups, h + ho_groups, groups.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess ||
       (e = hipMemsetAsync(b + o_hist, 0, (size_t)n_dev * 256 * 4, st)) != hipSuccess ||
       (e = hipMemsetAsync(b + o_succ, 0xff, (size_t)n_dev * 8, st)) != hipSuccess ||
       (e = hipMemsetAsync(b + o_cnt, 0, ((size_t)n_dev + 1) * 4, st)) != hipSuccess ||
-      (e = fr::launch_select_ranks(b + o_jobs, n_dev, b + o_groups, n_groups, groups.data(),
+      // (no host copy of the groups: nothing is read back between the passes)
+      (e = fr::launch_select_ranks(b + o_jobs, n_dev, b + o_groups, n_groups, nullptr,
                                    b + o_groups2, max_inc, untracked, N, T,
                                    reinterpret_cast<unsigned int *>(b + o_hist),
                                    reinterpret_cast<double *>(b + o_out),
                                    reinterpret_cast<unsigned long long *>(b + o_succ),
                                    reinterpret_cast<unsigned long long *>(b + o_cand),
-                                   reinterpret_cast<unsigned int *>(b + o_cnt), st)) !=
-          hipSuccess ||
-      (e = hipMemcpyAsync(dev_out.data(), b + o_out, (size_t)n_dev * 8, hipMemcpyDeviceToHost,
-                          st)) != hipSuccess ||
-      (e = hipMemcpyAsync(dev_succ.data(), b + o_succ, (size_t)n_dev * 8, hipMemcpyDeviceToHost,
-                          st)) != hipSuccess ||
-      (e = hipStreamSynchronize(st)) != hipSuccess)
-    return hip_fail(e, "fr_select_ranks");
-  for (int s = 0; s < n_jobs; ++s) {
-    double v = dev_out[dev_of[s]];
-    if (via_succ[s]) {
-      const unsigned long long k = dev_succ[dev_of[s]];
-      if (k != ~0ull) {   // the order-preserving key back to the double (kernels_misc.hip)
-        const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
-        std::memcpy(&v, &u, 8);
-      }
-    }
-    h_out[order[s]] = v;
+                                   reinterpret_cast<unsigned int *>(b + o_cnt), st)) != hipSuccess ||
+      (e = hipMemcpyAsync(h + ho_out, b + o_out, (size_t)n_dev * 8, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+      (e = hipMemcpyAsync(h + ho_succ, b + o_succ, (size_t)n_dev * 8, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+      (e = hipEventRecord(sel->done, st)) != hipSuccess) {
+    // (what was queued may still run: the blob is released once the stream has drained)
+    (void)hipStreamSynchronize(st);
+    release_selection(sel);
+    hip_fail(e, "fr_select_ranks");
+    return nullptr;
   }
+  return sel;
+}
+
+int fr_select_ranks_end(fr_selection_t *sel, double *h_out) {
+  if (!sel) return fail(FR_E_ARG, "fr_select_ranks_end: null selection");
+  hipError_t e = hipEventSynchronize(sel->done);
+  if (e != hipSuccess) {
+    release_selection(sel);
+    return hip_fail(e, "fr_select_ranks_end");
+  }
+  if (h_out)
+    for (int s = 0; s < sel->n_jobs; ++s) {
+      double v = sel->h_out_dev[sel->dev_of[s]];
+      if (sel->via_succ[s]) {
+        const unsigned long long k = sel->h_succ[sel->dev_of[s]];
+        if (k != ~0ull) {   // the order-preserving key back to the double (kernels_misc.hip)
+          const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+          std::memcpy(&v, &u, 8);
+        }
+      }
+      h_out[sel->order[s]] = v;
+    }
+  release_selection(sel);
   return FR_OK;
+}
+
+int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32_t n_jobs,
+                    const int32_t *job_row, const int32_t *job_inc, const int64_t *job_rank,
+                    double *h_out, void *stream) {
+  if (n_jobs == 0 && rows >= 0 && N >= 1 && T >= 1) return FR_OK;
+  if (n_jobs > 0 && !h_out) return fail(FR_E_ARG, "fr_select_ranks: bad argument");
+  fr_selection_t *sel = fr_select_ranks_begin(d_A, rows, N, T, n_jobs, job_row, job_inc, job_rank, stream);
+  if (!sel) return g_last_code;
+  return fr_select_ranks_end(sel, h_out);
 }
 
 int fr_release_scratch(void) {
   for (int d = 0; d < kScratchDevices; ++d) {
     std::lock_guard<std::mutex> lock(g_scratch_mu[d]);
-    if (g_scratch[d].ptr) (void)hipFree(g_scratch[d].ptr);
-    g_scratch[d] = Scratch{};
+    for (int i = 0; i < kScratchBlobs; ++i) {
+      Scratch &sc = g_scratch[d][i];
+      if (sc.busy) continue;   // (a selection in flight keeps its blob)
+      if (sc.ptr) (void)hipFree(sc.ptr);
+      if (sc.host) (void)hipHostFree(sc.host);
+      sc = Scratch{};
+    }
   }
   return FR_OK;
 }

@@ -1304,6 +1304,14 @@ static hipError_t select_ranks_mi(SelJob *jb, int n_jobs, const int2 *gr, int n_
                          0, st, jb, gr, N, T, cand, cand_count, succ);
       hipLaunchKernelGGL(select_small_kernel, dim3((unsigned)n_jobs), dim3(256), 0, st, jb, cand,
                          cand_count, out, succ, cand_count + n_jobs);
+      // (h_groups == nullptr - fr_select_ranks_begin: nothing is read back, the host does not wait.
+      // The five remaining passes are launched whatever is left for them, over all groups: the
+      // workgroups of a group without a job in them leave at once - eleven launches of a few
+      // microseconds each in the usual case)
+      if (h_groups == nullptr) {
+        trailing = true;
+        continue;
+      }
       // no job left in the histogram passes (the usual case): done.  Else only the jobs with
       // too many candidates for a workgroup - heavy ties that are not ONE value - go on, and
       // the five remaining passes run over THEIR groups alone (the host reads the jobs' flags)

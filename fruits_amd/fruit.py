@@ -34,12 +34,6 @@ def _check_batch(X) -> np.ndarray:
     return X
 
 
-# one helper thread: Fruit.fit overlaps the device-side selection of a slice with the host-side
-# bookkeeping (fr_select_ranks blocks until its results are on the host)
-from concurrent.futures import ThreadPoolExecutor as _ThreadPoolExecutor
-_SELECT_POOL = _ThreadPoolExecutor(max_workers=1, thread_name_prefix="fruits-select")
-
-
 class _FittedRows:
     """The fitted sieve copies of a slice, one list per iterated sum - what fruits/fruit.py:462-476
     builds as it fits - held as ARRAYS: per sieve the thresholds of all rows, computed from the
@@ -194,9 +188,10 @@ class Fruit:
         finally:
             for finish in deferred:
                 finish()
-        # (the selection scratch of the device-side fit lives outside torch's allocator: hand it
-        # back - a transform needs none of it)
-        nat.release_scratch()
+        # (the selection scratch of the device-side fit - a blob of device and page-locked memory
+        # per slice in flight, some 50 MB each - lives outside torch's allocator and is kept for
+        # the next fit: allocating it is a millisecond per blob on the fit's critical path.
+        # fruits_amd.release_scratch() hands it back.)
         self._fitted = True
 
     def transform(self, X: np.ndarray,
@@ -445,10 +440,10 @@ class FruitSlice:
         iterated sums to the host: the order statistics np.quantile interpolates
         between are selected on the device (fr_select_ranks).  Returns False when a
         sieve or the ISS layout needs the host path.  ``deferred``: the selections are only
-        STARTED (one helper thread, in order); a closure per word batch that waits for its
-        selection and hands the thresholds to the sieve copies is appended - Fruit.fit runs them
-        when every slice has been started, so that a slice's selection runs on the device while
-        this thread is busy with the next slice."""
+        QUEUED (fr_select_ranks_begin); a closure per word batch that waits for its selection and
+        forms the thresholds is appended - Fruit.fit runs them when every slice has been queued,
+        so that the device goes from one slice's selection to the next slice's iterated sums
+        without waiting for the host."""
         from .sieving.segment import SegmentSieve
         if os.environ.get("FRUITS_AMD_DEVICE_FIT", "1") == "0" or len(self._iss) != 1:
             return False
@@ -490,10 +485,10 @@ class FruitSlice:
             rows = np.repeat(np.arange(K_rows, dtype=np.int32), J)
             incs = np.tile(np.asarray(t_inc, dtype=np.int32), K_rows)
             ranks = np.tile(np.asarray(t_rank, dtype=np.int64), K_rows)
-            # the selection runs on the device (the C call releases the interpreter lock); the
-            # thresholds of the rows are formed as arrays when it is done (_FittedRows)
-            pending = (_SELECT_POOL.submit(nat.select_ranks, block, rows, incs, ranks, nat.stream_ptr())
-                       if len(rows) else None)
+            # the selection is QUEUED (fr_select_ranks_begin: no pass waits for the host) and this
+            # thread goes on to the next slice; the thresholds of the rows are formed as arrays
+            # when somebody waits for it (_FittedRows)
+            pending = nat.Selection(block, rows, incs, ranks) if len(rows) else None
             tables = self._sieves_extended.add_rows(K_rows)
 
             def finish(pending=pending, block=block, t_pairs=t_pairs, tables=tables, asks=asks,

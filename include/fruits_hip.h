@@ -369,12 +369,25 @@ int fr_pre_transform(const double *d_A, int64_t N, int64_t T, int64_t a_stride, 
  * interpolates between the two order statistics around q*(n-1); job j returns the
  * job_rank[j]-th smallest (0-based) of the job_inc[j]-times differenced
  * (N, T) block number job_row[j] of the device tensor d_A (rows, N, T).  Exact
- * (radix select); synchronous (fit is not a capture path); its device scratch is a
- * grow-only blob per device kept between calls - fr_release_scratch frees it. */
+ * (radix select); synchronous (fit is not a capture path); its scratch is kept between calls -
+ * fr_release_scratch frees it. */
 int fr_select_ranks(const double *d_A, int64_t rows, int64_t N, int64_t T, int32_t n_jobs,
                     const int32_t *job_row, const int32_t *job_inc, const int64_t *job_rank,
                     double *h_out, void *stream);
+/* The same in two halves, for a fit of several slices (fruits/fruit.py:110-121 fits them one after
+ * the other): _begin queues every pass of the selection on `stream` and returns at once - nothing
+ * is read back between the passes - so the caller can queue the next slice's iterated sums behind
+ * it; _end waits for exactly this selection (an event), writes the n_jobs values and frees the
+ * handle (h_out NULL: only waits and frees).  d_A must stay valid until _end.  A selection in
+ * flight owns one of 8 scratch blobs per device (device memory + page-locked host memory);
+ * FR_E_LIMIT (NULL, fr_last_error) when all are taken.  fr_select_ranks = _begin + _end. */
+typedef struct fr_selection fr_selection_t;
+fr_selection_t *fr_select_ranks_begin(const double *d_A, int64_t rows, int64_t N, int64_t T,
+                                      int32_t n_jobs, const int32_t *job_row, const int32_t *job_inc,
+                                      const int64_t *job_rank, void *stream);
+int fr_select_ranks_end(fr_selection_t *selection, double *h_out);
 
+/* frees the scratch blobs no selection is using */
 int fr_release_scratch(void);
 
 /* ------------------------------------------------------------------ STD ("next" row)
