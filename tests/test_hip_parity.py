@@ -2028,6 +2028,45 @@ def test_select_ranks_against_numpy(fr):
     np.testing.assert_array_equal(got, np.array(want))
 
 
+def test_selections_in_flight(fr):
+    """fr_select_ranks_begin / _end: several selections queued behind one another (what Fruit.fit
+    does with the slices of a fruit), ended in another order; every one owns a scratch blob until it
+    is ended - the ninth in flight is refused (FR_E_LIMIT) and accepted once one has ended; a
+    handle nobody asks is released when it is dropped."""
+    from fruits_amd import _native as nat
+    rng = np.random.default_rng(21)
+    blocks, sels, wants = [], [], []
+    for i in range(8):
+        A = rng.standard_normal((2, 5 + i, 300 + 17 * i))
+        if i % 3 == 0:
+            A[0, :, ::2] = 0.25                                  # heavy ties: all eight digits
+        Ad = nat.to_device(A)
+        rows, incs, ranks, want = [], [], [], []
+        for r in range(2):
+            for inc in (0, 1):
+                flat = np.sort(orc.pre_transform(A[r], inc).ravel())
+                for k in (0, flat.size // 3, flat.size // 3 + 1, flat.size - 1):
+                    rows.append(r); incs.append(inc); ranks.append(k); want.append(flat[k])
+        blocks.append((Ad, rows, incs, ranks))
+        sels.append(nat.Selection(Ad, rows, incs, ranks))
+        wants.append(np.array(want))
+    with pytest.raises(nat.NativeError, match="in flight"):
+        nat.Selection(*blocks[0])
+    for i in (5, 0, 7):
+        np.testing.assert_array_equal(sels[i].result(), wants[i])
+        np.testing.assert_array_equal(sels[i].result(), wants[i])     # (the values stay)
+    again = nat.Selection(*blocks[0])                                  # a blob is free again
+    np.testing.assert_array_equal(again.result(), wants[0])
+    del sels[1], sels[2]                                               # dropped without a result()
+    import gc
+    gc.collect()
+    np.testing.assert_array_equal(nat.select_ranks(*blocks[3]), wants[3])
+    for i, s_ in enumerate(sels):
+        s_.result()
+    fr.release_scratch()
+    np.testing.assert_array_equal(nat.select_ranks(*blocks[4]), wants[4])
+
+
 # --------------------------------------------------------------------------
 # BASELINE configs[2..4] at their full sizes: the experiment fruits verbatim
 # --------------------------------------------------------------------------
