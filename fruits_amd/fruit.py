@@ -34,6 +34,9 @@ def _check_batch(X) -> np.ndarray:
     return X
 
 
+_SELECTIONS_IN_FLIGHT = 6     # of the 8 the library allows per device (fr_select_ranks_begin)
+
+
 class _FittedRows:
     """The fitted sieve copies of a slice, one list per iterated sum - what fruits/fruit.py:462-476
     builds as it fits - held as ARRAYS: per sieve the thresholds of all rows, computed from the
@@ -179,8 +182,7 @@ class Fruit:
         X = _check_batch(X)
         cache_ = SharedSeedCache(X) if cache is None else cache
         # the slices are started one after the other; the device-side selections of a slice's
-        # thresholds (fr_select_ranks on a helper thread) run while the next slice is set up, and
-        # are waited for at the end
+        # thresholds are only queued (fr_select_ranks_begin) and waited for at the end
         deferred: list = []
         try:
             for slc in self._slices:
@@ -505,6 +507,10 @@ class FruitSlice:
                 finish()
             else:
                 deferred.append(finish)
+                # (a selection in flight owns one of 8 scratch blobs - and its (K, N, T) block:
+                # a fruit of many slices, or a slice of many word batches, ends the oldest)
+                while len(deferred) > _SELECTIONS_IN_FLIGHT:
+                    deferred.pop(0)()
         return True
 
     # ---- fused ISS + sieves (one launch, no (K, N, T) tensor) --------------------

@@ -2028,6 +2028,34 @@ def test_select_ranks_against_numpy(fr):
     np.testing.assert_array_equal(got, np.array(want))
 
 
+def test_fit_of_many_slices(fr):
+    """A fruit of more slices than selections may be in flight: Fruit.fit ends the oldest ones as
+    it goes; the thresholds equal those of the slices fitted one by one."""
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((24, 2, 120)).cumsum(axis=2)
+    def build():
+        fruit = fr.Fruit()
+        for i in range(11):
+            fruit.cut()
+            fruit.add(fr.ISS([fr.words.SimpleWord("[1][2]"), fr.words.SimpleWord("[%d]" % (1 + i % 2))],
+                             mode=fr.ISSMode.EXTENDED))
+            fruit.add(fr.sieving.NPI(q=(0.1 + 0.07 * i, 1.0), inc=i % 3), fr.sieving.END)
+            fruit.get_slice().fit_sample_size = 1.0
+        return fruit
+    a, b = build(), build()
+    np.random.seed(0)
+    a.fit(X)
+    np.random.seed(0)
+    for slc in b:
+        slc.fit(X)
+    for sa, sb in zip(a, b):
+        assert len(sa._sieves_extended) == len(sb._sieves_extended) == sa.niteratedsums()
+        for ra, rb in zip(sa._sieves_extended, sb._sieves_extended):
+            np.testing.assert_array_equal(ra[0]._quantiles, rb[0]._quantiles)
+    b._fitted = True
+    np.testing.assert_array_equal(a.transform(X), b.transform(X))
+
+
 def test_selections_in_flight(fr):
     """fr_select_ranks_begin / _end: several selections queued behind one another (what Fruit.fit
     does with the slices of a fruit), ended in another order; every one owns a scratch blob until it
