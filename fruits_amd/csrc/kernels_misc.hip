@@ -837,6 +837,70 @@ __device__ __forceinline__ void hist_level4(const SelGroup &g, unsigned int (*lh
   }
 }
 
+// The FIRST digit (sign, seven exponent bits): every element takes part and a block sees a handful of
+// values - as LDS adds they collide (the pass was bound by LDS conflicts: 1.9 TB/s against the third
+// digit's 3.9).  A thread counts the digit's values it meets in kBinPairs register pairs per
+// differencing order and only a further value evicts one to LDS; the pairs are added to the block's
+// histogram once, at the end.
+constexpr unsigned int kBinNone = 0xffffffffu;
+// (pairs per differencing order, Fruit.fit of fruit_reduced on one box: none 19.3 ms, one 20.0, two 17.9,
+// three 18.3, four 18.5, eight 18.8 - the compares are paid per element, two pairs hold the two signs)
+constexpr int kBinPairs = 2;
+struct BinCache {
+  unsigned int bin[kBinPairs], cnt[kBinPairs];
+};
+__device__ __forceinline__ void bin_cache_add(BinCache &c, unsigned int b, unsigned int *__restrict__ row) {
+  bool hit = false;
+#pragma unroll
+  for (int i = 0; i < kBinPairs; ++i) {
+    const bool h = b == c.bin[i];
+    c.cnt[i] += h ? 1u : 0u;
+    hit = hit || h;
+  }
+  if (!hit) {   // (rare: a free pair, else the last one goes to LDS)
+    bool placed = false;
+#pragma unroll
+    for (int i = 0; i + 1 < kBinPairs; ++i)
+      if (!placed && c.bin[i] == kBinNone) {
+        c.bin[i] = b;
+        c.cnt[i] = 1u;
+        placed = true;
+      }
+    if (!placed) {
+      if (c.bin[kBinPairs - 1] != kBinNone) atomicAdd(&row[c.bin[kBinPairs - 1]], c.cnt[kBinPairs - 1]);
+      c.bin[kBinPairs - 1] = b;
+      c.cnt[kBinPairs - 1] = 1u;
+    }
+  }
+}
+template <int MI, int LVL>
+__device__ __forceinline__ void hist_first4(const SelGroup &g, unsigned int (*lh)[256], BinCache (&bc)[MI + 1],
+                                            const int (&t)[kSelUnroll], double (&v)[kSelUnroll][MI + 1]) {
+  if constexpr (LVL <= MI) {
+    if constexpr (LVL > 0) next_level4<MI, LVL>(t, v);
+    const int kb = __builtin_amdgcn_readfirstlane(g.lvl[LVL]), ke = __builtin_amdgcn_readfirstlane(g.lvl[LVL + 1]);
+    if (kb != ke) {   // (one job per order takes part in the first pass: the order's histogram)
+      unsigned int *row = lh[__builtin_amdgcn_readfirstlane(g.act[kb])];
+#pragma unroll
+      for (int u = 0; u < kSelUnroll; ++u) bin_cache_add(bc[LVL], order_key_hi(v[u][0]) >> 24, row);
+    }
+    hist_first4<MI, LVL + 1>(g, lh, bc, t, v);
+  }
+}
+template <int MI, int LVL>
+__device__ __forceinline__ void hist_first_flush(const SelGroup &g, unsigned int (*lh)[256],
+                                                 const BinCache (&bc)[MI + 1]) {
+  if constexpr (LVL <= MI) {
+    if (g.lvl[LVL] != g.lvl[LVL + 1]) {
+      unsigned int *row = lh[g.act[g.lvl[LVL]]];
+#pragma unroll
+      for (int i = 0; i < kBinPairs; ++i)
+        if (bc[LVL].bin[i] != kBinNone) atomicAdd(&row[bc[LVL].bin[i]], bc[LVL].cnt[i]);
+    }
+    hist_first_flush<MI, LVL + 1>(g, lh, bc);
+  }
+}
+
 // SHIFT: the digit when it is one of the leading dword's (the four-wide path), else 0 - then the
 // run-time `shift` counts (the low digits: jobs with heavy ties only)
 template <int MI, int SHIFT>
@@ -857,7 +921,21 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const SelJob *__restri
   if (n_act == 0) return;
   for (int j = 0; j < nj; ++j) lh[j][threadIdx.x] = 0;
   __syncthreads();
-  if constexpr (SHIFT != 0) {
+  if constexpr (SHIFT == 56 && MI <= 2) {
+    BinCache bc[MI + 1];
+#pragma unroll
+    for (int l = 0; l <= MI; ++l)
+#pragma unroll
+      for (int i = 0; i < kBinPairs; ++i) {
+        bc[l].bin[i] = kBinNone;
+        bc[l].cnt[i] = 0u;
+      }
+    for_elements<MI>(
+        jobs[jb].base, N, T,
+        [&](const int (&t)[kSelUnroll], double (&v)[kSelUnroll][MI + 1]) { hist_first4<MI, 0>(g, lh, bc, t, v); },
+        [&](int t, double (&v)[MI + 1]) { hist_level<MI, 0>(g, lh, t, v, SHIFT); });
+    hist_first_flush<MI, 0>(g, lh, bc);
+  } else if constexpr (SHIFT != 0) {
     for_elements<MI>(
         jobs[jb].base, N, T,
         [&](const int (&t)[kSelUnroll], double (&v)[kSelUnroll][MI + 1]) { hist_level4<MI, SHIFT, 0>(g, lh, t, v); },
